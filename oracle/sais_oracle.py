@@ -1,0 +1,227 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.
+
+fp32, functional (state-dict in, tensors out) restatement of the SAIS hot path.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(sais_amd/) never does and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  Every function below is checked against golden vectors produced by
+running the reference's own modules in the build container (tests/golden/make_golden.py ->
+tests/golden/*.npz; test_oracle_vs_golden.py), to <=2e-5 max-abs on activations.
+
+Paths are relative to /root/reference/SAIS/scripts.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+VIT_HEADS = 6
+T_HEADS = 4
+
+
+# --------------------------------------------------------------------------- ViT-S/16
+def vit_patch_embed(sd, x):
+    """PatchEmbed.forward — dino-main/vision_transformer.py:116-131.  Conv2d(k=16,s=16) over
+    non-overlapping patches == one GEMM on the [F*196, 768] patch matrix."""
+    Fn, C, H, W = x.shape
+    P = 16
+    gh, gw = H // P, W // P
+    patches = x.reshape(Fn, C, gh, P, gw, P).permute(0, 2, 4, 1, 3, 5).reshape(Fn, gh * gw, C * P * P)
+    w = sd["patch_embed.proj.weight"].reshape(-1, C * P * P)
+    return patches @ w.t() + sd["patch_embed.proj.bias"]
+
+
+def vit_prepare_tokens(sd, x):
+    """prepare_tokens — vision_transformer.py:196-207 (pos-embed interpolation is the identity
+    at 224x224: :177-178; pos_drop has p=0)."""
+    tok = vit_patch_embed(sd, x)
+    cls = sd["cls_token"].expand(tok.shape[0], -1, -1)
+    return torch.cat((cls, tok), dim=1) + sd["pos_embed"]
+
+
+def vit_attention(sd, pre, xn, heads=VIT_HEADS, want_probs=False):
+    """Attention.forward — vision_transformer.py:68-92."""
+    Fn, N, D = xn.shape
+    hd = D // heads
+    qkv = F.linear(xn, sd[pre + "attn.qkv.weight"], sd[pre + "attn.qkv.bias"])
+    q, k, v = qkv.reshape(Fn, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    probs = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(dim=-1)
+    ctx = (probs @ v).transpose(1, 2).reshape(Fn, N, D)
+    out = F.linear(ctx, sd[pre + "attn.proj.weight"], sd[pre + "attn.proj.bias"])
+    return out, probs, qkv, ctx
+
+
+def vit_block(sd, i, x, trace=None):
+    """Block.forward — vision_transformer.py:95-113 in eval mode (DropPath = identity),
+    LayerNorm eps 1e-6 (vit_small :243-247), exact-erf GELU (Mlp :49-65)."""
+    pre = f"blocks.{i}."
+    D = x.shape[-1]
+    xn = F.layer_norm(x, (D,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-6)
+    a, probs, qkv, ctx = vit_attention(sd, pre, xn)
+    mid = x + a
+    xn2 = F.layer_norm(mid, (D,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-6)
+    u = F.linear(xn2, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
+    h = F.gelu(u)
+    out = mid + F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    if trace is not None:
+        trace.update(norm1=xn, qkv=qkv, attn_ctx=ctx, proj=a, mid=mid, norm2=xn2, fc1=u, gelu=h, probs=probs)
+    return out
+
+
+def vit_forward(sd, x, depth=12, trace=None):
+    """VisionTransformer.forward — vision_transformer.py:209-214: CLS row of the final LN."""
+    t = vit_prepare_tokens(sd, x)
+    if trace is not None:
+        trace["tokens"] = t
+    for i in range(depth):
+        bt = {} if (trace is not None and i == 0) else None
+        t = vit_block(sd, i, t, bt)
+        if trace is not None:
+            trace[f"block{i}"] = t
+            if bt:
+                trace.update({"b0_" + k: v for k, v in bt.items()})
+    t = F.layer_norm(t, (t.shape[-1],), sd["norm.weight"], sd["norm.bias"], 1e-6)
+    return t[:, 0]
+
+
+def vit_last_selfattention(sd, x, depth=12):
+    """get_last_selfattention — vision_transformer.py:216-223 -> [F,6,197,197]."""
+    t = vit_prepare_tokens(sd, x)
+    for i in range(depth - 1):
+        t = vit_block(sd, i, t)
+    pre = f"blocks.{depth - 1}."
+    xn = F.layer_norm(t, (t.shape[-1],), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-6)
+    return vit_attention(sd, pre, xn)[1]
+
+
+# --------------------------------------------------------------------------- temporal encoder + head
+def temporal_prepare(sd, x):
+    """prepareInputForTransformer — prepare_model.py:179-195.  x [B,nsnip,T,D].  The reference
+    adds the position rows IN PLACE into the caller's tensor; the oracle (and the product) do
+    not mutate inputs — values are identical.  Padded frames also receive a
+    position row (App. B.3); RGB and flow share CLS / positions (App. B.2)."""
+    B, ns, T, D = x.shape
+    pos = torch.cat([sd[f"frame_pos_embeddings.{i}"] for i in range(T)], dim=0)       # [T,D]
+    x = x + pos.view(1, 1, T, D)
+    cls = sd["frame_cls"].view(1, 1, 1, D).expand(B, ns, 1, D)
+    return torch.cat((cls, x), dim=2)                                                  # [B,ns,T+1,D]
+
+
+def temporal_layer(sd, pre, x, key_pad, heads=T_HEADS):
+    """torch-1.8 post-norm TransformerEncoderLayer in eval mode (dropout = identity) with the
+    README.md:43-48 edit that returns the head-averaged attention map.
+    x [Bn,S,D] (batch-first here; the reference feeds [S,Bn,D] — same math), key_pad bool [Bn,S]."""
+    Bn, S, D = x.shape
+    hd = D // heads
+    qkv = F.linear(x, sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"])
+    q, k, v = qkv.reshape(Bn, S, 3, heads, hd).permute(2, 0, 3, 1, 4)                  # [Bn,h,S,hd]
+    scores = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    scores = scores.masked_fill(key_pad.view(Bn, 1, 1, S), float("-inf"))
+    probs = scores.softmax(dim=-1)
+    ctx = (probs @ v).transpose(1, 2).reshape(Bn, S, D)
+    a = F.linear(ctx, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"])
+    x = F.layer_norm(x + a, (D,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
+    ff = F.linear(F.relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])),
+                  sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
+    x = F.layer_norm(x + ff, (D,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
+    return x, probs.mean(dim=1)
+
+
+def temporal_aggregate(sd, seq, pad, nlayers=4, trace=None):
+    """aggregateInputs — prepare_model.py:197-221.  seq [B,ns,S,D], pad bool [B,ns,S].
+    Returns (full relu'd sequence [B,ns,S,D], CLS rows [B,ns,D], attn of LAST layer [B*ns,S,S])."""
+    B, ns, S, D = seq.shape
+    x = seq.reshape(B * ns, S, D)
+    kp = pad.reshape(B * ns, S)
+    attn = None
+    for l in range(nlayers):
+        x, attn = temporal_layer(sd, f"transEncoderFrame.layers.{l}.", x, kp)
+        if trace is not None:
+            trace.append(x)
+    full = F.relu(x).reshape(B, ns, S, D)
+    return full, full[:, :, 0, :], attn
+
+
+def temporal_forward(sd, x, f, xpad, fpad, modalities="RGB-Flow", nlayers=4, importance=False, trace=None):
+    """fullModel.forward, data_type='reps', encoder 'ViT', task 'Prototypes', self_attention
+    — prepare_model.py:246-448.  Tensor inputs -> (emb [B,256], attn [B*ns,S,S]); list inputs
+    (test-time augmentation, :331-346) -> (list of embs, attn of version 0)."""
+    if isinstance(x, (list, tuple)):
+        embs, attn0 = [], None
+        for v in range(len(x)):
+            e, a = temporal_forward(sd, x[v], f[v] if f is not None else None, xpad[v],
+                                    fpad[v] if fpad is not None else None, modalities, nlayers)[:2]
+            embs.append(e)
+            attn0 = a if v == 0 else attn0
+        return embs, attn0
+    full = None
+    if modalities in ("RGB", "RGB-Flow"):
+        full, rgb, attn = temporal_aggregate(sd, temporal_prepare(sd, x), xpad, nlayers, trace)
+        rep = rgb.mean(dim=1)
+    if modalities in ("Flow", "RGB-Flow"):
+        ffull, flow, fattn = temporal_aggregate(sd, temporal_prepare(sd, f), fpad, nlayers)
+        if modalities == "Flow":
+            rep, attn, full = flow.mean(dim=1), fattn, ffull
+        else:
+            rep = rep + flow.mean(dim=1)                                               # :412
+    emb = F.linear(F.relu(rep), sd["linear.weight"], sd["linear.bias"])                # :416 (double ReLU, App. B.4)
+    if importance:
+        imp = F.linear(full, sd["importance_function.weight"], sd["importance_function.bias"])   # :419-421
+        return imp, emb, attn
+    return emb, attn
+
+
+# --------------------------------------------------------------------------- SupCon / prototype head
+def proto_matrix(prototypes):
+    keys = list(prototypes.keys())
+    return torch.cat([prototypes[k].reshape(1, -1) for k in keys], dim=0), keys
+
+
+def cosine_logits(emb, prototypes):
+    """sim = s_hat . p_hat^T — prepare_miscellaneous.py:16-28 (no epsilon in the norms, App. B.10)."""
+    p, _ = proto_matrix(prototypes)
+    return (emb / emb.norm(dim=1, keepdim=True)) @ (p / p.norm(dim=1, keepdim=True)).t()
+
+
+def nce_loss(emb, labels, prototypes):
+    """calcNCELoss — prepare_miscellaneous.py:14-46: -mean log( exp(sim[i,y_i]) / sum_j exp(sim[i,j]) ),
+    column y_i = index of the prototype whose key == str(label)."""
+    sim = cosine_logits(emb, prototypes)
+    _, keys = proto_matrix(prototypes)
+    cols = torch.tensor([keys.index(str(int(l))) for l in labels])
+    e = sim.exp()
+    return -(e[torch.arange(len(cols)), cols] / e.sum(dim=1)).log().mean()
+
+
+def probs_from_logits(sim):
+    """getProbs / calcProbs — prepare_miscellaneous.py:111-126, process_inference_results.py:76-91."""
+    e = sim.exp()
+    return e / e.sum(dim=1, keepdim=True)
+
+
+# --------------------------------------------------------------------------- composition
+def e2e_forward(vit_sd, t_sd, clips, fclips, pad, modalities, nlayers=4):
+    """clips [B,T,3,224,224] -> ViT per frame -> [B,1,T,384] -> temporal encoder -> emb, attn."""
+    B, T = clips.shape[:2]
+    reps = vit_forward(vit_sd, clips.reshape(B * T, *clips.shape[2:])).reshape(B, 1, T, -1)
+    freps = None
+    if modalities == "RGB-Flow":
+        freps = vit_forward(vit_sd, fclips.reshape(B * T, *fclips.shape[2:])).reshape(B, 1, T, -1)
+    emb, attn = temporal_forward(t_sd, reps, freps, pad, pad, modalities, nlayers)
+    return reps, emb, attn
+
+
+def collate_mask(lens):
+    """createPaddingMask — prepare_dataset.py:2798-2806: bool [B,1,maxT+1], True = masked key."""
+    maxT = max(lens)
+    m = torch.zeros(len(lens), 1, maxT + 1, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        m[b, :, n + 1:] = True
+    return m
+
+
+def flops_per_frame_fwd():
+    """GEMM FLOPs (2*MAC) of one ViT-S/16 forward frame."""
+    N, D, H = 197, 384, 1536
+    blk = 2 * N * D * 3 * D + 2 * 2 * 6 * N * N * 64 + 2 * N * D * D + 2 * 2 * N * D * H
+    return 2 * 196 * 768 * D + 12 * blk

@@ -1,0 +1,347 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by RUNNING THE REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference); the GPU box never sees the
+reference, only the .npz files this script writes next to itself.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Reference entry points exercised (paths relative to /root/reference/SAIS/scripts):
+  dino-main/vision_transformer.py:243-247  vit_small -> VisionTransformer.forward :209-214,
+                                           get_last_selfattention :216-223
+  prepare_model.py:18-101,179-221,246-448  fullModel(...).forward, Prototypes branch
+  prepare_miscellaneous.py:14-46           calcNCELoss
+  prepare_dataset.py:2798-2899             loadDataloader.createPaddingMask / pad_collate
+Shims: timm / torchvision / h5py are stubbed (never touched on this path) and
+nn.TransformerEncoder(Layer).forward are monkey-patched to also return the attention map,
+which is the README.md:43-48 hand-edit of torch 1.8 restated for torch 2.10.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+
+REF = "/root/reference/SAIS/scripts"
+
+
+def import_reference():
+    for name in ("timm", "torchvision", "h5py", "cv2"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["timm"].create_model = lambda *a, **k: nn.Identity()
+    tv = sys.modules["torchvision"]
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules["torchvision.transforms"] = tv.transforms
+    sys.modules["torchvision.models"] = tv.models
+    sys.path.insert(0, os.path.join(REF, "dino-main"))
+    sys.path.insert(0, REF)
+
+    # README.md:43-48 — torch-1.8 post-norm layer that also returns the attention map
+    def layer_forward(self, src, src_mask=None, src_key_padding_mask=None, **kw):
+        src2, attn = self.self_attn(src, src, src, attn_mask=src_mask,
+                                    key_padding_mask=src_key_padding_mask, need_weights=True)
+        src = self.norm1(src + self.dropout1(src2))
+        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        src = self.norm2(src + self.dropout2(src2))
+        return src, attn
+
+    def enc_forward(self, src, mask=None, src_key_padding_mask=None, **kw):
+        out, attn = src, None
+        for mod in self.layers:
+            out, attn = mod(out, src_mask=mask, src_key_padding_mask=src_key_padding_mask)
+        if self.norm is not None:
+            out = self.norm(out)
+        return out, attn
+
+    nn.TransformerEncoderLayer.forward = layer_forward
+    nn.TransformerEncoder.forward = enc_forward
+
+    import vision_transformer as vits
+    import prepare_model
+    import prepare_miscellaneous
+    return vits, prepare_model, prepare_miscellaneous
+
+
+ROWS = [0, 1, 100, 196]          # token rows sampled from [F,197,*] activations
+
+
+def samp(t):
+    return t.detach()[:, ROWS].contiguous().numpy().astype(np.float32)
+
+
+def golden_vit(vits, out):
+    torch.manual_seed(0)
+    model = vits.vit_small(patch_size=16, drop_path_rate=0.1)
+    sd = synth.vit_state_dict(seed=0)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x = synth.clips(seed=10, B=1, T=2)[0]                       # [2,3,224,224]
+    g = {}
+    acts = {}
+
+    blk0 = model.blocks[0]
+    hooks = []
+
+    def keep(mod, out_name=None, in_name=None):
+        def fn(m, i, o):
+            if out_name:
+                acts[out_name] = o
+            if in_name:
+                acts[in_name] = i[0]
+            return None
+        hooks.append(mod.register_forward_hook(fn))
+
+    keep(model.patch_embed, "patch")
+    keep(blk0.norm1, "b0_norm1")
+    keep(blk0.attn.qkv, "b0_qkv")
+    keep(blk0.attn.proj, "b0_proj", "b0_attn_ctx")
+    keep(blk0.norm2, "b0_norm2", "b0_mid")
+    keep(blk0.mlp.act, "b0_gelu", "b0_fc1")
+    keep(blk0, "block0", "tokens")
+    keep(model.blocks[5], "block5")
+    keep(model.blocks[11], "block11")
+
+    with torch.no_grad():
+        rep = model(x)
+    for h in hooks:
+        h.remove()
+    with torch.no_grad():
+        attn = model.get_last_selfattention(x)                  # [2,6,197,197]
+    g["rep"] = rep.numpy()
+    g["patch_s"] = acts["patch"][:, [0, 1, 99, 195]].numpy()
+    for k in ("tokens", "b0_norm1", "b0_qkv", "b0_attn_ctx", "b0_proj", "b0_mid", "b0_norm2",
+              "b0_fc1", "b0_gelu", "block0", "block5", "block11"):
+        g[k + "_s"] = samp(acts[k])
+    g["attn_rows"] = attn[:, :, [0, 57, 196], :].numpy()        # [2,6,3,197]
+    g["attn_colsum"] = attn.sum(dim=2).numpy()                  # [2,6,197] checksum over queries
+    g["rows"] = np.array(ROWS)
+
+    # gradients: loss = sum(rep * w)  (drop-path is identity in eval; dropout p=0)
+    wvec = torch.randn(2, 384, generator=torch.Generator().manual_seed(77))
+    model.zero_grad()
+    rep = model(x)
+    (rep * wvec).sum().backward()
+    g["grad_wvec"] = wvec.numpy()
+    for name, p in model.named_parameters():
+        gr = p.grad
+        g["gnorm/" + name] = np.float32(gr.norm().item())
+        if gr.dim() <= 1 or name == "cls_token":
+            g["grad/" + name] = gr.numpy()
+        elif name == "pos_embed":
+            g["grad/" + name] = gr[:, ROWS].numpy()
+        elif name == "patch_embed.proj.weight":
+            g["grad/" + name] = gr[:8].numpy()
+        else:
+            g["grad/" + name] = gr[:8].numpy()                  # first 8 output rows
+    np.savez_compressed(os.path.join(out, "vit.npz"), **g)
+    print("vit.npz: rep", rep.shape, "keys", len(g))
+
+
+def build_full(prepare_model, nclasses, modalities, nlayers=4, importance=False, seed=1):
+    m = prepare_model.fullModel('reps', nclasses, 'in_vs_out', 384, 'ViT', modalities=modalities,
+                                freeze_encoder_params=True, self_attention=True, importance_loss=importance)
+    if nlayers != 4:                                             # config 1: 1-layer variant (the 4 is hard-coded :76)
+        m.transEncoderFrame.layers = m.transEncoderFrame.layers[:nlayers]
+        m.transEncoderClip.layers = m.transEncoderClip.layers[:nlayers]
+    sd = synth.temporal_state_dict(seed=seed, importance=importance, nlayers=nlayers)
+    missing = set(dict(m.state_dict()).keys()) ^ set(sd.keys())
+    assert not missing, sorted(missing)[:10]
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m
+
+
+def golden_temporal(prepare_model, misc, out):
+    g = {}
+    cases = {"T15": [15, 15, 15], "T12r": [12, 7, 10], "T9r": [9, 1, 5, 9], "T32r": [32, 20, 32, 3, 17, 32, 8, 25]}
+    for modal in ("RGB", "RGB-Flow"):
+        m = build_full(prepare_model, 2, modal)
+        for cname, lens in cases.items():
+            B, T = len(lens), max(lens)
+            x = synth.reps(seed=100 + T, B=B, T=T)
+            f = synth.reps(seed=200 + T, B=B, T=T)
+            for b, n in enumerate(lens):                        # pad_collate zero-pads (pad_sequence)
+                x[b, :, n:] = 0
+                f[b, :, n:] = 0
+            pad = synth.padding_mask(lens)
+            layer_out = []
+            hooks = [l.register_forward_hook(lambda mod, i, o: layer_out.append(o[0].detach().clone()))
+                     for l in m.transEncoderFrame.layers]
+            with torch.no_grad():
+                emb, attn = m(x.clone(), f.clone(), lens, lens, 'Prototypes', pad.clone(), pad.clone(), None)
+            for h in hooks:
+                h.remove()
+            key = f"{modal}/{cname}/"
+            g[key + "lens"] = np.array(lens)
+            g[key + "emb"] = emb.numpy()
+            g[key + "attn"] = attn.numpy()
+            # RGB stream runs first: 4 layer outputs [S,B,384] -> keep [B,S,384]
+            if modal == "RGB":
+                for li in range(4):
+                    g[key + f"rgb_layer{li}"] = layer_out[li].permute(1, 0, 2).numpy()
+    # TTA list path (prepare_model.py:331-346): 3 versions of lengths 15/12/9, attn from version 0
+    m = build_full(prepare_model, 2, "RGB-Flow")
+    xs, fs, pads, lens_l = [], [], [], []
+    for v, T in enumerate((15, 12, 9)):
+        lens = [T, T]
+        xs.append(synth.reps(seed=300 + v, B=2, T=T))
+        fs.append(synth.reps(seed=400 + v, B=2, T=T))
+        pads.append(synth.padding_mask(lens))
+        lens_l.append(lens)
+    with torch.no_grad():
+        embs, attn = m([t.clone() for t in xs], [t.clone() for t in fs], lens_l, lens_l, 'Prototypes',
+                       [p.clone() for p in pads], [p.clone() for p in pads], None)
+    for v in range(3):
+        g[f"TTA/emb{v}"] = embs[v].numpy()
+    g["TTA/attn"] = attn.numpy()
+
+    # loss / probs / grads for C in {2,3}
+    for C in (2, 3):
+        m = build_full(prepare_model, C, "RGB-Flow")
+        lens = [32, 20, 32, 3, 17, 32, 8, 25]
+        B, T = len(lens), 32
+        x = synth.reps(seed=500 + C, B=B, T=T)
+        f = synth.reps(seed=600 + C, B=B, T=T)
+        for b, n in enumerate(lens):
+            x[b, :, n:] = 0
+            f[b, :, n:] = 0
+        pad = synth.padding_mask(lens)
+        protos = nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in synth.prototypes(seed=2, nclasses=C).items()})
+        lab = synth.labels(seed=700 + C, B=B, nclasses=C)
+        names = [f"vid_{i}" for i in range(B)]
+        x_in = x.clone().requires_grad_(True)
+        # the reference adds pos embeddings IN PLACE into its input (prepare_model.py:192);
+        # feed a non-leaf copy so autograd still yields d loss / d x
+        emb, attn = m(x_in * 1.0, f.clone(), lens, lens, 'Prototypes', pad.clone(), pad.clone(), None)
+        loss = misc.calcNCELoss(0, emb, lab, names, protos, None)
+        loss.backward()
+        key = f"loss/C{C}/"
+        g[key + "lens"] = np.array(lens)
+        g[key + "labels"] = lab.numpy()
+        g[key + "emb"] = emb.detach().numpy()
+        g[key + "attn"] = attn.detach().numpy()
+        g[key + "loss"] = np.float32(loss.item())
+        with torch.no_grad():
+            p = torch.vstack(list(protos.values()))
+            sim = (emb / emb.norm(dim=1, keepdim=True)) @ (p / p.norm(dim=1, keepdim=True)).T
+            g[key + "sim"] = sim.numpy()
+            g[key + "probs"] = (sim.exp() / sim.exp().sum(1, keepdim=True)).numpy()
+        g[key + "grad_x"] = x_in.grad.numpy()
+        for k in protos.keys():
+            g[key + f"grad_proto{k}"] = protos[k].grad.numpy()
+        P = dict(m.named_parameters())
+        for n in ("linear.weight", "linear.bias", "frame_cls", "frame_pos_embeddings.0", "frame_pos_embeddings.31",
+                  "transEncoderFrame.layers.0.self_attn.in_proj_bias", "transEncoderFrame.layers.3.self_attn.in_proj_bias",
+                  "transEncoderFrame.layers.0.norm1.weight", "transEncoderFrame.layers.3.norm2.bias",
+                  "transEncoderFrame.layers.1.linear1.bias", "transEncoderFrame.layers.2.linear2.bias",
+                  "transEncoderFrame.layers.2.self_attn.out_proj.bias"):
+            g[key + "grad/" + n] = P[n].grad.numpy()
+        for n in ("transEncoderFrame.layers.0.self_attn.in_proj_weight", "transEncoderFrame.layers.3.linear1.weight",
+                  "transEncoderFrame.layers.1.linear2.weight", "transEncoderFrame.layers.2.self_attn.out_proj.weight"):
+            g[key + "grad8/" + n] = P[n].grad[:8].numpy()
+        g[key + "ngrads"] = np.int64(sum(1 for q in P.values() if q.grad is not None))
+        for n, q in P.items():
+            if q.grad is not None and not n.startswith("frame_pos_embeddings"):
+                g[key + "gnorm/" + n] = np.float32(q.grad.norm().item())
+    np.savez_compressed(os.path.join(out, "temporal.npz"), **g)
+    print("temporal.npz keys", len(g))
+
+
+def golden_collate(out):
+    import prepare_dataset
+    dl = prepare_dataset.loadDataloader.__new__(prepare_dataset.loadDataloader)
+    dl.task = 'Prototypes'
+    lens = [5, 3, 7, 1]
+    gen = torch.Generator().manual_seed(5)
+    batch = []
+    for i, n in enumerate(lens):
+        s = torch.randn(1, n, 384, generator=gen)               # nsnippets x nframes x dim
+        fl = torch.randn(1, n, 384, generator=gen)
+        imp = torch.zeros(1, n)
+        batch.append((f"v{i}", s, fl, torch.tensor(i % 2), imp, 'dom'))
+    outp = dl.pad_collate(batch)
+    names, sp, fp, ip, lab, sl, fl_, sm, fm, im, dom = outp
+    g = {"lens": np.array(lens), "snippets_padded": sp.numpy(), "snippets_mask": sm.numpy(),
+         "flows_mask": fm.numpy(), "labels": lab.numpy(), "snippets_lens": np.array(sl)}
+    np.savez_compressed(os.path.join(out, "collate.npz"), **g)
+    print("collate.npz", sp.shape, sm.shape)
+
+
+def golden_e2e(vits, prepare_model, misc, out):
+    """SURVEY §3.4 composition.  (a) config 1: B=1,T=16, 1-layer temporal encoder, RGB;
+    (b) B=2,T=4, 4 layers, RGB-Flow, with gradients through ViT + temporal + prototypes."""
+    g = {}
+    vit = vits.vit_small(patch_size=16, drop_path_rate=0.0)
+    vit.load_state_dict(synth.vit_state_dict(seed=0), strict=True)
+    vit.eval()
+
+    def run(B, T, nlayers, modal, C, tag, grads):
+        m = build_full(prepare_model, C, modal, nlayers=nlayers)
+        for p_ in m.parameters():
+            p_.grad = None
+        vit.zero_grad()
+        clips = synth.clips(seed=900 + T, B=B, T=T)
+        lens = [T] * B
+        pad = synth.padding_mask(lens)
+        protos = nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in synth.prototypes(seed=2, nclasses=C).items()})
+        lab = synth.labels(seed=800 + T, B=B, nclasses=C)
+        with torch.set_grad_enabled(grads):
+            reps = vit(clips.view(B * T, 3, 224, 224)).view(B, 1, T, 384)
+            if modal == "RGB-Flow":
+                fclips = synth.clips(seed=950 + T, B=B, T=T)
+                freps = vit(fclips.view(B * T, 3, 224, 224)).view(B, 1, T, 384)
+            else:
+                freps = reps.detach().clone()
+            emb, attn = m(reps * 1.0, freps * 1.0, lens, lens, 'Prototypes', pad.clone(), pad.clone(), None)
+            loss = misc.calcNCELoss(0, emb, lab, [f"v_{i}" for i in range(B)], protos, None)
+        p = torch.vstack(list(protos.values())).detach()
+        e = emb.detach()
+        sim = (e / e.norm(dim=1, keepdim=True)) @ (p / p.norm(dim=1, keepdim=True)).T
+        g[tag + "reps"] = reps.detach().numpy()
+        g[tag + "emb"] = e.numpy()
+        g[tag + "attn"] = attn.detach().numpy()
+        g[tag + "sim"] = sim.numpy()
+        g[tag + "loss"] = np.float32(loss.item())
+        g[tag + "labels"] = lab.numpy()
+        if grads:
+            loss.backward()
+            V = dict(vit.named_parameters())
+            for n in ("cls_token", "norm.weight", "blocks.11.mlp.fc2.bias", "blocks.0.attn.qkv.bias",
+                      "blocks.6.norm1.weight", "patch_embed.proj.bias"):
+                g[tag + "vgrad/" + n] = V[n].grad.numpy()
+            for n in ("blocks.0.attn.qkv.weight", "blocks.11.mlp.fc1.weight", "blocks.5.attn.proj.weight"):
+                g[tag + "vgrad8/" + n] = V[n].grad[:8].numpy()
+            for n, q in V.items():
+                g[tag + "vgnorm/" + n] = np.float32(q.grad.norm().item())
+            P = dict(m.named_parameters())
+            for n in ("linear.bias", "frame_cls", "frame_pos_embeddings.0",
+                      "transEncoderFrame.layers.3.norm2.bias", "transEncoderFrame.layers.0.self_attn.in_proj_bias"):
+                g[tag + "tgrad/" + n] = P[n].grad.numpy()
+            for k in protos.keys():
+                g[tag + f"grad_proto{k}"] = protos[k].grad.numpy()
+
+    run(1, 16, 1, "RGB", 2, "cfg1/", grads=False)
+    run(2, 4, 4, "RGB-Flow", 2, "train/", grads=True)
+    np.savez_compressed(os.path.join(out, "e2e.npz"), **g)
+    print("e2e.npz keys", len(g))
+
+
+def main():
+    torch.set_num_threads(8)
+    vits, prepare_model, misc = import_reference()
+    golden_vit(vits, HERE)
+    golden_temporal(prepare_model, misc, HERE)
+    golden_collate(HERE)
+    golden_e2e(vits, prepare_model, misc, HERE)
+
+
+if __name__ == "__main__":
+    main()

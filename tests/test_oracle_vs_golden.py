@@ -1,0 +1,183 @@
+"""Pins oracle/sais_oracle.py to the golden vectors the reference itself produced
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+import synth
+from oracle import sais_oracle as O
+
+TOL = 2e-5
+
+
+def close(a, b, tol=TOL):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), f"max-abs {err}"
+
+
+def test_vit_forward_and_intermediates(golden):
+    g = golden("vit")
+    sd = synth.vit_state_dict(seed=0)
+    x = synth.clips(seed=10, B=1, T=2)[0]
+    tr = {}
+    with torch.no_grad():
+        rep = O.vit_forward(sd, x, trace=tr)
+        attn = O.vit_last_selfattention(sd, x)
+    rows = list(g["rows"])
+    close(rep, g["rep"], 5e-5)
+    close(O.vit_patch_embed(sd, x)[:, [0, 1, 99, 195]], g["patch_s"])
+    for k in ("tokens", "b0_norm1", "b0_qkv", "b0_attn_ctx", "b0_proj", "b0_mid", "b0_norm2",
+              "b0_fc1", "b0_gelu", "block0", "block5", "block11"):
+        close(tr[k][:, rows], g[k + "_s"], 5e-5)
+    close(attn[:, :, [0, 57, 196], :], g["attn_rows"], 1e-6)
+    close(attn.sum(dim=2), g["attn_colsum"], 1e-5)
+
+
+def test_vit_grads(golden):
+    g = golden("vit")
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0).items()}
+    x = synth.clips(seed=10, B=1, T=2)[0]
+    rep = O.vit_forward(sd, x)
+    (rep * torch.from_numpy(g["grad_wvec"])).sum().backward()
+    for name, p in sd.items():
+        ref = g["grad/" + name]
+        gr = p.grad
+        if gr.dim() <= 1 or name == "cls_token":
+            got = gr
+        elif name == "pos_embed":
+            got = gr[:, list(g["rows"])]
+        else:
+            got = gr[:8]
+        close(got, ref, 2e-4)
+        assert abs(gr.norm().item() - g["gnorm/" + name]) <= 2e-4 * max(1.0, g["gnorm/" + name])
+
+
+def _case_inputs(lens, T):
+    B = len(lens)
+    x = synth.reps(seed=100 + T, B=B, T=T)
+    f = synth.reps(seed=200 + T, B=B, T=T)
+    for b, n in enumerate(lens):
+        x[b, :, n:] = 0
+        f[b, :, n:] = 0
+    return x, f, synth.padding_mask(lens)
+
+
+def test_temporal_forward_all_cases(golden):
+    g = golden("temporal")
+    sd = synth.temporal_state_dict(seed=1)
+    for modal in ("RGB", "RGB-Flow"):
+        for cname in ("T15", "T12r", "T9r", "T32r"):
+            key = f"{modal}/{cname}/"
+            lens = [int(v) for v in g[key + "lens"]]
+            x, f, pad = _case_inputs(lens, max(lens))
+            tr = []
+            with torch.no_grad():
+                emb, attn = O.temporal_forward(sd, x, f, pad, pad, modal, trace=tr)
+            close(emb, g[key + "emb"])
+            close(attn, g[key + "attn"], 1e-6)
+            assert np.allclose(attn.sum(-1).numpy(), 1.0, atol=1e-5)
+            if modal == "RGB":
+                for li in range(4):
+                    close(tr[li], g[key + f"rgb_layer{li}"])
+
+
+def test_temporal_tta_list_path(golden):
+    g = golden("temporal")
+    sd = synth.temporal_state_dict(seed=1)
+    xs, fs, pads = [], [], []
+    for v, T in enumerate((15, 12, 9)):
+        xs.append(synth.reps(seed=300 + v, B=2, T=T))
+        fs.append(synth.reps(seed=400 + v, B=2, T=T))
+        pads.append(synth.padding_mask([T, T]))
+    with torch.no_grad():
+        embs, attn = O.temporal_forward(sd, xs, fs, pads, pads, "RGB-Flow")
+    for v in range(3):
+        close(embs[v], g[f"TTA/emb{v}"])
+    close(attn, g["TTA/attn"], 1e-6)
+
+
+def test_loss_probs_and_grads(golden):
+    g = golden("temporal")
+    for C in (2, 3):
+        key = f"loss/C{C}/"
+        sd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+        lens = [int(v) for v in g[key + "lens"]]
+        B, T = len(lens), 32
+        x = synth.reps(seed=500 + C, B=B, T=T)
+        f = synth.reps(seed=600 + C, B=B, T=T)
+        for b, n in enumerate(lens):
+            x[b, :, n:] = 0
+            f[b, :, n:] = 0
+        x.requires_grad_(True)
+        pad = synth.padding_mask(lens)
+        protos = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(seed=2, nclasses=C).items()}
+        lab = synth.labels(seed=700 + C, B=B, nclasses=C)
+        assert (lab.numpy() == g[key + "labels"]).all()
+        emb, attn = O.temporal_forward(sd, x, f, pad, pad, "RGB-Flow")
+        loss = O.nce_loss(emb, lab, protos)
+        loss.backward()
+        close(emb, g[key + "emb"])
+        close(attn, g[key + "attn"], 1e-6)
+        close(O.cosine_logits(emb, protos), g[key + "sim"], 1e-6)
+        close(O.probs_from_logits(O.cosine_logits(emb, protos)), g[key + "probs"], 1e-6)
+        assert abs(loss.item() - float(g[key + "loss"])) < 1e-6
+        close(x.grad, g[key + "grad_x"], 1e-6)
+        for k in protos:
+            close(protos[k].grad, g[key + f"grad_proto{k}"], 1e-6)
+        for name in [k[len(key + "grad/"):] for k in g.files if k.startswith(key + "grad/")]:
+            close(sd[name].grad, g[key + "grad/" + name], 1e-6)
+        for name in [k[len(key + "grad8/"):] for k in g.files if k.startswith(key + "grad8/")]:
+            close(sd[name].grad[:8], g[key + "grad8/" + name], 1e-6)
+        # the reference's disabled DDP needed find_unused_parameters: only 83 tensors get a grad
+        assert sum(1 for p in sd.values() if p.grad is not None) == int(g[key + "ngrads"])
+
+
+def test_collate_mask(golden):
+    g = golden("collate")
+    m = O.collate_mask([int(v) for v in g["lens"]])
+    assert (m.numpy() == g["snippets_mask"]).all()
+    assert (synth.padding_mask([int(v) for v in g["lens"]]).numpy() == g["flows_mask"]).all()
+
+
+def test_e2e_composition(golden):
+    g = golden("e2e")
+    vsd = synth.vit_state_dict(seed=0)
+    # config 1: B=1, T=16, 1-layer temporal encoder, RGB
+    tsd = synth.temporal_state_dict(seed=1, nlayers=1)
+    clips = synth.clips(seed=900 + 16, B=1, T=16)
+    pad = synth.padding_mask([16])
+    with torch.no_grad():
+        reps, emb, attn = O.e2e_forward(vsd, tsd, clips, None, pad, "RGB", nlayers=1)
+    protos = synth.prototypes(seed=2, nclasses=2)
+    close(reps, g["cfg1/reps"], 1e-4)
+    close(emb, g["cfg1/emb"], 1e-4)
+    close(attn, g["cfg1/attn"], 1e-5)
+    close(O.cosine_logits(emb, protos), g["cfg1/sim"], 1e-5)
+    lab = synth.labels(seed=800 + 16, B=1)
+    assert abs(O.nce_loss(emb, lab, protos).item() - float(g["cfg1/loss"])) < 1e-5
+
+
+def test_e2e_train_grads(golden):
+    g = golden("e2e")
+    vsd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0).items()}
+    tsd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+    protos = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(seed=2, nclasses=2).items()}
+    B, T = 2, 4
+    clips, fclips = synth.clips(seed=900 + T, B=B, T=T), synth.clips(seed=950 + T, B=B, T=T)
+    pad = synth.padding_mask([T] * B)
+    reps, emb, attn = O.e2e_forward(vsd, tsd, clips, fclips, pad, "RGB-Flow")
+    lab = synth.labels(seed=800 + T, B=B)
+    loss = O.nce_loss(emb, lab, protos)
+    loss.backward()
+    close(emb, g["train/emb"], 1e-4)
+    close(O.cosine_logits(emb, protos), g["train/sim"], 1e-5)
+    assert abs(loss.item() - float(g["train/loss"])) < 1e-5
+    for k in g.files:
+        if k.startswith("train/vgrad/"):
+            close(vsd[k[len("train/vgrad/"):]].grad, g[k], 2e-4)
+        elif k.startswith("train/vgrad8/"):
+            close(vsd[k[len("train/vgrad8/"):]].grad[:8], g[k], 2e-4)
+        elif k.startswith("train/tgrad/"):
+            close(tsd[k[len("train/tgrad/"):]].grad, g[k], 2e-4)
+        elif k.startswith("train/grad_proto"):
+            close(protos[k[len("train/grad_proto"):]].grad, g[k], 2e-4)
