@@ -1,0 +1,141 @@
+/* libsais_hip.so — C ABI of the MI355X (gfx950) kernels behind the SAIS ViT-over-video hot path.
+ *
+ * The reference (danikiyasseh/SAIS) has no FFI / plugin interface: every op on this path is a stock
+ * torch.nn module executed by ATen on the CPU.  The entry points below are therefore the operator
+ * set a maintainer would bind in place of those modules; each one cites the reference code it
+ * replaces (paths relative to SAIS/scripts/).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers owned by the caller; no allocation, no host sync, no global state;
+ *   - asynchronous on the passed hipStream_t (`stream`, passed as void*); re-entrant across streams;
+ *   - returns 0 (SAIS_OK) or a negative error code, never throws;
+ *   - "bf16" = bfloat16 storage, "f32" = IEEE float; all accumulation / statistics in f32;
+ *   - row-major tensors, `ld*` = leading dimension in ELEMENTS.
+ */
+#ifndef SAIS_HIP_H
+#define SAIS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAIS_ABI_VERSION 1
+int sais_abi_version(void);
+
+/* ---------------------------------------------------------------- GEMM  C = A . B^T (+epilogue)
+ * Replaces nn.Linear.forward everywhere on the path:
+ *   dino-main/vision_transformer.py:59-65 (Mlp fc1/fc2), :80-92 (Attention qkv/proj), :128-131
+ *   (PatchEmbed conv == GEMM on patches); prepare_model.py:74-81 (TransformerEncoderLayer in_proj /
+ *   out_proj / linear1 / linear2).  With the transposed weight it is also dX = dY . W.          */
+enum {
+    SAIS_EPI_BIAS_BF16 = 0,       /* out bf16 = acc + bias                                           */
+    SAIS_EPI_BIAS_RELU_BF16 = 1,  /* out bf16 = relu(acc + bias)                                     */
+    SAIS_EPI_BIAS_F32 = 2,        /* out f32  = acc + bias                                           */
+    SAIS_EPI_BIAS_RESID_F32 = 3,  /* out f32  = aux(f32) + acc + bias ; out2 (optional) same in bf16 */
+    SAIS_EPI_BIAS_GELU_BF16 = 4,  /* out bf16 = gelu_erf(acc + bias) ; out2 (optional) = acc + bias  */
+    SAIS_EPI_DGELU_BF16 = 5,      /* out bf16 = acc * gelu'(aux bf16)                                */
+    SAIS_EPI_DRELU_BF16 = 6,      /* out bf16 = acc * (aux bf16 > 0)                                 */
+    SAIS_EPI_PATCH_F32 = 7        /* patch-embed: row f*grp_in+q -> token row f*grp_out+q+grp_off,
+                                     out f32 = acc + bias + aux(f32 pos)[q+grp_off]                  */
+};
+
+typedef struct SaisGemm {
+    const void* A; int lda;        /* bf16 [M,K]                         */
+    const void* B; int ldb;        /* bf16 [N,K]  (nn.Linear weight)     */
+    int M, N, K;                   /* N % 128 == 0, K % 64 == 0          */
+    int epilogue;                  /* SAIS_EPI_*                         */
+    const float* bias;             /* f32 [N] or NULL                    */
+    void* out; int ldo;
+    void* out2; int ldo2;
+    const void* aux; int ldaux;
+    int grp_in, grp_out, grp_off;  /* SAIS_EPI_PATCH_F32 only            */
+} SaisGemm;
+
+int sais_gemm_nt(const SaisGemm* g, void* stream);
+
+/* dW[N1,N2] += P[M,N1]^T . Q[M,N2]  and (db != NULL)  db[N1] += column sums of P.
+ * Weight / bias gradients of every nn.Linear above (autograd of F.linear).  Accumulates with f32
+ * atomics into dW/db (caller zeroes them: optimizer.zero_grad(), perform_training.py:155).        */
+int sais_gemm_tn(const void* P, int ldp, const void* Q, int ldq, int M, int N1, int N2,
+                 float* dW, int ldw, float* db, int nsplit, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm over dim = 384
+ * nn.LayerNorm in Block / final norm (vision_transformer.py:99,103,107-113,212; eps 1e-6 from
+ * vit_small :243-247) and norm1/norm2 of the post-norm TransformerEncoderLayer (prepare_model.py:74-81;
+ * eps 1e-5).  Row r of x starts at x + r*ldx (so the CLS-only final norm is ldx = 197*384).
+ * Outputs are optional (NULL): y_bf16 feeds the next MFMA GEMM, y_f32 is the post-norm residual,
+ * mean/rstd are saved for backward.                                                              */
+int sais_layernorm_fwd(const float* x, long ldx, int rows, int dim, const float* gamma, const float* beta,
+                       float eps, void* y_bf16, long ldy16, float* y_f32, long ldy32, float* mean, float* rstd,
+                       void* stream);
+/* dy = dy_bf16 (optional) + dy_f32 (optional);  dx = dres (optional) + dLN(dy);  dgamma/dbeta += (atomics). */
+int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float* dy_f32, long lddy32, const float* x, long ldx,
+                       const float* mean, const float* rstd, const float* gamma, const float* dres, long lddres,
+                       int rows, int dim, float* dx_f32, long lddx32, void* dx_bf16, long lddx16, float* dgamma,
+                       float* dbeta, void* stream);
+
+/* ---------------------------------------------------------------- ViT spatial attention (197 tokens, 6 heads x 64)
+ * Attention.forward core, vision_transformer.py:83-90: softmax(q k^T / 8) v per (frame, head).
+ * qkv bf16 [frames*197, 3*384] laid out as the qkv Linear writes it (q | k | v, head-major inside).
+ * out bf16 [frames*197, 384]; lse f32 [frames,6,197] (saved for backward, optional);
+ * probs f32 [frames,6,197,197] (optional: get_last_selfattention, :216-223).                      */
+int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, float* lse, float* probs,
+                      void* stream);
+/* dqkv bf16 [frames*197, 1152] from dout bf16 [frames*197, 384]; delta_ws f32 [frames,6,197] scratch. */
+int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const float* lse, float* delta_ws,
+                      int frames, void* dqkv, long lddqkv, void* stream);
+
+/* ---------------------------------------------------------------- ViT embedding glue
+ * PatchEmbed + prepare_tokens, vision_transformer.py:116-131,196-207.                            */
+int sais_patchify(const float* frames_f32 /*[F,3,224,224]*/, int frames, void* patches_bf16 /*[F*196,768]*/, void* stream);
+int sais_vit_cls_rows(const float* cls, const float* pos0, float* tokens, long frame_stride, int frames, int dim,
+                      void* stream);
+/* dcls/dpos += reductions of dtokens f32 [F,ntok,dim]; dpatch_bf16 [F*(ntok-1), dim] = rows 1.. (dY of patch GEMM) */
+int sais_vit_embed_bwd(const float* dtokens, int frames, int ntok, int dim, float* dcls, float* dpos,
+                       void* dpatch_bf16, void* stream);
+
+/* ---------------------------------------------------------------- optimizer + weight shadows
+ * optim.SGD(params, lr) — prepare_model.py:566-567, perform_training.py:155-158 (no momentum / wd).
+ * param -= lr * grad_scale * grad; shadow_bf16 (optional) refreshed in the same pass.            */
+int sais_sgd_step(float* param, const float* grad, void* shadow_bf16, long n, float lr, float grad_scale, void* stream);
+int sais_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
+int sais_transpose_cast_bf16(const float* src, int rows, int cols, void* dst_bf16 /*[cols,rows]*/, void* stream);
+int sais_scale_f32(float* p, long n, float s, void* stream);
+
+/* ---------------------------------------------------------------- temporal encoder glue (dim 384, 4 heads x 96)
+ * prepareInputForTransformer, prepare_model.py:179-195: z[b,0] = frame_cls, z[b,1+t] = x[b,t] + pos[t]
+ * (out of place: the reference's in-place += on the caller's tensor is NOT reproduced).          */
+int sais_temporal_prepare_fwd(const float* x, long x_clip_stride, long x_frame_stride, const float* pos /*[T,384]*/,
+                              const float* cls, int B, int T, float* z_f32, void* z_bf16, void* stream);
+int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf16 /*optional, added*/, int B, int T, float* dx,
+                              long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos, float* dcls,
+                              void* stream);
+/* nn.MultiheadAttention core of the torch-1.8 post-norm TransformerEncoderLayer (prepare_model.py:74-81,
+ * called at :213) in eval mode: q scaled by 96^-0.5, key_pad[b][j] != 0 -> -inf, softmax, P v.
+ * attn_avg f32 [B,S,S] (optional) = P averaged over the 4 heads = the README.md:43-48 attention map. */
+#define SAIS_TEMPORAL_MAX_S_FWD 96
+#define SAIS_TEMPORAL_MAX_S_BWD 64
+int sais_temporal_attn_fwd(const void* qkv_bf16 /*[B*S,1152]*/, const unsigned char* key_pad /*[B,S]*/, int B, int S,
+                           void* ctx_bf16 /*[B*S,384]*/, float* attn_avg, void* stream);
+int sais_temporal_attn_bwd(const void* qkv_bf16, const unsigned char* key_pad, int B, int S, const void* dctx_bf16,
+                           void* dqkv_bf16, void* stream);
+
+/* ---------------------------------------------------------------- head + SupCon / prototype loss
+ * fullModel.forward Prototypes branch, prepare_model.py:215,220,381-416:
+ *   rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = linear(relu(rep))   (256 outputs)        */
+int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, int B, const float* W /*[256,384]*/,
+                  const float* bias, float* rep /*[B,384] saved*/, float* emb /*[B,256]*/, void* stream);
+int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb, const float* z_flow,
+                  long clip_stride, int B, float* dW, float* dbias, float* dz_rgb, float* dz_flow, void* stream);
+/* calcNCELoss / getProbs, prepare_miscellaneous.py:14-46,111-126: sim = s_hat p_hat^T (the class logits),
+ * probs = softmax(sim), loss = -mean log probs[i, label_col[i]].  With demb != NULL also the gradients:
+ * demb (written) and dprotos (accumulated), both scaled by loss_scale.                            */
+int sais_nce(const float* emb /*[B,256]*/, const float* protos /*[C,256]*/, const int* label_col, int B, int C,
+             float* sim, float* probs, float* loss, float* demb, float* dprotos, float loss_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

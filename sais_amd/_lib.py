@@ -1,0 +1,87 @@
+"""ctypes binding of libsais_hip.so (the C ABI declared in include/sais_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a kernel launch fails, this
+module raises.  (tests/ use oracle/ as the checker; nothing here imports it.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsais_hip.so")
+
+c_void_p, c_int, c_long, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+
+class SaisGemm(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("ldb", c_int),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("epilogue", c_int),
+                ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int),
+                ("out2", c_void_p), ("ldo2", c_int), ("aux", c_void_p), ("ldaux", c_int),
+                ("grp_in", c_int), ("grp_out", c_int), ("grp_off", c_int)]
+
+
+EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
+EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
+
+# name -> argtypes; every symbol include/sais_hip.h declares (checked by tests/test_abi.py)
+SIGNATURES = {
+    "sais_abi_version": [],
+    "sais_gemm_nt": [ctypes.POINTER(SaisGemm), c_void_p],
+    "sais_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "sais_layernorm_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p,
+                           c_long, c_void_p, c_void_p, c_void_p],
+    "sais_layernorm_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
+                           c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
+                           c_void_p],
+    "sais_vit_attn_fwd": [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
+    "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p],
+    "sais_patchify": [c_void_p, c_int, c_void_p, c_void_p],
+    "sais_vit_cls_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
+    "sais_vit_embed_bwd": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sais_sgd_step": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_void_p],
+    "sais_cast_bf16": [c_void_p, c_void_p, c_long, c_void_p],
+    "sais_transpose_cast_bf16": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "sais_scale_f32": [c_void_p, c_long, c_float, c_void_p],
+    "sais_temporal_prepare_fwd": [c_void_p, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p],
+    "sais_temporal_prepare_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_long, c_long, c_int, c_void_p,
+                                  c_void_p, c_void_p],
+    "sais_temporal_attn_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sais_temporal_attn_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sais_head_fwd": [c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sais_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p,
+                      c_void_p, c_void_p],
+    "sais_nce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                 c_float, c_void_p],
+}
+
+_lib = None
+
+
+class SaisHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libsais_hip.so and bind every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SaisHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sais_amd/csrc`).  There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise SaisHipError(f"{name} failed with code {rc}")
+    return rc

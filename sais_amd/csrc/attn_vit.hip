@@ -1,0 +1,312 @@
+// Spatial self-attention of the DINO ViT (197 tokens, head_dim 64) for gfx950: forward and backward.
+//   Attention.forward — dino-main/vision_transformer.py:80-92:
+//       attn = softmax(q k^T * 64^-0.5);  x = attn v   (per frame, per head; no mask, dropout p = 0)
+// One 256-thread workgroup per (frame, head): the whole K and V of a head (197 x 64 bf16 = 25 KiB
+// each) sit in LDS, so the 197x197 score matrix never touches HBM and softmax is exact (no online
+// rescale): every 16-query tile holds its full 16 x 208 score strip in 52 accumulator VGPRs.
+//
+// LDS image: 160-B rows (64 bf16 + 16 pad).  That stride is conflict-free BOTH for ds_read_b128 row
+// fragments (K as MFMA operand over d) and for ds_read_b64_tr_b16 transposed fragments (V^T / K^T /
+// Q^T / dO^T as MFMA operand over tokens), so one image serves both uses.
+//
+// Orientation: scores are computed transposed, S^T = K Q^T (key on accumulator rows, query on the
+// lane), so that P^T is already the B operand of O^T = V^T P^T with no lane movement; the k-slot
+// map of that product is  element e of lane group g  <->  key 32 s + 16 (e>>2) + 4 g + (e&3).
+#include "common.hpp"
+#include "../../include/sais_hip.h"
+
+namespace {
+constexpr int NTOK = 197, HD = 64, NH = 6, DM = 384;
+constexpr int ROWB = 160;                 // LDS row stride in bytes
+constexpr int NKT = 13;                   // 16-key tiles (208 >= 197)
+constexpr int NKS = 7;                    // 32-key k-steps (224)
+constexpr int TILE_ROWS = 224;
+constexpr int MAT_BYTES = TILE_ROWS * ROWB;   // 35840
+constexpr float LOG2E = 1.4426950408889634f;
+
+// stage rows [0,197) x 64 bf16 of a [M, ld] matrix (column offset applied by caller) into LDS, zero-fill pad rows
+DEVINL void stage_matrix(char* lds, const bf16* src, long ld, int tid) {
+    const int c = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        int r = r0 + 32 * i;
+        u32x4 v = r < NTOK ? *(const u32x4*)(src + (size_t)r * ld + c * 8) : u32x4{0, 0, 0, 0};
+        *(u32x4*)(lds + r * ROWB + c * 16) = v;
+    }
+}
+
+DEVINL bf16x8 row_frag(const char* lds, int row, int chunk) { return *(const bf16x8*)(lds + row * ROWB + chunk * 16); }
+
+// transposed fragment for k-step s (32 tokens) and 16-wide column tile ct
+DEVINL bf16x8 tr_frag(const char* lds, int s, int ct, int g, int li) {
+    const char* p = lds + (32 * s + 4 * g + (li >> 2)) * ROWB + (16 * ct + 4 * (li & 3)) * 2;
+    return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * ROWB));
+}
+
+DEVINL float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+DEVINL float group_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+
+DEVINL bf16x8 pack_p(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = (bf16)a[i]; r[4 + i] = (bf16)b[i]; }
+    return r;
+}
+
+// S^T strip for one 16-query tile: s[t][r] = score(key 16 t + 4 g + r, query q0 + li), masked to -inf past 197
+DEVINL void score_strip(const char* sK, const bf16x8 (&fq)[2], int g, int li, f32x4 (&s)[NKT]) {
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+        f32x4 a = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) a = mfma16(row_frag(sK, 16 * t + li, 4 * ks + g), fq[ks], a);
+        s[t] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (192 + 4 * g + r >= NTOK) s[NKT - 1][r] = -INFINITY;
+}
+
+DEVINL void load_q_frags(const bf16* base, long ld, int q, int g, bf16x8 (&f)[2]) {
+    const bf16* p = base + (size_t)(q < NTOK ? q : NTOK - 1) * ld + 8 * g;
+    f[0] = *(const bf16x8*)p;
+    f[1] = *(const bf16x8*)(p + 32);
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq, bf16* out, long ldo, float* lse,
+                                                       float* probs, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + MAT_BYTES;
+    const int h = blockIdx.x, f = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
+    stage_matrix(sK, base + DM, ldq, tid);
+    stage_matrix(sV, base + 2 * DM, ldq, tid);
+    __syncthreads();
+    const float c = scale * LOG2E;
+    for (int qt = wid; qt < NKT; qt += 4) {
+        const int q = qt * 16 + li;
+        bf16x8 fq[2];
+        load_q_frags(base, ldq, q, g, fq);
+        f32x4 s[NKT];
+        score_strip(sK, fq, g, li, s);
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
+        m = group_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float e = exp2f((s[t][r] - m) * c); s[t][r] = e; sum += e; }
+        sum = group_sum(sum);
+        const float inv = 1.0f / sum;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+        const f32x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 pf = pack_p(s[2 * ks], (2 * ks + 1 < NKT) ? s[2 * ks + 1] : z4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(sV, ks, dt, g, li), pf, o[dt]);
+        }
+        if (q < NTOK) {
+            bf16* orow = out + ((size_t)f * NTOK + q) * ldo + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[dt][r] * inv);
+                *(bf16x4*)(orow + 16 * dt) = v;
+            }
+            if (lse && g == 0) lse[((size_t)f * NH + h) * NTOK + q] = m * scale + __logf(sum);
+            if (probs) {
+                float* pr = probs + (((size_t)f * NH + h) * NTOK + q) * NTOK;
+#pragma unroll
+                for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int key = 16 * t + 4 * g + r;
+                        if (key < NTOK) pr[key] = s[t][r] * inv;
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward, dQ
+// Same orientation as forward (query on the lane).  P^T is rebuilt from the saved log-sum-exp,
+// dP^T = V dO^T, delta_q = sum_k P dP, dS^T = P (dP - delta) scale, dQ^T = K^T dS^T.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+                                                          const float* lse, float* delta, bf16* dqkv, long lddq,
+                                                          float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sK = smem;
+    char* sV = smem + MAT_BYTES;
+    const int h = blockIdx.x, f = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
+    const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
+    stage_matrix(sK, base + DM, ldq, tid);
+    stage_matrix(sV, base + 2 * DM, ldq, tid);
+    __syncthreads();
+    const float c = scale * LOG2E;
+    for (int qt = wid; qt < NKT; qt += 4) {
+        const int q = qt * 16 + li, qc = q < NTOK ? q : NTOK - 1;
+        bf16x8 fq[2], fdo[2];
+        load_q_frags(base, ldq, q, g, fq);
+        load_q_frags(dob, ldo, q, g, fdo);
+        const float l2 = lse[((size_t)f * NH + h) * NTOK + qc] * LOG2E;
+        f32x4 s[NKT];
+        score_strip(sK, fq, g, li, s);
+        float dl = 0.f;
+        f32x4 dp[NKT];
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            f32x4 a = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a = mfma16(row_frag(sV, 16 * t + li, 4 * ks + g), fdo[ks], a);
+            dp[t] = a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float p = exp2f(s[t][r] * c - l2); s[t][r] = p; dl += p * a[r]; }
+        }
+        dl = group_sum(dl);
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dl) * scale;
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
+        const f32x4 z4 = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 pf = pack_p(s[2 * ks], (2 * ks + 1 < NKT) ? s[2 * ks + 1] : z4);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(sK, ks, dt, g, li), pf, o[dt]);
+        }
+        if (q < NTOK) {
+            bf16* orow = dqkv + ((size_t)f * NTOK + q) * lddq + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16)o[dt][r];
+                *(bf16x4*)(orow + 16 * dt) = v;
+            }
+            if (g == 0) delta[((size_t)f * NH + h) * NTOK + q] = dl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward, dK / dV
+// Key on the lane: S = Q K^T and dP = dO V^T put P / dS in exactly the B-operand layout of
+// dV^T = dO^T P and dK^T = Q^T dS (sum over queries).  Each wave owns key tiles {w, w+4, ...} and
+// sweeps the 7 query k-steps; Q and dO of the head live in LDS (row + transposed reads).
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+                                                           const float* lse, const float* delta, bf16* dqkv,
+                                                           long lddq, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sQ = smem;
+    char* sO = smem + MAT_BYTES;
+    float* sL = (float*)(smem + 2 * MAT_BYTES);     // lse * log2e   [224]
+    float* sD = sL + TILE_ROWS;                     // delta         [224]
+    const int h = blockIdx.x, f = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
+    const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
+    const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
+    stage_matrix(sQ, base, ldq, tid);
+    stage_matrix(sO, dob, ldo, tid);
+    if (tid < TILE_ROWS) {
+        bool ok = tid < NTOK;
+        size_t idx = ((size_t)f * NH + h) * NTOK + tid;
+        sL[tid] = ok ? lse[idx] * LOG2E : INFINITY;     // exp2(-inf) = 0 for pad queries
+        sD[tid] = ok ? delta[idx] : 0.f;
+    }
+    __syncthreads();
+    const float c = scale * LOG2E;
+    for (int kt = wid; kt < NKT; kt += 4) {
+        const int key = kt * 16 + li;
+        bf16x8 fk[2], fv[2];
+        load_q_frags(base + DM, ldq, key, g, fk);
+        load_q_frags(base + 2 * DM, ldq, key, g, fv);
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll 1
+        for (int qs = 0; qs < NKS; ++qs) {
+            f32x4 p[2], ds[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qrow = 32 * qs + 16 * u;          // query tile base; lane holds q = qrow + 4 g + r
+                f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    a = mfma16(row_frag(sQ, qrow + li, 4 * ks + g), fk[ks], a);     // S[q][key]
+                    b = mfma16(row_frag(sO, qrow + li, 4 * ks + g), fv[ks], b);     // dP[q][key]
+                }
+                f32x4 l4 = *(const f32x4*)(sL + qrow + 4 * g);
+                f32x4 d4 = *(const f32x4*)(sD + qrow + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pv = exp2f(a[r] * c - l4[r]);
+                    p[u][r] = pv;
+                    ds[u][r] = pv * (b[r] - d4[r]) * scale;
+                }
+            }
+            bf16x8 pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = mfma16(tr_frag(sO, qs, dt, g, li), pf, dv[dt]);            // dV^T[d][key]
+                dk[dt] = mfma16(tr_frag(sQ, qs, dt, g, li), dsf, dk[dt]);           // dK^T[d][key]
+            }
+        }
+        if (key < NTOK) {
+            bf16* krow = dqkv + ((size_t)f * NTOK + key) * lddq + DM + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 a, b;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = (bf16)dk[dt][r]; b[r] = (bf16)dv[dt][r]; }
+                *(bf16x4*)(krow + 16 * dt) = a;
+                *(bf16x4*)(krow + DM + 16 * dt) = b;
+            }
+        }
+    }
+}
+
+constexpr int FWD_LDS = 2 * MAT_BYTES;
+constexpr int DKV_LDS = 2 * MAT_BYTES + 2 * TILE_ROWS * 4;
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? SAIS_OK : SAIS_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, float* lse,
+                                 float* probs, void* stream) {
+    if (!qkv || !out || frames <= 0 || (ldqkv & 7) || (ldo & 3)) return SAIS_ERR_ARG;
+    if (set_lds(attn_fwd_kernel, FWD_LDS)) return SAIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(NH, frames), dim3(256), FWD_LDS, (hipStream_t)stream, (const bf16*)qkv,
+                       ldqkv, (bf16*)out, ldo, lse, probs, 0.125f);
+    return sais_check_launch();
+}
+
+extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const float* lse,
+                                 float* delta_ws, int frames, void* dqkv, long lddqkv, void* stream) {
+    if (!qkv || !dout || !lse || !delta_ws || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) || (lddqkv & 3))
+        return SAIS_ERR_ARG;
+    if (set_lds(attn_bwd_dq_kernel, FWD_LDS) || set_lds(attn_bwd_dkv_kernel, DKV_LDS)) return SAIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(NH, frames), dim3(256), FWD_LDS, (hipStream_t)stream,
+                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, lse, delta_ws, (bf16*)dqkv, lddqkv, 0.125f);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(NH, frames), dim3(256), DKV_LDS, (hipStream_t)stream,
+                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, lse, delta_ws, (bf16*)dqkv, lddqkv, 0.125f);
+    return sais_check_launch();
+}

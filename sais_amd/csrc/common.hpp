@@ -1,0 +1,65 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of the SAIS hot path.
+// Wave = 64 lanes; MFMA = v_mfma_f32_16x16x32_bf16 (fp32 accumulate) unless stated otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define SAIS_OK 0
+#define SAIS_ERR_ARG (-1)
+#define SAIS_ERR_LAUNCH (-2)
+
+#define DEVINL __device__ __forceinline__
+
+// D[i][j] += sum_k A[i][k] B[k][j]; lane l holds A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15],
+// D[i=4*(l>>4)+r][j=l&15]  (cdna_hip_programming.md §3).
+DEVINL f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block of 16-bit elements, delivered
+// column-major: lane 4q+p supplies the address of row q, cols 4p..4p+3; lane i receives
+// column i of the 4 rows (row q in element q).  EXEC must be all ones; address 8-B aligned.
+DEVINL bf16x4 lds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(p));
+}
+
+DEVINL bf16x8 cat4(bf16x4 a, bf16x4 b) {
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+DEVINL bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16)0.0f;
+    return z;
+}
+
+DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+DEVINL float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+DEVINL float dgelu_erf(float u) {
+    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+}
+
+static inline int sais_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SAIS_OK : SAIS_ERR_LAUNCH;
+}

@@ -1,0 +1,345 @@
+// bf16 MFMA GEMMs for the SAIS hot path (gfx950).
+//
+//  sais_gemm_nt : C[M,N] = A[M,K] . B[N,K]^T  (+ fused epilogue)  — every nn.Linear forward
+//                 (vision_transformer.py:59-65,80-92; prepare_model.py:74-81,416) and, fed with the
+//                 pre-transposed weight, every dX = dY . W.
+//  sais_gemm_tn : dW[N1,N2] += P[M,N1]^T . Q[M,N2],  db[N1] += colsum(P) — every weight/bias gradient.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
+// 16x16x32 tiles, 64 fp32 accumulator VGPRs), BK = 64, two LDS stages (64 KiB), one barrier per K-step,
+// global->register->LDS staging issued before the MFMAs of the current step.
+// LDS image: 128-B rows, 16-B chunk index XOR (row & 7)  -> conflict-free ds_read_b128 fragment reads.
+// Operands are swapped in the MFMA (weights as "A", activations as "B") and weight rows are permuted
+// while staging so that every lane ends up with 16 CONTIGUOUS output columns of one output row:
+// epilogue stores are 32-B (bf16) / 64-B (fp32) per lane, a full 128-B line per row per wave.
+#include "common.hpp"
+#include "../../include/sais_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand per stage
+
+struct NtParams {
+    const bf16* A; const bf16* B;
+    int lda, ldb, M, N, K;
+    const float* bias;
+    void* out; int ldo;
+    void* out2; int ldo2;
+    const void* aux; int ldaux;
+    int grp_in, grp_out, grp_off;
+};
+
+DEVINL int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// weight-row permutation inside a 64-row wave panel: n_local = 16a + 4t + b  ->  LDS row 16t + 4a + b
+DEVINL int perm_row(int n) { return (n & 64) | ((n & 0x0c) << 2) | ((n & 0x30) >> 2) | (n & 3); }
+
+template <int EPI>
+DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16]) {
+    // one output row m, 16 contiguous columns n..n+15 (n multiple of 16)
+    float b[16];
+    if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 t = *(const f32x4*)(p.bias + n + 4 * i);
+            b[4 * i] = t[0]; b[4 * i + 1] = t[1]; b[4 * i + 2] = t[2]; b[4 * i + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = 0.f;
+    }
+    float y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) y[i] = v[i] + b[i];
+
+    auto store_bf16 = [&](void* base, int ld, const float (&z)[16]) {
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { lo[i] = (bf16)z[i]; hi[i] = (bf16)z[8 + i]; }
+        bf16* o = (bf16*)base + (size_t)m * ld + n;
+        *(bf16x8*)o = lo;
+        *(bf16x8*)(o + 8) = hi;
+    };
+    auto store_f32 = [&](void* base, int ld, size_t row, const float (&z)[16]) {
+        float* o = (float*)base + row * ld + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(o + 4 * i) = f32x4{z[4 * i], z[4 * i + 1], z[4 * i + 2], z[4 * i + 3]};
+    };
+
+    if constexpr (EPI == SAIS_EPI_BIAS_BF16) {
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_RELU_BF16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[i] = fmaxf(y[i], 0.f);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_F32) {
+        store_f32(p.out, p.ldo, m, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
+        const float* r = (const float*)p.aux + (size_t)m * p.ldaux + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 t = *(const f32x4*)(r + 4 * i);
+            y[4 * i] += t[0]; y[4 * i + 1] += t[1]; y[4 * i + 2] += t[2]; y[4 * i + 3] += t[3];
+        }
+        store_f32(p.out, p.ldo, m, y);
+        if (p.out2) store_bf16(p.out2, p.ldo2, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
+        if (p.out2) store_bf16(p.out2, p.ldo2, y);          // pre-activation u (training)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[i] = gelu_erf(y[i]);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
+        const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;
+        bf16x8 u0 = *(const bf16x8*)u, u1 = *(const bf16x8*)(u + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { y[i] *= dgelu_erf((float)u0[i]); y[8 + i] *= dgelu_erf((float)u1[i]); }
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_DRELU_BF16) {
+        const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;   // post-ReLU activation
+        bf16x8 u0 = *(const bf16x8*)u, u1 = *(const bf16x8*)(u + 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { y[i] = (float)u0[i] > 0.f ? y[i] : 0.f; y[8 + i] = (float)u1[i] > 0.f ? y[8 + i] : 0.f; }
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_PATCH_F32) {
+        // input row m = f*grp_in + q  ->  token row f*grp_out + q + grp_off ; + pos[q + grp_off][n]
+        int f = m / p.grp_in, q = m - f * p.grp_in;
+        const float* pos = (const float*)p.aux + (size_t)(q + p.grp_off) * p.ldaux + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 t = *(const f32x4*)(pos + 4 * i);
+            y[4 * i] += t[0]; y[4 * i + 1] += t[1]; y[4 * i + 2] += t[2]; y[4 * i + 3] += t[3];
+        }
+        store_f32(p.out, p.ldo, (size_t)f * p.grp_out + q + p.grp_off, y);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+
+    // staging map: 4 x (row = tid>>3 + 32 i, 16-B chunk = tid&7)
+    const int sc = tid & 7, sr = tid >> 3;
+    const bf16* ag[4]; const bf16* bg[4];
+    int a_lds[4], b_lds[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = sr + 32 * i;
+        int m = m0 + r;
+        a_ok[i] = m < p.M;
+        ag[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda + sc * 8;
+        bg[i] = p.B + (size_t)(n0 + r) * p.ldb + sc * 8;
+        a_lds[i] = swz(r, sc);
+        b_lds[i] = TILE_BYTES + swz(perm_row(r), sc);
+    }
+    u32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = a_ok[i] ? *(const u32x4*)(ag[i] + k0) : u32x4{0, 0, 0, 0};
+            rb[i] = *(const u32x4*)(bg[i] + k0);
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* s = smem + stage * 2 * TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)(s + a_lds[i]) = ra[i];
+            *(u32x4*)(s + b_lds[i]) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    const int nk = p.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const char* sa = smem + cur * 2 * TILE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = *(const bf16x8*)(sa + swz(wr * 64 + t * 16 + li, ks * 4 + g));
+                fb[t] = *(const bf16x8*)(sb + swz(wc * 64 + t * 16 + li, ks * 4 + g));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
+        }
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*64 + 16 g + (4 nt + r)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int m = m0 + wr * 64 + mt * 16 + li;
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+        epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN: dW[N1,N2] += sum_m P[m,N1] Q[m,N2].  Reduction index m is the SLOW dimension of both
+// operands, so MFMA fragments (8 consecutive k per lane) are column reads of the row-major LDS
+// tiles: ds_read_b64_tr_b16 (two per fragment).  LDS rows are padded 256 -> 288 B so the 8 rows a
+// half-wave touches per read fall on distinct banks.  Split over M (gridDim.z) with fp32
+// atomicAdd of the partial tiles; db via one extra MFMA column of ones in the n2-tile-0 blocks.
+constexpr int TK = 64;                 // m rows per step
+constexpr int TROW = 288;              // padded LDS row bytes (128 bf16 + 16 pad)
+constexpr int TTILE = TK * TROW;       // 18 KiB
+
+struct TnParams {
+    const bf16* P; const bf16* Q; int ldp, ldq, M, N1, N2;
+    float* dW; int ldw; float* db; int rows_per_split;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TTILE];   // 72 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
+    const int n2_0 = blockIdx.x * 128, n1_0 = blockIdx.y * 128;
+    const int mbeg = blockIdx.z * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    if (mbeg >= mend) return;
+
+    // staging: tile = 64 rows x 128 cols bf16 = 64 x 16 chunks; thread -> chunk tid&15, rows tid>>4 + 16 i
+    const int sc = tid & 15, sr = tid >> 4;
+    u32x4 rp[4], rq[4];
+    auto gload = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m = mb + sr + 16 * i;
+            bool ok = m < mend;
+            rp[i] = ok ? *(const u32x4*)(p.P + (size_t)m * p.ldp + n1_0 + sc * 8) : u32x4{0, 0, 0, 0};
+            rq[i] = ok ? *(const u32x4*)(p.Q + (size_t)m * p.ldq + n2_0 + sc * 8) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* s = smem + stage * 2 * TTILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int off = (sr + 16 * i) * TROW + sc * 16;
+            *(u32x4*)(s + off) = rp[i];
+            *(u32x4*)(s + TTILE + off) = rq[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    }
+    const bool do_bias = p.db != nullptr && blockIdx.x == 0 && wc == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+
+    // tr16 read address: lane-in-group = 4q + p supplies row q, cols c0 + 4p..4p+3 of the 4x16 block
+    const int q4 = li >> 2, p4 = li & 3;
+    const int nsteps = (mend - mbeg + TK - 1) / TK;
+    gload(mbeg);
+    lstore(0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps) gload(mbeg + (st + 1) * TK);
+        const char* sp = smem + cur * 2 * TTILE;
+        const char* sq = sp + TTILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fp[4], fq[4];
+            // k-slot (g, e) <-> m = 32 ks + 16 (e>>2) + 4 g + (e&3): a half-wave touches 8 CONSECUTIVE rows
+            // per read (conflict-free with the 288-B row stride); P and Q use the same slot map.
+            const int rbase = (ks * 32 + 4 * g + q4) * TROW + p4 * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int cp = (wr * 64 + t * 16) * 2, cq = (wc * 64 + t * 16) * 2;
+                fp[t] = cat4(lds_read_tr16(sp + rbase + cp), lds_read_tr16(sp + rbase + 16 * TROW + cp));
+                fq[t] = cat4(lds_read_tr16(sq + rbase + cq), lds_read_tr16(sq + rbase + 16 * TROW + cq));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma16(fp[it], fq[jt], acc[it][jt]);
+            if (do_bias) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) accb[it] = mfma16(fp[it], ones, accb[it]);
+            }
+        }
+        if (st + 1 < nsteps) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // D[i = n1][j = n2]: lane holds n2 = tile + li, n1 = tile + 4g + r
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int n1 = n1_0 + wr * 64 + it * 16 + 4 * g + r;
+            float* row = p.dW + (size_t)n1 * p.ldw + n2_0 + wc * 64 + li;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) atomicAdd(row + jt * 16, acc[it][jt][r]);
+            if (do_bias && li == 0) atomicAdd(p.db + n1, accb[it][r]);
+        }
+}
+
+}  // namespace
+
+#define LAUNCH_NT(E)                                                                        \
+    case E:                                                                                 \
+        hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
+        break;
+
+extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
+    if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
+    if (g->M <= 0 || g->N % BN || g->K % BK || g->lda % 8 || g->ldb % 8 || g->ldo % 8) return SAIS_ERR_ARG;
+    NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
+               g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off};
+    dim3 grid(g->N / BN, (g->M + BM - 1) / BM);
+    switch (g->epilogue) {
+        LAUNCH_NT(SAIS_EPI_BIAS_BF16)
+        LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)
+        LAUNCH_NT(SAIS_EPI_BIAS_F32)
+        LAUNCH_NT(SAIS_EPI_BIAS_RESID_F32)
+        LAUNCH_NT(SAIS_EPI_BIAS_GELU_BF16)
+        LAUNCH_NT(SAIS_EPI_DGELU_BF16)
+        LAUNCH_NT(SAIS_EPI_DRELU_BF16)
+        LAUNCH_NT(SAIS_EPI_PATCH_F32)
+        default: return SAIS_ERR_ARG;
+    }
+    return sais_check_launch();
+}
+
+extern "C" int sais_gemm_tn(const void* P, int ldp, const void* Q, int ldq, int M, int N1, int N2,
+                            float* dW, int ldw, float* db, int nsplit, void* stream) {
+    if (!P || !Q || !dW || M <= 0 || N1 % 128 || N2 % 128 || ldp % 8 || ldq % 8 || nsplit <= 0) return SAIS_ERR_ARG;
+    int rows = (M + nsplit - 1) / nsplit;
+    rows = (rows + TK - 1) / TK * TK;
+    int ns = (M + rows - 1) / rows;
+    TnParams p{(const bf16*)P, (const bf16*)Q, ldp, ldq, M, N1, N2, dW, ldw, db, rows};
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(N2 / 128, N1 / 128, ns), dim3(256), 0, (hipStream_t)stream, p);
+    return sais_check_launch();
+}

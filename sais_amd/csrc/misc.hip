@@ -1,0 +1,184 @@
+// Small HBM-bound helpers of the SAIS hot path (gfx950): patch gather, CLS rows, SGD, weight shadows.
+#include "common.hpp"
+#include "../../include/sais_hip.h"
+
+namespace {
+
+// PatchEmbed (vision_transformer.py:116-131): Conv2d(3->384, k=16, s=16) over NON-overlapping patches
+// is a GEMM on the [F*196, 768] patch matrix; column order = (c, py, px) = conv weight flatten.
+// One thread = one 16-pixel patch row segment (64-B f32 read, 32-B bf16 write).
+__global__ __launch_bounds__(256) void patchify_kernel(const float* img, bf16* out, int frames) {
+    const long total = (long)frames * 196 * 48;          // 48 = 3 channels * 16 rows
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        // consecutive threads walk px-segments of one image row: idx -> (f, c, y, gx)
+        long t = i;
+        const int gx = t % 14; t /= 14;
+        const int y = t % 224; t /= 224;
+        const int c = t % 3;
+        const int f = t / 3;
+        const float* src = img + (((size_t)f * 3 + c) * 224 + y) * 224 + gx * 16;
+        const int gy = y >> 4, py = y & 15;
+        bf16* dst = out + ((size_t)f * 196 + gy * 14 + gx) * 768 + c * 256 + py * 16;
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x4 a = *(const f32x4*)(src + 8 * k), b = *(const f32x4*)(src + 8 * k + 4);
+            bf16x8& d = k ? hi : lo;
+            d[0] = (bf16)a[0]; d[1] = (bf16)a[1]; d[2] = (bf16)a[2]; d[3] = (bf16)a[3];
+            d[4] = (bf16)b[0]; d[5] = (bf16)b[1]; d[6] = (bf16)b[2]; d[7] = (bf16)b[3];
+        }
+        *(bf16x8*)dst = lo;
+        *(bf16x8*)(dst + 8) = hi;
+    }
+}
+
+// prepare_tokens (vision_transformer.py:196-207): token row 0 of every frame = cls_token + pos_embed[0]
+__global__ void cls_rows_kernel(const float* cls, const float* pos0, float* tokens, long frame_stride, int frames, int dim) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= frames * dim) return;
+    int f = i / dim, c = i - f * dim;
+    tokens[(size_t)f * frame_stride + c] = cls[c] + pos0[c];
+}
+
+// d cls_token = d pos_embed[0] = sum over frames of d tokens[f, 0, :]
+__global__ void cls_rows_bwd_kernel(const float* dtokens, long frame_stride, int frames, int dim, float* dcls, float* dpos0) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= dim) return;
+    float s = 0.f;
+    for (int f = 0; f < frames; ++f) s += dtokens[(size_t)f * frame_stride + c];
+    atomicAdd(dcls + c, s);
+    atomicAdd(dpos0 + c, s);
+}
+
+// d pos_embed[1 + q][:] += sum_f dtok[f, 1 + q, :]   (rows 1..196)
+__global__ void pos_bwd_kernel(const float* dtokens, int frames, int ntok, int dim, float* dpos) {
+    int i = blockIdx.x * 256 + threadIdx.x;            // over (ntok-1)*dim
+    if (i >= (ntok - 1) * dim) return;
+    int q = i / dim + 1, c = i % dim;
+    float s = 0.f;
+    for (int f = 0; f < frames; ++f) s += dtokens[((size_t)f * ntok + q) * dim + c];
+    atomicAdd(dpos + (size_t)q * dim + c, s);
+}
+
+// gather the 196 patch-token rows of every frame into a dense bf16 [F*196, dim] matrix (dY of the patch GEMM)
+__global__ void gather_patch_rows_kernel(const float* dtokens, int frames, int ntok, int dim, bf16* out) {
+    long total = (long)frames * (ntok - 1) * (dim / 4);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = i % (dim / 4);
+        long r = i / (dim / 4);
+        int f = r / (ntok - 1), q = r % (ntok - 1);
+        f32x4 v = *(const f32x4*)(dtokens + ((size_t)f * ntok + q + 1) * dim + 4 * c4);
+        bf16x4 o;
+        o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+        *(bf16x4*)(out + (size_t)r * dim + 4 * c4) = o;
+    }
+}
+
+// vanilla SGD (prepare_model.py:566-567: optim.SGD(params, lr), no momentum / weight decay) fused with the
+// refresh of the bf16 shadow the MFMA kernels read.
+__global__ __launch_bounds__(256) void sgd_kernel(float* p, const float* g, bf16* shadow, long n, float lr, float gscale) {
+    long n4 = n >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 w = *(f32x4*)(p + 4 * i), d = *(const f32x4*)(g + 4 * i);
+        w -= lr * gscale * d;
+        *(f32x4*)(p + 4 * i) = w;
+        if (shadow) {
+            bf16x4 o;
+            o[0] = (bf16)w[0]; o[1] = (bf16)w[1]; o[2] = (bf16)w[2]; o[3] = (bf16)w[3];
+            *(bf16x4*)(shadow + 4 * i) = o;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        long i = (n4 << 2) + threadIdx.x;
+        float w = p[i] - lr * gscale * g[i];
+        p[i] = w;
+        if (shadow) shadow[i] = (bf16)w;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* dst, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (bf16)src[i];
+}
+
+// dst[C,R] (bf16) = src[R,C]^T (f32); 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, bf16* dst, int R, int C) {
+    __shared__ float tile[32][33];
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)c * R + r] = (bf16)tile[tx][j];
+    }
+}
+
+__global__ void scale_kernel(float* p, long n, float s) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= s;
+}
+
+int grid_for(long n, int per_block = 256) {
+    long b = (n + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+}  // namespace
+
+extern "C" int sais_abi_version(void) { return SAIS_ABI_VERSION; }
+
+extern "C" int sais_patchify(const float* frames_f32, int frames, void* patches_bf16, void* stream) {
+    if (!frames_f32 || !patches_bf16 || frames <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)frames * 196 * 48)), dim3(256), 0, (hipStream_t)stream,
+                       frames_f32, (bf16*)patches_bf16, frames);
+    return sais_check_launch();
+}
+
+extern "C" int sais_vit_cls_rows(const float* cls, const float* pos0, float* tokens, long frame_stride, int frames,
+                                 int dim, void* stream) {
+    if (!cls || !pos0 || !tokens || frames <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((frames * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls, pos0,
+                       tokens, frame_stride, frames, dim);
+    return sais_check_launch();
+}
+
+extern "C" int sais_vit_embed_bwd(const float* dtokens, int frames, int ntok, int dim, float* dcls, float* dpos,
+                                  void* dpatch_bf16, void* stream) {
+    if (!dtokens || !dcls || !dpos || !dpatch_bf16 || frames <= 0 || (dim & 3)) return SAIS_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cls_rows_bwd_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, dtokens, (long)ntok * dim, frames,
+                       dim, dcls, dpos);
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3(((ntok - 1) * dim + 255) / 256), dim3(256), 0, s, dtokens, frames, ntok, dim, dpos);
+    hipLaunchKernelGGL(gather_patch_rows_kernel, dim3(grid_for((long)frames * (ntok - 1) * dim / 4)), dim3(256), 0, s,
+                       dtokens, frames, ntok, dim, (bf16*)dpatch_bf16);
+    return sais_check_launch();
+}
+
+extern "C" int sais_sgd_step(float* param, const float* grad, void* shadow_bf16, long n, float lr, float grad_scale,
+                             void* stream) {
+    if (!param || !grad || n <= 0) return SAIS_ERR_ARG;
+    if (((uintptr_t)param | (uintptr_t)grad) & 15) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       (bf16*)shadow_bf16, n, lr, grad_scale);
+    return sais_check_launch();
+}
+
+extern "C" int sais_cast_bf16(const float* src, void* dst_bf16, long n, void* stream) {
+    if (!src || !dst_bf16 || n <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst_bf16, n);
+    return sais_check_launch();
+}
+
+extern "C" int sais_transpose_cast_bf16(const float* src, int rows, int cols, void* dst_bf16, void* stream) {
+    if (!src || !dst_bf16 || rows <= 0 || cols <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+                       (hipStream_t)stream, src, (bf16*)dst_bf16, rows, cols);
+    return sais_check_launch();
+}
+
+extern "C" int sais_scale_f32(float* p, long n, float s, void* stream) {
+    if (!p || n <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, s);
+    return sais_check_launch();
+}

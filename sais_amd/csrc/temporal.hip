@@ -1,0 +1,374 @@
+// Temporal encoder glue + SupCon / prototype head of SAIS for gfx950.  These tensors are tiny
+// (S = T+1 <= 97 tokens per clip, 4 heads x 96), latency-bound, and feed the <=1e-3 logit parity
+// budget directly, so everything here is exact fp32 VALU math staged through LDS; the linear layers
+// around them go through the MFMA GEMMs in gemm.hip.
+//
+//   prepareInputForTransformer  prepare_model.py:179-195   (sais_temporal_prepare_*)
+//   nn.MultiheadAttention core inside the torch-1.8 post-norm TransformerEncoderLayer, with
+//   key_padding_mask and the README.md:43-48 head-averaged attention-map return
+//                               prepare_model.py:74-81,197-221   (sais_temporal_attn_*)
+//   ReLU -> CLS row -> (+flow) -> ReLU -> Linear(384->256)   prepare_model.py:215,220,381-416 (sais_head_*)
+//   calcNCELoss / getProbs      prepare_miscellaneous.py:14-46,111-126   (sais_nce_*)
+#include "common.hpp"
+#include "../../include/sais_hip.h"
+
+namespace {
+constexpr int D = 384, TH = 4, THD = 96, EMB = 256, QS = 97;   // QS: padded LDS row (floats)
+
+// ---------------------------------------------------------------- prepare: z[b, 0] = cls ; z[b, 1+t] = x[b, t] + pos[t]
+__global__ void prepare_fwd_kernel(const float* x, long x_clip_stride, long x_frame_stride, const float* pos,
+                                   const float* cls, int B, int T, float* z32, bf16* z16) {
+    const int S = T + 1;
+    long total = (long)B * S * (D / 4);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c4 = i % (D / 4);
+        long r = i / (D / 4);
+        int b = r / S, s = r % S;
+        f32x4 v;
+        if (s == 0) v = *(const f32x4*)(cls + 4 * c4);
+        else {
+            v = *(const f32x4*)(x + (size_t)b * x_clip_stride + (size_t)(s - 1) * x_frame_stride + 4 * c4);
+            v += *(const f32x4*)(pos + (size_t)(s - 1) * D + 4 * c4);
+        }
+        *(f32x4*)(z32 + (size_t)r * D + 4 * c4) = v;
+        bf16x4 o;
+        o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+        *(bf16x4*)(z16 + (size_t)r * D + 4 * c4) = o;
+    }
+}
+
+// dz = dz32 + dz16 ; dx[b,t] (+)= dz[b,1+t] ; dpos[t] += sum_b ; dcls += sum_b dz[b,0]
+__global__ void prepare_bwd_kernel(const float* dz32, const bf16* dz16, int B, int T, float* dx, long dx_clip_stride,
+                                   long dx_frame_stride, int accumulate, float* dpos, float* dcls) {
+    const int S = T + 1;
+    int i = blockIdx.x * 256 + threadIdx.x;            // over S*D
+    if (i >= S * D) return;
+    int s = i / D, c = i % D;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        size_t idx = ((size_t)b * S + s) * D + c;
+        float v = dz32[idx] + (dz16 ? (float)dz16[idx] : 0.f);
+        acc += v;
+        if (s > 0 && dx) {
+            float* o = dx + (size_t)b * dx_clip_stride + (size_t)(s - 1) * dx_frame_stride + c;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+    if (s == 0) atomicAdd(dcls + c, acc);
+    else atomicAdd(dpos + (size_t)(s - 1) * D + c, acc);
+}
+
+// ---------------------------------------------------------------- masked multi-head attention, one WG per (clip, head)
+DEVINL void load_head(const bf16* qkv, int b, int h, int S, int which, float* dst, int tid) {
+    // dst[s][QS] <- qkv[(b*S+s), which*384 + h*96 + d]
+    for (int i = tid; i < S * (THD / 8); i += 256) {
+        int s = i / (THD / 8), c8 = i % (THD / 8);
+        bf16x8 v = *(const bf16x8*)(qkv + ((size_t)b * S + s) * (3 * D) + which * D + h * THD + 8 * c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[s * QS + 8 * c8 + e] = (float)v[e];
+    }
+}
+
+// P[i][j] = softmax_j( (q_i * scale) . k_j  masked by key_pad[b][j] )  -> sP[S][S+1]
+DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad, int S, float scale, float* sP, int tid) {
+    const int SP = S + 1;
+    for (int idx = tid; idx < S * S; idx += 256) {
+        int i = idx / S, j = idx % S;
+        float a = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < THD; ++d) a += sQ[i * QS + d] * sK[j * QS + d];
+        sP[i * SP + j] = pad[j] ? -INFINITY : a * scale;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    for (int i = w; i < S; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < S; j += 64) m = fmaxf(m, sP[i * SP + j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j < S; j += 64) { float e = __expf(sP[i * SP + j] - m); sP[i * SP + j] = e; sum += e; }
+        sum = wave_sum(sum);
+        float inv = 1.0f / sum;
+        for (int j = lane; j < S; j += 64) sP[i * SP + j] *= inv;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void tattn_fwd_kernel(const bf16* qkv, const unsigned char* key_pad, int S, bf16* ctx,
+                                                        float* attn_avg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sQ = (float*)smem;
+    float* sK = sQ + S * QS;
+    float* sV = sK + S * QS;
+    float* sP = sV + S * QS;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, SP = S + 1;
+    load_head(qkv, b, h, S, 0, sQ, tid);
+    load_head(qkv, b, h, S, 1, sK, tid);
+    load_head(qkv, b, h, S, 2, sV, tid);
+    __syncthreads();
+    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, 0.10206207261596577f /* 96^-0.5 */, sP, tid);
+    if (attn_avg)
+        for (int idx = tid; idx < S * S; idx += 256)
+            atomicAdd(attn_avg + (size_t)b * S * S + idx, sP[(idx / S) * SP + idx % S] * (1.0f / TH));
+    for (int idx = tid; idx < S * THD; idx += 256) {
+        int i = idx / THD, d = idx % THD;
+        float a = 0.f;
+        for (int j = 0; j < S; ++j) a += sP[i * SP + j] * sV[j * QS + d];
+        ctx[((size_t)b * S + i) * D + h * THD + d] = (bf16)a;
+    }
+}
+
+__global__ __launch_bounds__(256) void tattn_bwd_kernel(const bf16* qkv, const unsigned char* key_pad, int S,
+                                                        const bf16* dctx, bf16* dqkv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sQ = (float*)smem;
+    float* sK = sQ + S * QS;
+    float* sV = sK + S * QS;
+    float* sG = sV + S * QS;                 // dctx
+    float* sP = sG + S * QS;
+    float* sS = sP + S * (S + 1);            // dP then dS
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, SP = S + 1;
+    const float scale = 0.10206207261596577f;
+    load_head(qkv, b, h, S, 0, sQ, tid);
+    load_head(qkv, b, h, S, 1, sK, tid);
+    load_head(qkv, b, h, S, 2, sV, tid);
+    for (int i = tid; i < S * (THD / 8); i += 256) {
+        int s = i / (THD / 8), c8 = i % (THD / 8);
+        bf16x8 v = *(const bf16x8*)(dctx + ((size_t)b * S + s) * D + h * THD + 8 * c8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sG[s * QS + 8 * c8 + e] = (float)v[e];
+    }
+    __syncthreads();
+    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, scale, sP, tid);
+    // dV[j][d] = sum_i P[i][j] dctx[i][d]
+    for (int idx = tid; idx < S * THD; idx += 256) {
+        int j = idx / THD, d = idx % THD;
+        float a = 0.f;
+        for (int i = 0; i < S; ++i) a += sP[i * SP + j] * sG[i * QS + d];
+        dqkv[((size_t)b * S + j) * (3 * D) + 2 * D + h * THD + d] = (bf16)a;
+    }
+    // dP[i][j] = dctx_i . v_j
+    for (int idx = tid; idx < S * S; idx += 256) {
+        int i = idx / S, j = idx % S;
+        float a = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < THD; ++d) a += sG[i * QS + d] * sV[j * QS + d];
+        sS[i * SP + j] = a;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    for (int i = w; i < S; i += 4) {
+        float dot = 0.f;
+        for (int j = lane; j < S; j += 64) dot += sP[i * SP + j] * sS[i * SP + j];
+        dot = wave_sum(dot);
+        for (int j = lane; j < S; j += 64) sS[i * SP + j] = sP[i * SP + j] * (sS[i * SP + j] - dot) * scale;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < S * THD; idx += 256) {
+        int i = idx / THD, d = idx % THD;
+        float aq = 0.f, ak = 0.f;
+        for (int j = 0; j < S; ++j) {
+            aq += sS[i * SP + j] * sK[j * QS + d];      // dq_i = sum_j dS[i][j] k_j
+            ak += sS[j * SP + i] * sQ[j * QS + d];      // dk_i = sum_j dS[j][i] q_j
+        }
+        size_t row = ((size_t)b * S + i) * (3 * D) + h * THD + d;
+        dqkv[row] = (bf16)aq;
+        dqkv[row + D] = (bf16)ak;
+    }
+}
+
+// ---------------------------------------------------------------- head
+// rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = W relu(rep) + bias
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const float* zf, long clip_stride,
+                                                       const float* W, const float* bias, float* rep, float* emb) {
+    __shared__ float sr[D];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < D; c += 256) {
+        float v = 0.f;
+        if (zr) v += fmaxf(zr[(size_t)b * clip_stride + c], 0.f);
+        if (zf) v += fmaxf(zf[(size_t)b * clip_stride + c], 0.f);
+        rep[(size_t)b * D + c] = v;
+        sr[c] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    float a = bias[tid];
+    const float* w = W + (size_t)tid * D;
+    for (int c = 0; c < D; c += 4) {
+        f32x4 t = *(const f32x4*)(w + c);
+        a += t[0] * sr[c] + t[1] * sr[c + 1] + t[2] * sr[c + 2] + t[3] * sr[c + 3];
+    }
+    emb[(size_t)b * EMB + tid] = a;
+}
+
+// demb [B,256] -> dW += demb^T relu(rep), db += sum_b demb, dz_rgb[b,0,:] / dz_flow[b,0,:]
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const float* W, const float* rep,
+                                                       const float* zr, const float* zf, long clip_stride, int B,
+                                                       float* dW, float* dbias, float* dzr, float* dzf) {
+    __shared__ float sd[EMB];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    sd[tid] = demb[(size_t)b * EMB + tid];
+    __syncthreads();
+    atomicAdd(dbias + tid, sd[tid]);
+    for (int c = tid; c < D; c += 256) {
+        float r = rep[(size_t)b * D + c];
+        float r2 = fmaxf(r, 0.f);
+        float a = 0.f;
+        for (int o = 0; o < EMB; ++o) {
+            a += W[(size_t)o * D + c] * sd[o];
+            if (r2 != 0.f) atomicAdd(dW + (size_t)o * D + c, sd[o] * r2);
+        }
+        float drep = r > 0.f ? a : 0.f;
+        if (zr) dzr[(size_t)b * clip_stride + c] = zr[(size_t)b * clip_stride + c] > 0.f ? drep : 0.f;
+        if (zf) dzf[(size_t)b * clip_stride + c] = zf[(size_t)b * clip_stride + c] > 0.f ? drep : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------- SupCon / prototype loss; one workgroup
+__global__ __launch_bounds__(256) void nce_kernel(const float* emb, const float* protos, const int* label_col, int B,
+                                                  int C, float* sim, float* probs, float* loss, float* demb,
+                                                  float* dprotos, float loss_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* en = (float*)smem;                 // [B] |emb|
+    float* pn = en + B;                       // [C] |p|
+    float* ss = pn + C;                       // [B*C] sim
+    float* dsim = ss + B * C;                 // [B*C]
+    float* lrow = dsim + B * C;               // [B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int r = w; r < B + C; r += 4) {
+        const float* v = r < B ? emb + (size_t)r * EMB : protos + (size_t)(r - B) * EMB;
+        float a = 0.f;
+        for (int c = lane; c < EMB; c += 64) a += v[c] * v[c];
+        a = sqrtf(wave_sum(a));
+        if (lane == 0) (r < B ? en[r] : pn[r - B]) = a;
+    }
+    __syncthreads();
+    for (int idx = w; idx < B * C; idx += 4) {
+        int i = idx / C, j = idx % C;
+        float a = 0.f;
+        for (int c = lane; c < EMB; c += 64) a += emb[(size_t)i * EMB + c] * protos[(size_t)j * EMB + c];
+        a = wave_sum(a) / (en[i] * pn[j]);
+        if (lane == 0) { ss[idx] = a; if (sim) sim[idx] = a; }
+    }
+    __syncthreads();
+    for (int i = tid; i < B; i += 256) {
+        float den = 0.f;
+        for (int j = 0; j < C; ++j) den += __expf(ss[i * C + j]);
+        int y = label_col ? label_col[i] : 0;
+        for (int j = 0; j < C; ++j) {
+            float p = __expf(ss[i * C + j]) / den;
+            if (probs) probs[i * C + j] = p;
+            dsim[i * C + j] = (p - (j == y ? 1.f : 0.f)) * loss_scale / B;
+        }
+        lrow[i] = -__logf(__expf(ss[i * C + y]) / den);
+    }
+    __syncthreads();
+    if (tid == 0 && loss) {
+        float a = 0.f;
+        for (int i = 0; i < B; ++i) a += lrow[i];
+        *loss = a / B;
+    }
+    if (!demb) return;
+    // d s_hat_i = sum_j dsim[i][j] p_hat_j ;  d emb_i = (d s_hat_i - s_hat_i (s_hat_i . d s_hat_i)) / |emb_i|
+    for (int r = w; r < B + C; r += 4) {
+        const bool is_e = r < B;
+        const int i = is_e ? r : r - B;
+        const float* self = is_e ? emb + (size_t)i * EMB : protos + (size_t)i * EMB;
+        const float nself = is_e ? en[i] : pn[i];
+        float g[EMB / 64], sh[EMB / 64];
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < EMB / 64; ++u) {
+            int c = lane + 64 * u;
+            float a = 0.f;
+            if (is_e) for (int j = 0; j < C; ++j) a += dsim[i * C + j] * protos[(size_t)j * EMB + c] / pn[j];
+            else      for (int k = 0; k < B; ++k) a += dsim[k * C + i] * emb[(size_t)k * EMB + c] / en[k];
+            g[u] = a;
+            sh[u] = self[c] / nself;
+            dot += a * sh[u];
+        }
+        dot = wave_sum(dot);
+        float* out = is_e ? demb + (size_t)i * EMB : dprotos + (size_t)i * EMB;
+#pragma unroll
+        for (int u = 0; u < EMB / 64; ++u) {
+            float v = (g[u] - sh[u] * dot) / nself;
+            if (is_e) out[lane + 64 * u] = v; else out[lane + 64 * u] += v;
+        }
+    }
+}
+
+template <typename K>
+int set_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
+               ? SAIS_OK : SAIS_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int sais_temporal_prepare_fwd(const float* x, long x_clip_stride, long x_frame_stride, const float* pos,
+                                         const float* cls, int B, int T, float* z_f32, void* z_bf16, void* stream) {
+    if (!x || !pos || !cls || !z_f32 || !z_bf16 || B <= 0 || T <= 0 || (x_clip_stride & 3) || (x_frame_stride & 3))
+        return SAIS_ERR_ARG;
+    long total = (long)B * (T + 1) * (D / 4);
+    hipLaunchKernelGGL(prepare_fwd_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       x_clip_stride, x_frame_stride, pos, cls, B, T, z_f32, (bf16*)z_bf16);
+    return sais_check_launch();
+}
+
+extern "C" int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf16, int B, int T, float* dx,
+                                         long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos,
+                                         float* dcls, void* stream) {
+    if (!dz_f32 || !dpos || !dcls || B <= 0 || T <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(prepare_bwd_kernel, dim3(((T + 1) * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz_f32,
+                       (const bf16*)dz_bf16, B, T, dx, dx_clip_stride, dx_frame_stride, accumulate, dpos, dcls);
+    return sais_check_launch();
+}
+
+extern "C" int sais_temporal_attn_fwd(const void* qkv_bf16, const unsigned char* key_pad, int B, int S, void* ctx_bf16,
+                                      float* attn_avg, void* stream) {
+    if (!qkv_bf16 || !key_pad || !ctx_bf16 || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_FWD) return SAIS_ERR_ARG;
+    int lds = (3 * S * QS + S * (S + 1)) * 4;
+    if (set_lds(tattn_fwd_kernel, lds)) return SAIS_ERR_LAUNCH;
+    hipStream_t s = (hipStream_t)stream;
+    if (attn_avg && hipMemsetAsync(attn_avg, 0, (size_t)B * S * S * 4, s) != hipSuccess) return SAIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(256), lds, s, (const bf16*)qkv_bf16, key_pad, S,
+                       (bf16*)ctx_bf16, attn_avg);
+    return sais_check_launch();
+}
+
+extern "C" int sais_temporal_attn_bwd(const void* qkv_bf16, const unsigned char* key_pad, int B, int S,
+                                      const void* dctx_bf16, void* dqkv_bf16, void* stream) {
+    if (!qkv_bf16 || !key_pad || !dctx_bf16 || !dqkv_bf16 || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_BWD)
+        return SAIS_ERR_ARG;
+    int lds = (4 * S * QS + 2 * S * (S + 1)) * 4;
+    if (set_lds(tattn_bwd_kernel, lds)) return SAIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv_bf16,
+                       key_pad, S, (const bf16*)dctx_bf16, (bf16*)dqkv_bf16);
+    return sais_check_launch();
+}
+
+extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, int B, const float* W,
+                             const float* bias, float* rep, float* emb, void* stream) {
+    if ((!z_rgb && !z_flow) || !W || !bias || !rep || !emb || B <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride, W, bias,
+                       rep, emb);
+    return sais_check_launch();
+}
+
+extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb,
+                             const float* z_flow, long clip_stride, int B, float* dW, float* dbias, float* dz_rgb,
+                             float* dz_flow, void* stream) {
+    if (!demb || !W || !rep || !dW || !dbias || B <= 0) return SAIS_ERR_ARG;
+    if ((z_rgb && !dz_rgb) || (z_flow && !dz_flow)) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, demb, W, rep, z_rgb, z_flow,
+                       clip_stride, B, dW, dbias, dz_rgb, dz_flow);
+    return sais_check_launch();
+}
+
+extern "C" int sais_nce(const float* emb, const float* protos, const int* label_col, int B, int C, float* sim,
+                        float* probs, float* loss, float* demb, float* dprotos, float loss_scale, void* stream) {
+    if (!emb || !protos || B <= 0 || C <= 0 || (demb && (!dprotos || !label_col))) return SAIS_ERR_ARG;
+    int lds = (B + C + 2 * B * C + B) * 4;
+    if (lds > 64 * 1024) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(nce_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, emb, protos, label_col, B, C, sim, probs,
+                       loss, demb, dprotos, loss_scale);
+    return sais_check_launch();
+}

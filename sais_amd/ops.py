@@ -1,0 +1,138 @@
+"""Tensor-level wrappers over the C ABI (include/sais_hip.h).  torch is plumbing only: device
+memory, the current HIP stream, and dtype checks; every op below is one hand-written gfx950 kernel.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise L.SaisHipError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise L.SaisHipError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise L.SaisHipError(f"{name}: innermost dimension must be contiguous")
+
+
+def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0, 0, 0)):
+    """out[M,N] = a[M,K] . w[N,K]^T (+epilogue).  a, w bf16 2-D (row stride free)."""
+    _chk(a, BF16, "A"); _chk(w, BF16, "B"); _chk(bias, F32, "bias")
+    M = a.shape[0] if M is None else M
+    N, K = w.shape
+    g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
+                   _p(out), out.stride(-2), _p(out2), 0 if out2 is None else out2.stride(-2),
+                   _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2])
+    L.call("sais_gemm_nt", ctypes.byref(g), _stream())
+    return out
+
+
+def gemm_tn(p, q, dW, db=None, nsplit=None):
+    """dW[N1,N2] += p[M,N1]^T . q[M,N2] ; db[N1] += colsum(p)."""
+    _chk(p, BF16, "P"); _chk(q, BF16, "Q"); _chk(dW, F32, "dW"); _chk(db, F32, "db")
+    M, N1 = p.shape
+    N2 = q.shape[1]
+    if nsplit is None:
+        tiles = (N1 // 128) * (N2 // 128)
+        nsplit = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles))
+    L.call("sais_gemm_tn", _p(p), p.stride(0), _p(q), q.stride(0), M, N1, N2, _p(dW), dW.stride(0), _p(db), nsplit,
+           _stream())
+
+
+def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None, rstd=None, ldy16=384, ldy32=384):
+    _chk(x, F32, "x"); _chk(y16, BF16, "y16"); _chk(y32, F32, "y32")
+    L.call("sais_layernorm_fwd", _p(x), ldx, rows, 384, _p(gamma), _p(beta), eps, _p(y16), ldy16, _p(y32), ldy32,
+           _p(mean), _p(rstd), _stream())
+
+
+def layernorm_bwd(x, ldx, mean, rstd, gamma, rows, dy16=None, dy32=None, dres=None, dx32=None, dx16=None,
+                  dgamma=None, dbeta=None, lddy16=384, lddy32=384, lddres=384, lddx32=384, lddx16=384):
+    _chk(dy16, BF16, "dy16"); _chk(dy32, F32, "dy32"); _chk(dx16, BF16, "dx16"); _chk(dx32, F32, "dx32")
+    L.call("sais_layernorm_bwd", _p(dy16), lddy16, _p(dy32), lddy32, _p(x), ldx, _p(mean), _p(rstd), _p(gamma),
+           _p(dres), lddres, rows, 384, _p(dx32), lddx32, _p(dx16), lddx16, _p(dgamma), _p(dbeta), _stream())
+
+
+def vit_attn_fwd(qkv, frames, out, lse=None, probs=None):
+    _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out")
+    L.call("sais_vit_attn_fwd", _p(qkv), qkv.stride(0), frames, _p(out), out.stride(0), _p(lse), _p(probs), _stream())
+
+
+def vit_attn_bwd(qkv, dout, lse, delta_ws, frames, dqkv):
+    L.call("sais_vit_attn_bwd", _p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(lse), _p(delta_ws), frames,
+           _p(dqkv), dqkv.stride(0), _stream())
+
+
+def patchify(frames_f32, patches):
+    _chk(frames_f32, F32, "frames")
+    L.call("sais_patchify", _p(frames_f32), frames_f32.shape[0], _p(patches), _stream())
+
+
+def vit_cls_rows(cls, pos0, tokens, frames):
+    L.call("sais_vit_cls_rows", _p(cls), _p(pos0), _p(tokens), 197 * 384, frames, 384, _stream())
+
+
+def vit_embed_bwd(dtokens, frames, dcls, dpos, dpatch):
+    L.call("sais_vit_embed_bwd", _p(dtokens), frames, 197, 384, _p(dcls), _p(dpos), _p(dpatch), _stream())
+
+
+def sgd_step(param, grad, shadow, lr, grad_scale=1.0):
+    L.call("sais_sgd_step", _p(param), _p(grad), _p(shadow), param.numel(), lr, grad_scale, _stream())
+
+
+def cast_bf16(src, dst):
+    L.call("sais_cast_bf16", _p(src), _p(dst), src.numel(), _stream())
+
+
+def transpose_cast_bf16(src, rows, cols, dst):
+    L.call("sais_transpose_cast_bf16", _p(src), rows, cols, _p(dst), _stream())
+
+
+def scale_(t, s):
+    L.call("sais_scale_f32", _p(t), t.numel(), s, _stream())
+
+
+def temporal_prepare_fwd(x, clip_stride, frame_stride, pos, cls, B, T, z32, z16):
+    L.call("sais_temporal_prepare_fwd", _p(x), clip_stride, frame_stride, _p(pos), _p(cls), B, T, _p(z32), _p(z16),
+           _stream())
+
+
+def temporal_prepare_bwd(dz32, dz16, B, T, dx, clip_stride, frame_stride, accumulate, dpos, dcls):
+    L.call("sais_temporal_prepare_bwd", _p(dz32), _p(dz16), B, T, _p(dx), clip_stride, frame_stride,
+           1 if accumulate else 0, _p(dpos), _p(dcls), _stream())
+
+
+def temporal_attn_fwd(qkv, key_pad_u8, B, S, ctx, attn_avg=None):
+    L.call("sais_temporal_attn_fwd", _p(qkv), _p(key_pad_u8), B, S, _p(ctx), _p(attn_avg), _stream())
+
+
+def temporal_attn_bwd(qkv, key_pad_u8, B, S, dctx, dqkv):
+    L.call("sais_temporal_attn_bwd", _p(qkv), _p(key_pad_u8), B, S, _p(dctx), _p(dqkv), _stream())
+
+
+def head_fwd(z_rgb, z_flow, clip_stride, B, W, bias, rep, emb):
+    L.call("sais_head_fwd", _p(z_rgb), _p(z_flow), clip_stride, B, _p(W), _p(bias), _p(rep), _p(emb), _stream())
+
+
+def head_bwd(demb, W, rep, z_rgb, z_flow, clip_stride, B, dW, dbias, dz_rgb, dz_flow):
+    L.call("sais_head_bwd", _p(demb), _p(W), _p(rep), _p(z_rgb), _p(z_flow), clip_stride, B, _p(dW), _p(dbias),
+           _p(dz_rgb), _p(dz_flow), _stream())
+
+
+def nce(emb, protos, label_col, sim=None, probs=None, loss=None, demb=None, dprotos=None, loss_scale=1.0):
+    B, C = emb.shape[0], protos.shape[0]
+    L.call("sais_nce", _p(emb), _p(protos), _p(label_col), B, C, _p(sim), _p(probs), _p(loss), _p(demb), _p(dprotos),
+           loss_scale, _stream())

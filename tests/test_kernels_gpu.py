@@ -1,0 +1,334 @@
+"""Per-kernel parity on a real MI355X: every entry point of libsais_hip.so (called through the
+C ABI) against a plain fp32 torch reference of the same op on the same seeded inputs.
+bf16 operands are generated in bf16 first, so the only differences are accumulation order
+(fp32 in both) and the final bf16 rounding where the output is bf16."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sais_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def assert_close(got, ref, atol, rtol=0.0, name=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{name}: max err {err.max().item():.3e} (ref max {ref.abs().max().item():.3e}), {bad.sum().item()} bad"
+
+
+# ------------------------------------------------------------------ MFMA layout: exact small-integer data
+def test_gemm_nt_exact_integers(ops):
+    from sais_amd import _lib as L
+    M, N, K = 200, 256, 128
+    g = torch.Generator().manual_seed(1)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()     # asymmetric B
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), L.EPI_BIAS_F32, out)
+    assert torch.equal(out.cpu(), a @ w.t())
+
+
+def test_gemm_tn_exact_integers(ops):
+    M, N1, N2 = 333, 256, 128
+    g = torch.Generator().manual_seed(2)
+    p = torch.randint(-3, 4, (M, N1), generator=g).float()
+    q = torch.randint(-3, 4, (M, N2), generator=g).float()
+    dW = torch.zeros(N1, N2, device=DEV)
+    db = torch.zeros(N1, device=DEV)
+    ops.gemm_tn(p.to(torch.bfloat16).to(DEV), q.to(torch.bfloat16).to(DEV), dW, db, nsplit=3)
+    assert torch.equal(dW.cpu(), p.t() @ q)
+    assert torch.equal(db.cpu(), p.sum(0))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (50432 // 8, 1152, 384), (264, 2048, 384), (128, 384, 1536)])
+def test_gemm_nt_epilogues(ops, M, N, K):
+    from sais_amd import _lib as L
+    a = rnd(M, K, seed=3, dtype=torch.bfloat16)
+    w = rnd(N, K, seed=4, scale=0.05, dtype=torch.bfloat16)
+    bias = rnd(N, seed=5, scale=0.1)
+    ref = a.float() @ w.float().t() + bias
+    tol = dict(atol=2e-2, rtol=1e-2)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, w, L.EPI_BIAS_BF16, out, bias=bias)
+    assert_close(out, ref, name="bias_bf16", **tol)
+    ops.gemm_nt(a, w, L.EPI_BIAS_RELU_BF16, out, bias=bias)
+    assert_close(out, ref.relu(), name="relu", **tol)
+    o32 = torch.empty(M, N, device=DEV)
+    ops.gemm_nt(a, w, L.EPI_BIAS_F32, o32, bias=bias)
+    assert_close(o32, ref, atol=1e-3, rtol=1e-4, name="f32")
+    res = rnd(M, N, seed=6)
+    x = res.clone()
+    x16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, w, L.EPI_BIAS_RESID_F32, x, bias=bias, aux=x, out2=x16)       # in place
+    assert_close(x, ref + res, atol=1e-3, rtol=1e-4, name="resid")
+    assert_close(x16, ref + res, name="resid16", **tol)
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, w, L.EPI_BIAS_GELU_BF16, out, bias=bias, out2=u)
+    assert_close(out, F.gelu(ref), name="gelu", **tol)
+    assert_close(u, ref, name="gelu_pre", **tol)
+    pre = rnd(M, N, seed=7, dtype=torch.bfloat16)
+    ops.gemm_nt(a, w, L.EPI_DGELU_BF16, out, aux=pre)
+    pf = pre.float().requires_grad_(True)
+    F.gelu(pf).sum().backward()
+    assert_close(out, (ref - bias) * pf.grad, name="dgelu", **tol)
+    ops.gemm_nt(a, w, L.EPI_DRELU_BF16, out, aux=pre)
+    assert_close(out, (ref - bias) * (pre.float() > 0), name="drelu", **tol)
+
+
+def test_gemm_patch_epilogue(ops):
+    from sais_amd import _lib as L
+    Fr, K, N = 3, 768, 384
+    a = rnd(Fr * 196, K, seed=8, dtype=torch.bfloat16)
+    w = rnd(N, K, seed=9, scale=0.05, dtype=torch.bfloat16)
+    bias, pos = rnd(N, seed=10), rnd(197, N, seed=11)
+    tok = torch.zeros(Fr, 197, N, device=DEV)
+    ops.gemm_nt(a, w, L.EPI_PATCH_F32, tok, bias=bias, aux=pos, grp=(196, 197, 1))
+    ref = (a.float() @ w.float().t() + bias).view(Fr, 196, N) + pos[1:]
+    assert_close(tok[:, 1:], ref, atol=1e-3, rtol=1e-4)
+    assert tok[:, 0].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1000, 256, 128), (50432 // 16, 384, 1536), (264, 1152, 384)])
+def test_gemm_tn(ops, M, N1, N2):
+    p = rnd(M, N1, seed=12, dtype=torch.bfloat16)
+    q = rnd(M, N2, seed=13, dtype=torch.bfloat16)
+    dW = torch.zeros(N1, N2, device=DEV)
+    db = torch.zeros(N1, device=DEV)
+    ops.gemm_tn(p, q, dW, db)
+    ref = p.float().t() @ q.float()
+    assert_close(dW, ref, atol=2e-3 * math.sqrt(M), rtol=1e-4)
+    assert_close(db, p.float().sum(0), atol=1e-3 * math.sqrt(M))
+    ops.gemm_tn(p, q, dW, None)                      # accumulates
+    assert_close(dW, 2 * ref, atol=4e-3 * math.sqrt(M), rtol=1e-4)
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,eps", [(197 * 3, 1e-6), (1001, 1e-5)])
+def test_layernorm_fwd_bwd(ops, rows, eps):
+    x = rnd(rows, 384, seed=20, scale=2.0) + 0.3
+    gamma, beta = 1 + 0.1 * rnd(384, seed=21), 0.1 * rnd(384, seed=22)
+    y16 = torch.empty(rows, 384, dtype=torch.bfloat16, device=DEV)
+    y32 = torch.empty(rows, 384, device=DEV)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(x, rows, 384, gamma, beta, eps, y16, y32, mean, rstd)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (384,), gr, br, eps)
+    assert_close(y32, ref, atol=2e-5)
+    assert_close(y16, ref, atol=2e-2, rtol=1e-2)
+    dy16 = rnd(rows, 384, seed=23, dtype=torch.bfloat16)
+    dy32 = rnd(rows, 384, seed=24)
+    dres = rnd(rows, 384, seed=25)
+    ref.backward(dy16.float() + dy32)
+    dx32 = torch.empty(rows, 384, device=DEV)
+    dx16 = torch.empty(rows, 384, dtype=torch.bfloat16, device=DEV)
+    dg, db = torch.zeros(384, device=DEV), torch.zeros(384, device=DEV)
+    ops.layernorm_bwd(x, 384, mean, rstd, gamma, rows, dy16=dy16, dy32=dy32, dres=dres, dx32=dx32, dx16=dx16,
+                      dgamma=dg, dbeta=db)
+    assert_close(dx32, xr.grad + dres, atol=1e-4, rtol=1e-4)
+    assert_close(dx16, xr.grad + dres, atol=3e-2, rtol=1e-2)
+    assert_close(dg, gr.grad, atol=2e-3, rtol=1e-4)
+    assert_close(db, br.grad, atol=2e-3, rtol=1e-4)
+
+
+def test_layernorm_cls_rows_strided(ops):
+    Fr = 5
+    x = rnd(Fr, 197, 384, seed=26)
+    gamma, beta = 1 + 0.1 * rnd(384, seed=27), 0.1 * rnd(384, seed=28)
+    y = torch.empty(Fr, 384, device=DEV)
+    ops.layernorm_fwd(x, Fr, 197 * 384, gamma, beta, 1e-6, y32=y)
+    assert_close(y, F.layer_norm(x[:, 0], (384,), gamma, beta, 1e-6), atol=2e-5)
+
+
+# ------------------------------------------------------------------ ViT attention
+def _attn_ref(qkv, frames):
+    q, k, v = qkv.float().view(frames, 197, 3, 6, 64).permute(2, 0, 3, 1, 4)
+    p = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(frames * 197, 384), p
+
+
+def test_vit_attention_fwd_bwd(ops):
+    frames = 3
+    qkv = rnd(frames * 197, 1152, seed=30, scale=1.5, dtype=torch.bfloat16)
+    out = torch.empty(frames * 197, 384, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(frames, 6, 197, device=DEV)
+    probs = torch.empty(frames, 6, 197, 197, device=DEV)
+    ops.vit_attn_fwd(qkv, frames, out, lse, probs)
+    qr = qkv.float().requires_grad_(True)
+    ref, p = _attn_ref(qr, frames)
+    assert_close(probs, p, atol=2e-3, rtol=2e-2, name="probs")
+    assert_close(out, ref, atol=2e-2, rtol=2e-2, name="out")
+    qf, kf = qkv.float().view(frames, 197, 3, 6, 64).permute(2, 0, 3, 1, 4)[:2]
+    assert_close(lse, torch.logsumexp((qf @ kf.transpose(-2, -1)) * 0.125, -1), atol=1e-3, name="lse")
+    dout = rnd(frames * 197, 384, seed=31, dtype=torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv = torch.full((frames * 197, 1152), float("nan"), dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(frames, 6, 197, device=DEV)
+    ops.vit_attn_bwd(qkv, dout, lse, delta, frames, dqkv)
+    g = qr.grad
+    scale = g.abs().max().item()
+    assert_close(dqkv, g, atol=2e-2 * scale, rtol=2e-2, name="dqkv")
+
+
+def test_vit_attention_forced_peaky_rows(ops):
+    """A spiked key per query forces near-one-hot softmax rows (exercises the max subtraction)."""
+    frames = 1
+    qkv = rnd(197, 1152, seed=32, scale=0.5, dtype=torch.bfloat16)
+    qkv[:, 384:768] *= 12.0
+    out = torch.empty(197, 384, dtype=torch.bfloat16, device=DEV)
+    ops.vit_attn_fwd(qkv, frames, out)
+    ref, _ = _attn_ref(qkv, frames)
+    assert torch.isfinite(out.float()).all()
+    assert_close(out, ref, atol=3e-2, rtol=3e-2)
+
+
+# ------------------------------------------------------------------ embedding glue, optimizer
+def test_patchify_matches_conv_unfold(ops):
+    Fr = 2
+    img = rnd(Fr, 3, 224, 224, seed=40)
+    patches = torch.empty(Fr * 196, 768, dtype=torch.bfloat16, device=DEV)
+    ops.patchify(img, patches)
+    ref = img.reshape(Fr, 3, 14, 16, 14, 16).permute(0, 2, 4, 1, 3, 5).reshape(Fr * 196, 768)
+    assert torch.equal(patches.cpu(), ref.to(torch.bfloat16).cpu())
+
+
+def test_cls_rows_and_embed_bwd(ops):
+    Fr = 4
+    cls, pos = rnd(384, seed=41), rnd(197, 384, seed=42)
+    tok = torch.zeros(Fr, 197, 384, device=DEV)
+    ops.vit_cls_rows(cls, pos, tok, Fr)
+    assert_close(tok[:, 0], (cls + pos[0]).expand(Fr, -1), atol=0)
+    dtok = rnd(Fr, 197, 384, seed=43)
+    dcls, dpos = torch.zeros(384, device=DEV), torch.zeros(197, 384, device=DEV)
+    dpatch = torch.empty(Fr * 196, 384, dtype=torch.bfloat16, device=DEV)
+    ops.vit_embed_bwd(dtok, Fr, dcls, dpos, dpatch)
+    assert_close(dcls, dtok[:, 0].sum(0), atol=1e-5)
+    assert_close(dpos, dtok.sum(0), atol=1e-5)
+    assert torch.equal(dpatch.cpu(), dtok[:, 1:].reshape(-1, 384).to(torch.bfloat16).cpu())
+
+
+def test_sgd_cast_transpose(ops):
+    n = 384 * 1152 + 3
+    p, g = rnd(n, seed=44), rnd(n, seed=45)
+    ref = p - 0.1 * 0.5 * g
+    sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ops.sgd_step(p, g, sh, 0.1, 0.5)
+    assert_close(p, ref, atol=1e-7)
+    assert torch.equal(sh.cpu(), ref.to(torch.bfloat16).cpu())
+    w = rnd(1152, 384, seed=46)
+    wt = torch.empty(384, 1152, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_cast_bf16(w, 1152, 384, wt)
+    assert torch.equal(wt.cpu(), w.t().contiguous().to(torch.bfloat16).cpu())
+    c = torch.empty(1152 * 384, dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(w, c)
+    assert torch.equal(c.view(1152, 384).cpu(), w.to(torch.bfloat16).cpu())
+
+
+# ------------------------------------------------------------------ temporal glue + head + loss
+def test_temporal_prepare(ops):
+    B, T = 3, 9
+    x = rnd(B, 1, T, 384, seed=50)
+    pos, cls = rnd(T, 384, seed=51), rnd(384, seed=52)
+    z32 = torch.empty(B * (T + 1), 384, device=DEV)
+    z16 = torch.empty(B * (T + 1), 384, dtype=torch.bfloat16, device=DEV)
+    ops.temporal_prepare_fwd(x, T * 384, 384, pos, cls, B, T, z32, z16)
+    ref = torch.cat((cls.expand(B, 1, 384), x[:, 0] + pos), 1)
+    assert_close(z32.view(B, T + 1, 384), ref, atol=0)
+    dz32 = rnd(B * (T + 1), 384, seed=53)
+    dz16 = rnd(B * (T + 1), 384, seed=54, dtype=torch.bfloat16)
+    dx = torch.empty(B, 1, T, 384, device=DEV)
+    dpos, dcls = torch.zeros(T, 384, device=DEV), torch.zeros(384, device=DEV)
+    ops.temporal_prepare_bwd(dz32, dz16, B, T, dx, T * 384, 384, False, dpos, dcls)
+    d = (dz32 + dz16.float()).view(B, T + 1, 384)
+    assert_close(dx[:, 0], d[:, 1:], atol=1e-6)
+    assert_close(dpos, d[:, 1:].sum(0), atol=1e-5)
+    assert_close(dcls, d[:, 0].sum(0), atol=1e-5)
+
+
+@pytest.mark.parametrize("S,lens", [(33, [32, 20, 3, 0, 17]), (16, [15, 15]), (64, [63, 10, 40])])
+def test_temporal_attention_fwd_bwd(ops, S, lens):
+    B = len(lens)
+    qkv = rnd(B * S, 1152, seed=60, scale=1.0, dtype=torch.bfloat16)
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    for b, n in enumerate(lens):
+        pad[b, n + 1:] = True
+    padu = pad.to(torch.uint8).to(DEV)
+    ctx = torch.empty(B * S, 384, dtype=torch.bfloat16, device=DEV)
+    avg = torch.empty(B, S, S, device=DEV)
+    ops.temporal_attn_fwd(qkv, padu, B, S, ctx, avg)
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = qr.view(B, S, 3, 4, 96).permute(2, 0, 3, 1, 4)
+    sc = (q * 96 ** -0.5) @ k.transpose(-2, -1)
+    sc = sc.masked_fill(pad.to(DEV).view(B, 1, 1, S), float("-inf"))
+    p = sc.softmax(-1)
+    ref = (p @ v).transpose(1, 2).reshape(B * S, 384)
+    assert_close(avg, p.mean(1), atol=1e-5, name="attn_avg")
+    assert_close(ctx, ref, atol=1e-2, rtol=1e-2, name="ctx")
+    dctx = rnd(B * S, 384, seed=61, dtype=torch.bfloat16)
+    ref.backward(dctx.float())
+    dqkv = torch.empty(B * S, 1152, dtype=torch.bfloat16, device=DEV)
+    ops.temporal_attn_bwd(qkv, padu, B, S, dctx, dqkv)
+    assert_close(dqkv, qr.grad, atol=2e-2 * qr.grad.abs().max().item(), rtol=1e-2, name="dqkv")
+
+
+@pytest.mark.parametrize("two_stream", [False, True])
+def test_head_fwd_bwd(ops, two_stream):
+    B, S = 5, 7
+    zr, zf = rnd(B, S, 384, seed=70), rnd(B, S, 384, seed=71)
+    W, bias = rnd(256, 384, seed=72, scale=0.05), rnd(256, seed=73, scale=0.1)
+    rep, emb = torch.empty(B, 384, device=DEV), torch.empty(B, 256, device=DEV)
+    ops.head_fwd(zr, zf if two_stream else None, S * 384, B, W, bias, rep, emb)
+    zr_, zf_ = zr.clone().requires_grad_(True), zf.clone().requires_grad_(True)
+    W_, b_ = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    r = F.relu(zr_)[:, 0] + (F.relu(zf_)[:, 0] if two_stream else 0)
+    ref = F.linear(F.relu(r), W_, b_)
+    assert_close(emb, ref, atol=1e-4)
+    demb = rnd(B, 256, seed=74)
+    ref.backward(demb)
+    dW, db = torch.zeros(256, 384, device=DEV), torch.zeros(256, device=DEV)
+    dzr, dzf = torch.zeros(B, S, 384, device=DEV), torch.zeros(B, S, 384, device=DEV)
+    ops.head_bwd(demb, W, rep, zr, zf if two_stream else None, S * 384, B, dW, db, dzr, dzf if two_stream else None)
+    assert_close(dW, W_.grad, atol=1e-4)
+    assert_close(db, b_.grad, atol=1e-5)
+    assert_close(dzr, zr_.grad, atol=1e-5)
+    if two_stream:
+        assert_close(dzf, zf_.grad, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C", [(8, 2), (5, 3), (1, 2)])
+def test_nce_loss_and_grads(ops, B, C):
+    from oracle import sais_oracle as O
+    emb = rnd(B, 256, seed=80)
+    protos = torch.rand(C, 256, generator=torch.Generator().manual_seed(81)).to(DEV)
+    lab = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(82))
+    sim, probs = torch.empty(B, C, device=DEV), torch.empty(B, C, device=DEV)
+    loss = torch.empty(1, device=DEV)
+    demb, dpro = torch.empty(B, 256, device=DEV), torch.zeros(C, 256, device=DEV)
+    ops.nce(emb, protos, lab.int().to(DEV), sim, probs, loss, demb, dpro)
+    e = emb.cpu().requires_grad_(True)
+    pd = {str(c): protos[c:c + 1].cpu().clone().requires_grad_(True) for c in range(C)}
+    ref = O.nce_loss(e, lab, pd)
+    ref.backward()
+    assert_close(sim, O.cosine_logits(e, pd).detach(), atol=1e-6)
+    assert_close(probs, O.probs_from_logits(O.cosine_logits(e, pd)).detach(), atol=1e-6)
+    assert abs(loss.item() - ref.item()) < 1e-6
+    assert_close(demb, e.grad, atol=1e-7)
+    assert_close(dpro, torch.cat([pd[str(c)].grad for c in range(C)]), atol=1e-7)
