@@ -6,6 +6,9 @@ module raises.  (tests/ use oracle/ as the checker; nothing here imports it.)
 import ctypes
 import os
 
+import torch  # noqa: F401  -- must come first: libsais_hip.so has to bind to the HIP runtime torch ships,
+#                             otherwise two runtimes coexist and launches fail with "no ROCm-capable device"
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsais_hip.so")
 
@@ -22,11 +25,15 @@ class SaisGemm(ctypes.Structure):
 
 EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
+EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
 
 # name -> argtypes; every symbol include/sais_hip.h declares (checked by tests/test_abi.py)
 SIGNATURES = {
     "sais_abi_version": [],
     "sais_gemm_nt": [ctypes.POINTER(SaisGemm), c_void_p],
+    "sais_gemm_nt_f32": [ctypes.POINTER(SaisGemm), c_void_p],
+    "sais_gemm_tn_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "sais_transpose_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_layernorm_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p,
                            c_long, c_void_p, c_void_p, c_void_p],
@@ -76,6 +83,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.sais_last_error.restype = ctypes.c_char_p
+    lib.sais_last_error.argtypes = []
     _lib = lib
     return lib
 
@@ -83,5 +92,6 @@ def load():
 def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
-        raise SaisHipError(f"{name} failed with code {rc}")
+        why = load().sais_last_error().decode() if rc == -2 else "invalid argument"
+        raise SaisHipError(f"{name} failed with code {rc}: {why}")
     return rc

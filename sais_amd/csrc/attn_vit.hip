@@ -292,6 +292,7 @@ int set_lds(K kernel, int bytes) {
 
 extern "C" int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, float* lse,
                                  float* probs, void* stream) {
+    SAIS_ENTER();
     if (!qkv || !out || frames <= 0 || (ldqkv & 7) || (ldo & 3)) return SAIS_ERR_ARG;
     if (set_lds(attn_fwd_kernel, FWD_LDS)) return SAIS_ERR_LAUNCH;
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(NH, frames), dim3(256), FWD_LDS, (hipStream_t)stream, (const bf16*)qkv,
@@ -301,6 +302,7 @@ extern "C" int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* 
 
 extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const float* lse,
                                  float* delta_ws, int frames, void* dqkv, long lddqkv, void* stream) {
+    SAIS_ENTER();
     if (!qkv || !dout || !lse || !delta_ws || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) || (lddqkv & 3))
         return SAIS_ERR_ARG;
     if (set_lds(attn_bwd_dq_kernel, FWD_LDS) || set_lds(attn_bwd_dkv_kernel, DKV_LDS)) return SAIS_ERR_LAUNCH;

@@ -59,7 +59,14 @@ DEVINL float dgelu_erf(float u) {
     return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
 }
 
+// hipGetLastError is sticky across the whole process (torch included): clear it on entry so that
+// sais_check_launch() reports only this call's own launch status.
+#define SAIS_ENTER() (void)hipGetLastError()
+
+extern "C" void sais_set_last_error(int hip_error);      // misc.hip
+
 static inline int sais_check_launch() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) sais_set_last_error((int)e);
     return e == hipSuccess ? SAIS_OK : SAIS_ERR_LAUNCH;
 }

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* 
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (bf16)src[i];
 }
 
-// dst[C,R] (bf16) = src[R,C]^T (f32); 32x32 tiles through LDS
-__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, bf16* dst, int R, int C) {
+// dst[C,R] = src[R,C]^T (f32 in, bf16 or f32 out); 32x32 tiles through LDS
+template <typename TO>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, TO* dst, int R, int C) {
     __shared__ float tile[32][33];
     int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, b
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         int c = c0 + j, r = r0 + tx;
-        if (c < C && r < R) dst[(size_t)c * R + r] = (bf16)tile[tx][j];
+        if (c < C && r < R) dst[(size_t)c * R + r] = (TO)tile[tx][j];
     }
 }
 
@@ -128,7 +129,12 @@ int grid_for(long n, int per_block = 256) {
 
 extern "C" int sais_abi_version(void) { return SAIS_ABI_VERSION; }
 
+static thread_local int g_last_hip_error = 0;
+extern "C" void sais_set_last_error(int e) { g_last_hip_error = e; }
+extern "C" const char* sais_last_error(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
+
 extern "C" int sais_patchify(const float* frames_f32, int frames, void* patches_bf16, void* stream) {
+    SAIS_ENTER();
     if (!frames_f32 || !patches_bf16 || frames <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)frames * 196 * 48)), dim3(256), 0, (hipStream_t)stream,
                        frames_f32, (bf16*)patches_bf16, frames);
@@ -137,6 +143,7 @@ extern "C" int sais_patchify(const float* frames_f32, int frames, void* patches_
 
 extern "C" int sais_vit_cls_rows(const float* cls, const float* pos0, float* tokens, long frame_stride, int frames,
                                  int dim, void* stream) {
+    SAIS_ENTER();
     if (!cls || !pos0 || !tokens || frames <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(cls_rows_kernel, dim3((frames * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls, pos0,
                        tokens, frame_stride, frames, dim);
@@ -145,6 +152,7 @@ extern "C" int sais_vit_cls_rows(const float* cls, const float* pos0, float* tok
 
 extern "C" int sais_vit_embed_bwd(const float* dtokens, int frames, int ntok, int dim, float* dcls, float* dpos,
                                   void* dpatch_bf16, void* stream) {
+    SAIS_ENTER();
     if (!dtokens || !dcls || !dpos || !dpatch_bf16 || frames <= 0 || (dim & 3)) return SAIS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(cls_rows_bwd_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, dtokens, (long)ntok * dim, frames,
@@ -157,6 +165,7 @@ extern "C" int sais_vit_embed_bwd(const float* dtokens, int frames, int ntok, in
 
 extern "C" int sais_sgd_step(float* param, const float* grad, void* shadow_bf16, long n, float lr, float grad_scale,
                              void* stream) {
+    SAIS_ENTER();
     if (!param || !grad || n <= 0) return SAIS_ERR_ARG;
     if (((uintptr_t)param | (uintptr_t)grad) & 15) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad,
@@ -165,19 +174,30 @@ extern "C" int sais_sgd_step(float* param, const float* grad, void* shadow_bf16,
 }
 
 extern "C" int sais_cast_bf16(const float* src, void* dst_bf16, long n, void* stream) {
+    SAIS_ENTER();
     if (!src || !dst_bf16 || n <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst_bf16, n);
     return sais_check_launch();
 }
 
 extern "C" int sais_transpose_cast_bf16(const float* src, int rows, int cols, void* dst_bf16, void* stream) {
+    SAIS_ENTER();
     if (!src || !dst_bf16 || rows <= 0 || cols <= 0) return SAIS_ERR_ARG;
-    hipLaunchKernelGGL(transpose_cast_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+    hipLaunchKernelGGL(transpose_cast_kernel<bf16>, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
                        (hipStream_t)stream, src, (bf16*)dst_bf16, rows, cols);
     return sais_check_launch();
 }
 
+extern "C" int sais_transpose_f32(const float* src, int rows, int cols, float* dst, void* stream) {
+    SAIS_ENTER();
+    if (!src || !dst || rows <= 0 || cols <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(transpose_cast_kernel<float>, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, rows, cols);
+    return sais_check_launch();
+}
+
 extern "C" int sais_scale_f32(float* p, long n, float s, void* stream) {
+    SAIS_ENTER();
     if (!p || n <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, s);
     return sais_check_launch();

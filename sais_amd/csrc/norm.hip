@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy16, long lddy
 extern "C" int sais_layernorm_fwd(const float* x, long ldx, int rows, int dim, const float* gamma, const float* beta,
                                   float eps, void* y_bf16, long ldy16, float* y_f32, long ldy32, float* mean,
                                   float* rstd, void* stream) {
+    SAIS_ENTER();
     if (!x || !gamma || !beta || dim != D || rows <= 0 || (ldx & 3) || (ldy16 & 3) || (ldy32 & 3)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, gamma,
                        beta, eps, (bf16*)y_bf16, ldy16, y_f32, ldy32, mean, rstd);
@@ -154,6 +155,7 @@ extern "C" int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float*
                                   long ldx, const float* mean, const float* rstd, const float* gamma,
                                   const float* dres, long lddres, int rows, int dim, float* dx_f32, long lddx32,
                                   void* dx_bf16, long lddx16, float* dgamma, float* dbeta, void* stream) {
+    SAIS_ENTER();
     if (!x || !mean || !rstd || !gamma || dim != D || rows <= 0 || (!dy_bf16 && !dy_f32)) return SAIS_ERR_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SAIS_ERR_ARG;
     int grid = (rows + 7) / 8;

@@ -31,9 +31,11 @@ __global__ void prepare_fwd_kernel(const float* x, long x_clip_stride, long x_fr
             v += *(const f32x4*)(pos + (size_t)(s - 1) * D + 4 * c4);
         }
         *(f32x4*)(z32 + (size_t)r * D + 4 * c4) = v;
-        bf16x4 o;
-        o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
-        *(bf16x4*)(z16 + (size_t)r * D + 4 * c4) = o;
+        if (z16) {
+            bf16x4 o;
+            o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+            *(bf16x4*)(z16 + (size_t)r * D + 4 * c4) = o;
+        }
     }
 }
 
@@ -59,13 +61,13 @@ __global__ void prepare_bwd_kernel(const float* dz32, const bf16* dz16, int B, i
 }
 
 // ---------------------------------------------------------------- masked multi-head attention, one WG per (clip, head)
-DEVINL void load_head(const bf16* qkv, int b, int h, int S, int which, float* dst, int tid) {
+DEVINL void load_head(const float* qkv, int b, int h, int S, int which, float* dst, int tid) {
     // dst[s][QS] <- qkv[(b*S+s), which*384 + h*96 + d]
-    for (int i = tid; i < S * (THD / 8); i += 256) {
-        int s = i / (THD / 8), c8 = i % (THD / 8);
-        bf16x8 v = *(const bf16x8*)(qkv + ((size_t)b * S + s) * (3 * D) + which * D + h * THD + 8 * c8);
+    for (int i = tid; i < S * (THD / 4); i += 256) {
+        int s = i / (THD / 4), c4 = i % (THD / 4);
+        f32x4 v = *(const f32x4*)(qkv + ((size_t)b * S + s) * (3 * D) + which * D + h * THD + 4 * c4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[s * QS + 8 * c8 + e] = (float)v[e];
+        for (int e = 0; e < 4; ++e) dst[s * QS + 4 * c4 + e] = v[e];
     }
 }
 
@@ -94,7 +96,7 @@ DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void tattn_fwd_kernel(const bf16* qkv, const unsigned char* key_pad, int S, bf16* ctx,
+__global__ __launch_bounds__(256) void tattn_fwd_kernel(const float* qkv, const unsigned char* key_pad, int S, float* ctx,
                                                         float* attn_avg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = (float*)smem;
@@ -114,12 +116,12 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const bf16* qkv, const u
         int i = idx / THD, d = idx % THD;
         float a = 0.f;
         for (int j = 0; j < S; ++j) a += sP[i * SP + j] * sV[j * QS + d];
-        ctx[((size_t)b * S + i) * D + h * THD + d] = (bf16)a;
+        ctx[((size_t)b * S + i) * D + h * THD + d] = a;
     }
 }
 
-__global__ __launch_bounds__(256) void tattn_bwd_kernel(const bf16* qkv, const unsigned char* key_pad, int S,
-                                                        const bf16* dctx, bf16* dqkv) {
+__global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const unsigned char* key_pad, int S,
+                                                        const float* dctx, float* dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = (float*)smem;
     float* sK = sQ + S * QS;
@@ -132,11 +134,11 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const bf16* qkv, const u
     load_head(qkv, b, h, S, 0, sQ, tid);
     load_head(qkv, b, h, S, 1, sK, tid);
     load_head(qkv, b, h, S, 2, sV, tid);
-    for (int i = tid; i < S * (THD / 8); i += 256) {
-        int s = i / (THD / 8), c8 = i % (THD / 8);
-        bf16x8 v = *(const bf16x8*)(dctx + ((size_t)b * S + s) * D + h * THD + 8 * c8);
+    for (int i = tid; i < S * (THD / 4); i += 256) {
+        int s = i / (THD / 4), c4 = i % (THD / 4);
+        f32x4 v = *(const f32x4*)(dctx + ((size_t)b * S + s) * D + h * THD + 4 * c4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sG[s * QS + 8 * c8 + e] = (float)v[e];
+        for (int e = 0; e < 4; ++e) sG[s * QS + 4 * c4 + e] = v[e];
     }
     __syncthreads();
     probs_lds(sQ, sK, key_pad + (size_t)b * S, S, scale, sP, tid);
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const bf16* qkv, const u
         int j = idx / THD, d = idx % THD;
         float a = 0.f;
         for (int i = 0; i < S; ++i) a += sP[i * SP + j] * sG[i * QS + d];
-        dqkv[((size_t)b * S + j) * (3 * D) + 2 * D + h * THD + d] = (bf16)a;
+        dqkv[((size_t)b * S + j) * (3 * D) + 2 * D + h * THD + d] = a;
     }
     // dP[i][j] = dctx_i . v_j
     for (int idx = tid; idx < S * S; idx += 256) {
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const bf16* qkv, const u
             ak += sS[j * SP + i] * sQ[j * QS + d];      // dk_i = sum_j dS[j][i] q_j
         }
         size_t row = ((size_t)b * S + i) * (3 * D) + h * THD + d;
-        dqkv[row] = (bf16)aq;
-        dqkv[row + D] = (bf16)ak;
+        dqkv[row] = aq;
+        dqkv[row + D] = ak;
     }
 }
 
@@ -305,7 +307,8 @@ int set_lds(K kernel, int bytes) {
 
 extern "C" int sais_temporal_prepare_fwd(const float* x, long x_clip_stride, long x_frame_stride, const float* pos,
                                          const float* cls, int B, int T, float* z_f32, void* z_bf16, void* stream) {
-    if (!x || !pos || !cls || !z_f32 || !z_bf16 || B <= 0 || T <= 0 || (x_clip_stride & 3) || (x_frame_stride & 3))
+    SAIS_ENTER();
+    if (!x || !pos || !cls || !z_f32 || B <= 0 || T <= 0 || (x_clip_stride & 3) || (x_frame_stride & 3))
         return SAIS_ERR_ARG;
     long total = (long)B * (T + 1) * (D / 4);
     hipLaunchKernelGGL(prepare_fwd_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
@@ -316,37 +319,39 @@ extern "C" int sais_temporal_prepare_fwd(const float* x, long x_clip_stride, lon
 extern "C" int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf16, int B, int T, float* dx,
                                          long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos,
                                          float* dcls, void* stream) {
+    SAIS_ENTER();
     if (!dz_f32 || !dpos || !dcls || B <= 0 || T <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(prepare_bwd_kernel, dim3(((T + 1) * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz_f32,
                        (const bf16*)dz_bf16, B, T, dx, dx_clip_stride, dx_frame_stride, accumulate, dpos, dcls);
     return sais_check_launch();
 }
 
-extern "C" int sais_temporal_attn_fwd(const void* qkv_bf16, const unsigned char* key_pad, int B, int S, void* ctx_bf16,
+extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key_pad, int B, int S, float* ctx,
                                       float* attn_avg, void* stream) {
-    if (!qkv_bf16 || !key_pad || !ctx_bf16 || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_FWD) return SAIS_ERR_ARG;
+    SAIS_ENTER();
+    if (!qkv || !key_pad || !ctx || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_FWD) return SAIS_ERR_ARG;
     int lds = (3 * S * QS + S * (S + 1)) * 4;
     if (set_lds(tattn_fwd_kernel, lds)) return SAIS_ERR_LAUNCH;
     hipStream_t s = (hipStream_t)stream;
     if (attn_avg && hipMemsetAsync(attn_avg, 0, (size_t)B * S * S * 4, s) != hipSuccess) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(256), lds, s, (const bf16*)qkv_bf16, key_pad, S,
-                       (bf16*)ctx_bf16, attn_avg);
+    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(256), lds, s, qkv, key_pad, S, ctx, attn_avg);
     return sais_check_launch();
 }
 
-extern "C" int sais_temporal_attn_bwd(const void* qkv_bf16, const unsigned char* key_pad, int B, int S,
-                                      const void* dctx_bf16, void* dqkv_bf16, void* stream) {
-    if (!qkv_bf16 || !key_pad || !dctx_bf16 || !dqkv_bf16 || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_BWD)
+extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B, int S,
+                                      const float* dctx, float* dqkv, void* stream) {
+    SAIS_ENTER();
+    if (!qkv || !key_pad || !dctx || !dqkv || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_BWD)
         return SAIS_ERR_ARG;
     int lds = (4 * S * QS + 2 * S * (S + 1)) * 4;
     if (set_lds(tattn_bwd_kernel, lds)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv_bf16,
-                       key_pad, S, (const bf16*)dctx_bf16, (bf16*)dqkv_bf16);
+    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(256), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, dqkv);
     return sais_check_launch();
 }
 
 extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, int B, const float* W,
                              const float* bias, float* rep, float* emb, void* stream) {
+    SAIS_ENTER();
     if ((!z_rgb && !z_flow) || !W || !bias || !rep || !emb || B <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride, W, bias,
                        rep, emb);
@@ -356,6 +361,7 @@ extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_
 extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb,
                              const float* z_flow, long clip_stride, int B, float* dW, float* dbias, float* dz_rgb,
                              float* dz_flow, void* stream) {
+    SAIS_ENTER();
     if (!demb || !W || !rep || !dW || !dbias || B <= 0) return SAIS_ERR_ARG;
     if ((z_rgb && !dz_rgb) || (z_flow && !dz_flow)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, demb, W, rep, z_rgb, z_flow,
@@ -365,6 +371,7 @@ extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep
 
 extern "C" int sais_nce(const float* emb, const float* protos, const int* label_col, int B, int C, float* sim,
                         float* probs, float* loss, float* demb, float* dprotos, float loss_scale, void* stream) {
+    SAIS_ENTER();
     if (!emb || !protos || B <= 0 || C <= 0 || (demb && (!dprotos || !label_col))) return SAIS_ERR_ARG;
     int lds = (B + C + 2 * B * C + B) * 4;
     if (lds > 64 * 1024) return SAIS_ERR_ARG;

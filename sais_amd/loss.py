@@ -1,0 +1,60 @@
+"""SupCon / prototype-cosine head of SAIS on MI355X — drop-in for
+SAIS/scripts/prepare_miscellaneous.py:14-46 (`calcNCELoss`), :111-126 (`getProbs`) and
+process_inference_results.py:76-91 (`calcProbs`).  One single-workgroup fp32 kernel (`sais_nce`)
+computes the L2 norms, the cosine "class logits", softmax probabilities, the loss and — when
+gradients are needed — d emb and d prototypes in the same launch."""
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _stack(prototypes):
+    keys = list(prototypes.keys())
+    return torch.cat([prototypes[k].reshape(1, -1) for k in keys], dim=0).float().contiguous(), keys
+
+
+def _label_cols(labels, keys, device):
+    # column of the prototype whose key == str(label)  (prepare_miscellaneous.py:31-37)
+    cols = [keys.index(str(int(l))) for l in (labels.tolist() if torch.is_tensor(labels) else labels)]
+    return torch.tensor(cols, dtype=torch.int32, device=device)
+
+
+class _NCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, cols, *protos):
+        p = torch.cat([q.reshape(1, -1) for q in protos], dim=0).float().contiguous()
+        emb = emb.float().contiguous()
+        B, C = emb.shape[0], p.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=emb.device)
+        demb = torch.empty_like(emb)
+        dpro = torch.zeros_like(p)
+        ops.nce(emb, p, cols, None, None, loss, demb, dpro, 1.0)
+        ctx.save_for_backward(demb, dpro)
+        ctx.shapes = [q.shape for q in protos]
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        demb, dpro = ctx.saved_tensors
+        return (demb * g, None) + tuple((dpro[i] * g).view(s) for i, s in enumerate(ctx.shapes))
+
+
+def calcNCELoss(rank, snip_sequence, labels, videoname, gesture_prototypes, domains):
+    """Same signature as the reference; `rank`, `videoname`, `domains` are accepted and unused, as there."""
+    if not snip_sequence.is_cuda:
+        raise L.SaisHipError("calcNCELoss needs device tensors: the HIP path has no CPU fallback")
+    keys = list(gesture_prototypes.keys())
+    cols = _label_cols(labels, keys, snip_sequence.device)
+    return _NCEFn.apply(snip_sequence, cols, *[gesture_prototypes[k] for k in keys])
+
+
+def cosine_logits_and_probs(snip_sequence, gesture_prototypes):
+    """sim [B,C] (the class logits) and probs = softmax(sim) — getProbs / calcProbs."""
+    p, _ = _stack(gesture_prototypes)
+    emb = snip_sequence.detach().float().contiguous()
+    B, C = emb.shape[0], p.shape[0]
+    sim = torch.empty(B, C, dtype=torch.float32, device=emb.device)
+    probs = torch.empty_like(sim)
+    ops.nce(emb, p.detach(), None, sim, probs, None, None, None, 1.0)
+    return sim, probs

@@ -41,16 +41,28 @@ def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0,
     return out
 
 
+def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None):
+    """fp32-operand variant (bf16x3 split on the matrix cores): out f32[M,N] = a f32[M,K] . w f32[N,K]^T."""
+    _chk(a, F32, "A"); _chk(w, F32, "B"); _chk(bias, F32, "bias"); _chk(out, F32, "out"); _chk(aux, F32, "aux")
+    M = a.shape[0] if M is None else M
+    N, K = w.shape
+    g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
+                   _p(out), out.stride(-2), None, 0, _p(aux), 0 if aux is None else aux.stride(-2), 0, 0, 0)
+    L.call("sais_gemm_nt_f32", ctypes.byref(g), _stream())
+    return out
+
+
 def gemm_tn(p, q, dW, db=None, nsplit=None):
-    """dW[N1,N2] += p[M,N1]^T . q[M,N2] ; db[N1] += colsum(p)."""
-    _chk(p, BF16, "P"); _chk(q, BF16, "Q"); _chk(dW, F32, "dW"); _chk(db, F32, "db")
+    """dW[N1,N2] += p[M,N1]^T . q[M,N2] ; db[N1] += colsum(p).  p, q both bf16 or both f32."""
+    f32 = p.dtype == F32
+    _chk(p, F32 if f32 else BF16, "P"); _chk(q, F32 if f32 else BF16, "Q"); _chk(dW, F32, "dW"); _chk(db, F32, "db")
     M, N1 = p.shape
     N2 = q.shape[1]
     if nsplit is None:
         tiles = (N1 // 128) * (N2 // 128)
         nsplit = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles))
-    L.call("sais_gemm_tn", _p(p), p.stride(0), _p(q), q.stride(0), M, N1, N2, _p(dW), dW.stride(0), _p(db), nsplit,
-           _stream())
+    L.call("sais_gemm_tn_f32" if f32 else "sais_gemm_tn", _p(p), p.stride(0), _p(q), q.stride(0), M, N1, N2, _p(dW),
+           dW.stride(0), _p(db), nsplit, _stream())
 
 
 def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None, rstd=None, ldy16=384, ldy32=384):
@@ -99,6 +111,10 @@ def cast_bf16(src, dst):
 
 def transpose_cast_bf16(src, rows, cols, dst):
     L.call("sais_transpose_cast_bf16", _p(src), rows, cols, _p(dst), _stream())
+
+
+def transpose_f32(src, rows, cols, dst):
+    L.call("sais_transpose_f32", _p(src), rows, cols, _p(dst), _stream())
 
 
 def scale_(t, s):

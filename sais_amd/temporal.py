@@ -1,0 +1,296 @@
+"""Temporal TransformerEncoder + prototype head of SAIS on MI355X — drop-in for the hot-path slice of
+the reference's `fullModel` (SAIS/scripts/prepare_model.py:18-488): data_type='reps',
+encoder_type='ViT', task='Prototypes', self_attention=True (what main.sh:27 runs).
+
+Same constructor / forward signatures, same parameter names and shapes (4118 keys
+incl. the 2x2000 single-row position parameters and the never-used clip/MIL tensors), so
+`params.zip` loads strictly once the `module.` prefix is stripped and `encoder.*` ballast dropped.
+
+forward(x, f, xlens, flens, task, xpad, fpad, domains) -> (emb [B,256], attn [B,T+1,T+1])
+(list inputs = test-time-augmentation versions -> (list of embs, attn of version 0), :331-346).
+
+Kernels: prepare (CLS + positions) -> 4 x [MFMA in_proj -> LDS masked attention (+ head-averaged map
+on the last layer) -> MFMA out_proj + residual -> LN -> MFMA linear1 + ReLU -> MFMA linear2 + residual
+-> LN] -> fused ReLU/CLS/two-stream-add/ReLU/Linear(384->256) head.  Backward is hand-written as well.
+The MFMA GEMMs here are the fp32-operand "bf16x3" variant (sais_gemm_nt_f32).
+
+Deliberate differences: inputs are never mutated (the reference does `x += pos` in place,
+:192, and `rgb += flow`, :412); dropout (p=0.1, train() only, RNG-dependent) is the identity;
+nsnippets must be 1; MIL / ClassificationHead / R3D / raw branches are out of scope and raise.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .flat import FlatParams
+
+D, TH, FF, EMB, NPOS = 384, 4, 2048, 256, 2000
+
+
+def _make_encoder(rep_dim):
+    layer = nn.TransformerEncoderLayer(d_model=rep_dim, nhead=TH)       # prepare_model.py:75
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return nn.TransformerEncoder(layer, num_layers=4)               # :76 (deep-copies one layer)
+
+
+class _TemporalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, f, xpad, fpad, anchor):
+        emb, attn, saved = model._forward_kernels(x, f, xpad, fpad, save=True)
+        ctx.model, ctx.saved = model, saved
+        ctx.needs = (x is not None and x.requires_grad, f is not None and f.requires_grad)
+        ctx.mark_non_differentiable(attn)
+        return emb, attn
+
+    @staticmethod
+    def backward(ctx, demb, _dattn):
+        dx, df = ctx.model._backward_kernels(ctx.saved, demb.contiguous(), ctx.needs)
+        ctx.saved = None
+        return None, dx, df, None, None, None
+
+
+class fullModel(nn.Module):
+    def __init__(self, data_type='raw', nclasses=2, domain='NH_02', rep_dim=512, encoder_type='R3D',
+                 modalities='RGB-Flow', encoder_depth=18, load_pretrained_params=True, freeze_encoder_params=True,
+                 self_attention=True, importance_loss=False):
+        super().__init__()
+        if data_type != 'reps' or encoder_type != 'ViT' or rep_dim != D or not self_attention:
+            raise NotImplementedError("MI355X hot path = fullModel('reps', ..., 384, 'ViT', self_attention=True); "
+                                      "raw / R3D / I3D branches are out of scope (SURVEY §2)")
+        if importance_loss:
+            raise NotImplementedError("importance head (-il, prepare_model.py:55-56) is a 'next' row (SURVEY §8 a13)")
+        if modalities not in ('RGB', 'Flow', 'RGB-Flow'):
+            raise ValueError(modalities)
+        # registration order mirrors the reference so state_dict ordering matches too
+        self.linear = nn.Linear(rep_dim, EMB)
+        if '+' in domain:
+            self.linearB = nn.Linear(rep_dim, EMB)
+        self.linear2 = nn.Linear(EMB, 3)                                 # :50 (dead on this path, App. B.5)
+        self.frame_cls = nn.Parameter(torch.rand(1, rep_dim))
+        self.clip_cls = nn.Parameter(torch.rand(1, rep_dim))
+        # filled one key at a time (as the reference does, :64-69): ParameterDict(dict) would SORT the keys
+        # lexicographically, and rows 0..T-1 must be consecutive in the flat buffer for the prepare kernel
+        self.frame_pos_embeddings = nn.ParameterDict()
+        self.clip_pos_embeddings = nn.ParameterDict()
+        for table in (self.frame_pos_embeddings, self.clip_pos_embeddings):
+            for i in range(NPOS):
+                table[str(i)] = nn.Parameter(torch.rand(1, rep_dim))
+        self.transEncoderFrame = _make_encoder(rep_dim)
+        self.transEncoderClip = _make_encoder(rep_dim)
+        self.attentionA = nn.Linear(rep_dim, EMB)
+        self.attentionB = nn.Linear(rep_dim, EMB)
+        self.attentionModules = nn.ModuleDict({str(c): nn.Linear(EMB, 1) for c in range(3)})
+        self.finalModules = nn.ModuleDict({str(c): nn.Linear(rep_dim, 1) for c in range(3)})
+        self.nclasses, self.domain, self.rep_dim = nclasses, domain, rep_dim
+        self.modalities, self.self_attention, self.importance_loss = modalities, self_attention, importance_loss
+        self.data_type, self.encoder_type = data_type, encoder_type
+        self.flat = None
+        self._sig = None
+        self._anchor = None
+        self.grad_ready_hook = None
+
+    # ------------------------------------------------------------------ engine plumbing
+    @property
+    def nlayers(self):
+        return len(self.transEncoderFrame.layers)
+
+    def _lnames(self, l):
+        return f"transEncoderFrame.layers.{l}."
+
+    def _t_names(self):
+        out = []
+        for l in range(self.nlayers):
+            p = self._lnames(l)
+            out += [p + "self_attn.in_proj_weight", p + "self_attn.out_proj.weight", p + "linear1.weight",
+                    p + "linear2.weight"]
+        return out
+
+    def _sentinels(self):
+        return ["linear.weight", "frame_cls", "frame_pos_embeddings.0", self._lnames(0) + "self_attn.in_proj_weight",
+                self._lnames(self.nlayers - 1) + "linear2.weight"]
+
+    def _engine(self, device):
+        if self.flat is None or not self.flat.intact() or self.flat.device != device:
+            self.flat = FlatParams(self, device, f32_transposes=True)
+            self._anchor = torch.zeros(1, device=device, requires_grad=True)
+            self._sig = None
+        sig = self.flat.signature(self._sentinels())
+        if sig != self._sig:
+            self.flat.refresh_shadows(self._t_names())
+            self._sig = self.flat.signature(self._sentinels())
+        return self.flat
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._sig = None
+        return r
+
+    def sgd_step(self, lr, grad_scale=1.0):
+        self.flat.sgd_step(lr, grad_scale, self._t_names())
+        self._sig = self.flat.signature(self._sentinels())
+
+    # ------------------------------------------------------------------ reference signature
+    def forward(self, x, f, xlens, flens, task, xpad, fpad, domains=None):
+        if task != 'Prototypes':
+            raise NotImplementedError(f"task {task!r}: only 'Prototypes' is on the MI355X hot path")
+        if isinstance(x, (list, tuple)) or isinstance(f, (list, tuple)):          # TTA versions, :331-346
+            n = len(x) if x is not None else len(f)
+            embs, attn0 = [], None
+            for v in range(n):
+                e, a = self._forward_one(None if x is None else x[v], None if f is None else f[v],
+                                         None if xpad is None else xpad[v], None if fpad is None else fpad[v])
+                embs.append(e)
+                if v == 0:
+                    attn0 = a
+            return embs, attn0
+        return self._forward_one(x, f, xpad, fpad)
+
+    def _forward_one(self, x, f, xpad, fpad):
+        use_x = self.modalities in ('RGB', 'RGB-Flow')
+        use_f = self.modalities in ('Flow', 'RGB-Flow')
+        x = self._check(x, "x") if use_x else None
+        f = self._check(f, "f") if use_f else None
+        dev = (x if x is not None else f).device
+        xpad = self._mask(xpad, x, dev) if use_x else None
+        fpad = self._mask(fpad, f, dev) if use_f else None
+        self._engine(dev)
+        if torch.is_grad_enabled() and self.linear.weight.requires_grad:
+            return _TemporalFn.apply(self, x, f, xpad, fpad, self._anchor)
+        emb, attn, _ = self._forward_kernels(x, f, xpad, fpad, save=False)
+        return emb, attn
+
+    @staticmethod
+    def _check(t, name):
+        if t is None:
+            raise ValueError(f"{name} is required for this modality")
+        if not t.is_cuda:
+            raise L.SaisHipError("fullModel.forward needs device tensors: the HIP path has no CPU fallback")
+        if t.dim() != 4 or t.shape[1] != 1 or t.shape[3] != D:
+            raise NotImplementedError(f"{name}: expected [B,1,T,384] (nsnippets == 1), got {tuple(t.shape)}")
+        return t.float()
+
+    @staticmethod
+    def _mask(pad, t, dev):
+        B, _, T, _ = t.shape
+        if pad is None:
+            return torch.zeros(B, T + 1, dtype=torch.uint8, device=dev)
+        pad = pad.reshape(B, T + 1)                                             # :209
+        return pad.to(device=dev, dtype=torch.uint8).contiguous()
+
+    # ------------------------------------------------------------------ kernels
+    # All temporal activations are fp32 in HBM (they are tiny: clips*(T+1) rows) and every nn.Linear runs
+    # on sais_gemm_nt_f32 (bf16x3 split on the matrix cores): the cosine logits inherit ~fp32 accuracy
+    # from this half of the path, leaving the whole 1e-3 budget to the bf16 ViT.
+    def _stream_fwd(self, x, pad, save, want_attn):
+        fl = self.flat
+        dev = x.device
+        B, _, T, _ = x.shape
+        S, M = T + 1, B * (T + 1)
+        if T > NPOS:
+            raise ValueError("at most 2000 frames (position table, prepare_model.py:67)")
+        e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        z = e32(M, D)
+        o = fl.offsets["frame_pos_embeddings.0"]
+        assert fl.offsets[f"frame_pos_embeddings.{T - 1}"] == o + (T - 1) * D      # rows contiguous in the flat buffer
+        ops.temporal_prepare_fwd(x, x.stride(0), x.stride(2), fl.flat[o:o + T * D], fl.w32("frame_cls"), B, T, z, None)
+        layers = []
+        attn = None
+        for l in range(self.nlayers):
+            p = self._lnames(l)
+            last = l == self.nlayers - 1
+            qkv, ctx = e32(M, 3 * D), e32(M, D)
+            ops.gemm_nt_f32(z, fl.w32(p + "self_attn.in_proj_weight"), L.EPI_BIAS_F32, qkv,
+                            bias=fl.w32(p + "self_attn.in_proj_bias"))
+            if want_attn and last:
+                attn = e32(B, S, S)
+            ops.temporal_attn_fwd(qkv, pad, B, S, ctx, attn if last else None)
+            y1 = e32(M, D)
+            ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_RESID_F32, y1,
+                            bias=fl.w32(p + "self_attn.out_proj.bias"), aux=z)
+            z1, m1, r1 = e32(M, D), e32(M), e32(M)
+            ops.layernorm_fwd(y1, M, D, fl.w32(p + "norm1.weight"), fl.w32(p + "norm1.bias"), 1e-5, y32=z1, mean=m1, rstd=r1)
+            h = e32(M, FF)
+            ops.gemm_nt_f32(z1, fl.w32(p + "linear1.weight"), L.EPI_BIAS_RELU_F32, h, bias=fl.w32(p + "linear1.bias"))
+            y2 = e32(M, D)
+            ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_RESID_F32, y2, bias=fl.w32(p + "linear2.bias"),
+                            aux=z1)
+            zo, m2, r2 = e32(M, D), e32(M), e32(M)
+            ops.layernorm_fwd(y2, M, D, fl.w32(p + "norm2.weight"), fl.w32(p + "norm2.bias"), 1e-5, y32=zo, mean=m2, rstd=r2)
+            if save:
+                layers.append(dict(z=z, qkv=qkv, ctx=ctx, y1=y1, m1=m1, r1=r1, z1=z1, h=h, y2=y2, m2=m2, r2=r2))
+            z = zo
+        return z, attn, dict(layers=layers, pad=pad, B=B, T=T, x=x) if save else None
+
+    def _forward_kernels(self, x, f, xpad, fpad, save):
+        fl = self.flat
+        zr = zf = sr = sf = attn = None
+        if x is not None:
+            zr, attn, sr = self._stream_fwd(x, xpad, save, want_attn=True)
+        if f is not None:
+            zf, fattn, sf = self._stream_fwd(f, fpad, save, want_attn=(x is None))
+            if x is None:
+                attn = fattn
+        ref = x if x is not None else f
+        B, S = ref.shape[0], ref.shape[2] + 1
+        if zr is not None and zf is not None and zr.shape != zf.shape:
+            raise ValueError("RGB and flow streams must have the same padded length")
+        rep = torch.empty(B, D, dtype=torch.float32, device=ref.device)
+        emb = torch.empty(B, EMB, dtype=torch.float32, device=ref.device)
+        ops.head_fwd(zr, zf, S * D, B, fl.w32("linear.weight"), fl.w32("linear.bias"), rep, emb)
+        saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, S=S) if save else None
+        return emb, attn, saved
+
+    def _stream_bwd(self, s, dz, need_dx):
+        """dz: f32 [M,384] gradient wrt the stream's final (pre-ReLU) encoder output."""
+        fl = self.flat
+        dev = dz.device
+        B, T = s["B"], s["T"]
+        S, M = T + 1, B * (T + 1)
+        e32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        for l in reversed(range(self.nlayers)):
+            p = self._lnames(l)
+            a = s["layers"][l]
+            dy2 = e32(M, D)
+            ops.layernorm_bwd(a["y2"], D, a["m2"], a["r2"], fl.w32(p + "norm2.weight"), M, dy32=dz, dx32=dy2,
+                              dgamma=fl.g(p + "norm2.weight"), dbeta=fl.g(p + "norm2.bias"))
+            dh = e32(M, FF)
+            ops.gemm_nt_f32(dy2, fl.wt16[p + "linear2.weight"], L.EPI_DRELU_F32, dh, aux=a["h"])
+            ops.gemm_tn(dy2, a["h"], fl.g(p + "linear2.weight"), fl.g(p + "linear2.bias"))
+            dz1 = e32(M, D)                                   # = dy2 (residual) + dh . W1
+            ops.gemm_nt_f32(dh, fl.wt16[p + "linear1.weight"], L.EPI_BIAS_RESID_F32, dz1, aux=dy2)
+            ops.gemm_tn(dh, a["z1"], fl.g(p + "linear1.weight"), fl.g(p + "linear1.bias"))
+            dy1 = e32(M, D)
+            ops.layernorm_bwd(a["y1"], D, a["m1"], a["r1"], fl.w32(p + "norm1.weight"), M, dy32=dz1, dx32=dy1,
+                              dgamma=fl.g(p + "norm1.weight"), dbeta=fl.g(p + "norm1.bias"))
+            dctx = e32(M, D)
+            ops.gemm_nt_f32(dy1, fl.wt16[p + "self_attn.out_proj.weight"], L.EPI_BIAS_F32, dctx)
+            ops.gemm_tn(dy1, a["ctx"], fl.g(p + "self_attn.out_proj.weight"), fl.g(p + "self_attn.out_proj.bias"))
+            dqkv = e32(M, 3 * D)
+            ops.temporal_attn_bwd(a["qkv"], s["pad"], B, S, dctx, dqkv)
+            dz = e32(M, D)                                    # = dy1 (residual) + dqkv . Win
+            ops.gemm_nt_f32(dqkv, fl.wt16[p + "self_attn.in_proj_weight"], L.EPI_BIAS_RESID_F32, dz, aux=dy1)
+            ops.gemm_tn(dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))
+        x = s["x"]
+        dx = torch.empty_like(x) if need_dx else None
+        o = fl.offsets["frame_pos_embeddings.0"]
+        ops.temporal_prepare_bwd(dz, None, B, T, dx, 0 if dx is None else dx.stride(0), 0 if dx is None else dx.stride(2),
+                                 False, fl.grad[o:o + T * D], fl.g("frame_cls"))
+        return dx
+
+    def _backward_kernels(self, saved, demb, needs):
+        fl = self.flat
+        fl.attach_grads()
+        B, S = saved["B"], saved["S"]
+        zr, zf = saved["zr"], saved["zf"]
+        dzr = torch.zeros_like(zr) if zr is not None else None
+        dzf = torch.zeros_like(zf) if zf is not None else None
+        ops.head_bwd(demb, fl.w32("linear.weight"), saved["rep"], zr, zf, S * D, B, fl.g("linear.weight"),
+                     fl.g("linear.bias"), dzr, dzf)
+        dx = self._stream_bwd(saved["sr"], dzr, needs[0]) if zr is not None else None
+        df = self._stream_bwd(saved["sf"], dzf, needs[1]) if zf is not None else None
+        if self.grad_ready_hook:
+            self.grad_ready_hook(0, fl.numel)
+        return dx, df

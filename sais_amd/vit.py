@@ -1,0 +1,280 @@
+"""DINO ViT-S/16 spatial encoder on MI355X — drop-in for the reference's
+SAIS/scripts/dino-main/vision_transformer.py (`vit_small`, `VisionTransformer.forward` :209-214,
+`get_last_selfattention` :216-223) with the same parameter names / shapes (150-tensor state_dict,
+SURVEY App. A), so `dino_deitsmall16_pretrain.pth` loads strictly.
+
+Every block runs as hand-written gfx950 kernels through the C ABI (include/sais_hip.h):
+  LN -> [MFMA GEMM qkv] -> [LDS-resident attention] -> [MFMA GEMM proj + residual] ->
+  LN -> [MFMA GEMM fc1 + GELU] -> [MFMA GEMM fc2 + residual]
+with bf16 MFMA operands, fp32 accumulation, fp32 residual stream and fp32 LN/softmax statistics.
+Backward is hand-written too (dX GEMMs on pre-transposed bf16 weight shadows, dW GEMMs with
+transposed LDS reads, recompute-from-LSE attention backward); parameter gradients are accumulated
+by the kernels directly into the flat gradient buffer that p.grad views.
+
+Deliberate differences from the reference (documented in DESIGN.md): only the ViT-S/16 @224
+geometry is supported; DropPath (stochastic, train() only, never used by SAIS which runs the ViT in
+eval(): extract_representations.py:362) is the identity.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .flat import FlatParams
+
+D, NTOK, HEADS, HID, PATCH_K = 384, 197, 6, 1536, 768
+
+
+class _Attention(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.qkv = nn.Linear(D, 3 * D, bias=True)
+        self.proj = nn.Linear(D, D)
+
+
+class _Mlp(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(D, HID)
+        self.fc2 = nn.Linear(HID, D)
+
+
+class _Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(D, eps=1e-6)
+        self.attn = _Attention()
+        self.norm2 = nn.LayerNorm(D, eps=1e-6)
+        self.mlp = _Mlp()
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.proj = nn.Conv2d(3, D, kernel_size=16, stride=16)
+        self.num_patches = 196
+        self.patch_size = 16
+
+
+def _trunc_normal_(t, std=0.02):
+    # utils.trunc_normal_ (dino-main/utils.py:513-551) with a=-2, b=2
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+class _ViTFn(torch.autograd.Function):
+    """Whole-ViT forward/backward as one autograd node.  Parameter gradients are written by the HIP
+    kernels into model.flat.grad (p.grad views) as a side effect; `anchor` only keeps the node alive."""
+
+    @staticmethod
+    def forward(ctx, model, x, anchor):
+        reps, saved = model._forward_kernels(x, save=True)
+        ctx.model, ctx.saved = model, saved
+        ctx.x_requires_grad = x.requires_grad
+        return reps
+
+    @staticmethod
+    def backward(ctx, dreps):
+        ctx.model._backward_kernels(ctx.saved, dreps.contiguous())
+        ctx.saved = None
+        return None, None, None
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, img_size=[224], patch_size=16, in_chans=3, num_classes=0, embed_dim=384, depth=12,
+                 num_heads=6, mlp_ratio=4., qkv_bias=True, drop_path_rate=0., **kwargs):
+        super().__init__()
+        if (patch_size, in_chans, embed_dim, num_heads, int(embed_dim * mlp_ratio), img_size[0], num_classes) != \
+                (16, 3, D, HEADS, HID, 224, 0) or not qkv_bias:
+            raise NotImplementedError("the MI355X kernels implement the ViT-S/16 @224 geometry only")
+        self.num_features = self.embed_dim = embed_dim
+        self.depth = depth
+        self.drop_path_rate = drop_path_rate        # accepted for signature parity; identity (see module doc)
+        self.patch_embed = _PatchEmbed()
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
+        self.pos_embed = nn.Parameter(torch.zeros(1, NTOK, D))
+        self.blocks = nn.ModuleList([_Block() for _ in range(depth)])
+        self.norm = nn.LayerNorm(D, eps=1e-6)
+        self.head = nn.Identity()
+        _trunc_normal_(self.pos_embed)
+        _trunc_normal_(self.cls_token)
+        for m in self.modules():                     # _init_weights, vision_transformer.py:165-172
+            if isinstance(m, nn.Linear):
+                _trunc_normal_(m.weight)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+        self.flat = None
+        self._sig = None
+        self._anchor = None
+        self.grad_ready_hook = None                  # callable(lo, hi): flat-grad slice [lo,hi) is final
+        self._t_names = []
+        for i in range(depth):
+            p = f"blocks.{i}."
+            self._t_names += [p + "attn.qkv.weight", p + "attn.proj.weight", p + "mlp.fc1.weight", p + "mlp.fc2.weight"]
+        self._sentinels = ["cls_token", "patch_embed.proj.weight", "blocks.0.attn.qkv.weight", "norm.weight",
+                           f"blocks.{depth - 1}.mlp.fc2.weight"]
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine(self, device):
+        if self.flat is None or not self.flat.intact() or self.flat.device != device:
+            self.flat = FlatParams(self, device)
+            self._anchor = torch.zeros(1, device=device, requires_grad=True)
+            self._sig = None
+        sig = self.flat.signature(self._sentinels)
+        if sig != self._sig:
+            self.flat.refresh_shadows(self._t_names)
+            self._sig = self.flat.signature(self._sentinels)
+        return self.flat
+
+    def shadows_dirty(self):
+        self._sig = None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._sig = None
+        return r
+
+    def sgd_step(self, lr, grad_scale=1.0):
+        """Fused vanilla SGD over the whole flat buffer (prepare_model.py:566-567) + shadow refresh."""
+        self.flat.sgd_step(lr, grad_scale, self._t_names)
+        self._sig = self.flat.signature(self._sentinels)
+
+    def block_grad_range(self, i):
+        """[lo, hi) slice of the flat gradient buffer that belongs to block i."""
+        f = self.flat
+        lo = f.offsets[f"blocks.{i}.norm1.weight"]
+        hi = f.offsets[f"blocks.{i + 1}.norm1.weight"] if i + 1 < self.depth else f.offsets["norm.weight"]
+        return lo, hi
+
+    # ------------------------------------------------------------------ public API (reference signatures)
+    def forward(self, x):
+        x = self._check_input(x)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in (self.cls_token, self.norm.weight))
+        self._engine(x.device)
+        if need_grad:
+            return _ViTFn.apply(self, x, self._anchor)
+        return self._forward_kernels(x, save=False)[0]
+
+    def get_last_selfattention(self, x):
+        x = self._check_input(x)
+        self._engine(x.device)
+        return self._forward_kernels(x, save=False, want_last_attn=True)[0]
+
+    def _check_input(self, x):
+        if not x.is_cuda:
+            raise L.SaisHipError("VisionTransformer.forward needs a device tensor: the HIP path has no CPU fallback")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224):
+            raise ValueError(f"expected [F,3,224,224], got {tuple(x.shape)}")
+        return x.contiguous().float()
+
+    # ------------------------------------------------------------------ forward kernels
+    def _forward_kernels(self, img, save, want_last_attn=False):
+        f = self.flat
+        dev = img.device
+        Fr = img.shape[0]
+        M = Fr * NTOK
+        e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        patches = e16(Fr * 196, PATCH_K)
+        ops.patchify(img, patches)
+        x = e32(Fr, NTOK, D)
+        ops.gemm_nt(patches, f.w("patch_embed.proj.weight").view(D, PATCH_K), L.EPI_PATCH_F32, x,
+                    bias=f.w32("patch_embed.proj.bias"), aux=f.w32("pos_embed").view(NTOK, D), grp=(196, 197, 1))
+        ops.vit_cls_rows(f.w32("cls_token"), f.w32("pos_embed"), x, Fr)
+        x = x.view(M, D)
+        saved = {"patches": patches, "blocks": [], "Fr": Fr} if save else None
+        xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
+        for i in range(self.depth):
+            p = f"blocks.{i}."
+            last_attn = want_last_attn and i == self.depth - 1
+            if save:
+                xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
+            mean1 = e32(M) if save else None
+            rstd1 = e32(M) if save else None
+            ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
+                              rstd=rstd1)
+            ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
+            lse = e32(Fr, HEADS, NTOK) if save else None
+            probs = e32(Fr, HEADS, NTOK, NTOK) if last_attn else None
+            ops.vit_attn_fwd(qkv, Fr, ao, lse, probs)
+            if last_attn:
+                return probs, None
+            x_mid = e32(M, D) if save else x
+            ops.gemm_nt(ao, f.w(p + "attn.proj.weight"), L.EPI_BIAS_RESID_F32, x_mid, bias=f.w32(p + "attn.proj.bias"),
+                        aux=x)
+            xn2 = e16(M, D) if save else xn
+            mean2 = e32(M) if save else None
+            rstd2 = e32(M) if save else None
+            ops.layernorm_fwd(x_mid, M, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2,
+                              mean=mean2, rstd=rstd2)
+            u = e16(M, HID) if save else None
+            ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_BF16, h, bias=f.w32(p + "mlp.fc1.bias"), out2=u)
+            x_out = e32(M, D) if save else x
+            ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"),
+                        aux=x_mid)
+            if save:
+                saved["blocks"].append(dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=lse,
+                                            x_mid=x_mid, mean2=mean2, rstd2=rstd2, xn2=xn2, u=u, h=h))
+            x = x_out
+        reps = e32(Fr, D)
+        meanN = e32(Fr) if save else None
+        rstdN = e32(Fr) if save else None
+        ops.layernorm_fwd(x, Fr, NTOK * D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN,
+                          rstd=rstdN)
+        if save:
+            saved.update(x_final=x, meanN=meanN, rstdN=rstdN)
+        return reps, saved
+
+    # ------------------------------------------------------------------ backward kernels
+    def _backward_kernels(self, saved, dreps):
+        f = self.flat
+        f.attach_grads()
+        dev = dreps.device
+        Fr = saved["Fr"]
+        M = Fr * NTOK
+        e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
+        dx16 = e16(M, D)
+        ops.layernorm_bwd(saved["x_final"], NTOK * D, saved["meanN"], saved["rstdN"], f.w32("norm.weight"), Fr,
+                          dy32=dreps, dx32=dx, lddx32=NTOK * D, dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
+        ops.cast_bf16(dx, dx16)
+        du, dxn, dao, dqkv = e16(M, HID), e16(M, D), e16(M, D), e16(M, 3 * D)
+        delta = torch.empty(Fr, HEADS, NTOK, dtype=torch.float32, device=dev)
+        if self.grad_ready_hook:
+            self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
+        for i in reversed(range(self.depth)):
+            p = f"blocks.{i}."
+            s = saved["blocks"][i]
+            # MLP branch
+            ops.gemm_nt(dx16, f.wt16[p + "mlp.fc2.weight"], L.EPI_DGELU_BF16, du, aux=s["u"])
+            ops.gemm_tn(dx16, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias"))
+            ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
+            ops.gemm_tn(du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias"))
+            ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
+                              dx32=dx, dx16=dx16, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))
+            # attention branch
+            ops.gemm_nt(dx16, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
+            ops.gemm_tn(dx16, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias"))
+            ops.vit_attn_bwd(s["qkv"], dao, s["lse"], delta, Fr, dqkv)
+            ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn)
+            ops.gemm_tn(dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))
+            ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,
+                              dx32=dx, dx16=dx16, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
+            saved["blocks"][i] = None
+            if self.grad_ready_hook:
+                self.grad_ready_hook(*self.block_grad_range(i))
+        dpatch = e16(Fr * 196, D)
+        ops.vit_embed_bwd(dx, Fr, f.g("cls_token"), f.g("pos_embed"), dpatch)
+        ops.gemm_tn(dpatch, saved["patches"], f.g("patch_embed.proj.weight").view(D, PATCH_K),
+                    f.g("patch_embed.proj.bias"))
+        if self.grad_ready_hook:
+            self.grad_ready_hook(0, f.offsets["blocks.0.norm1.weight"])
+
+
+def vit_small(patch_size=16, **kwargs):
+    """vision_transformer.py:243-247."""
+    return VisionTransformer(patch_size=patch_size, embed_dim=384, depth=kwargs.pop("depth", 12), num_heads=6,
+                             mlp_ratio=4, qkv_bias=True, **kwargs)
