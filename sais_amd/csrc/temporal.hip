@@ -298,10 +298,18 @@ __global__ __launch_bounds__(256) void nce_kernel(const float* emb, const float*
     }
 }
 
+// raise the dynamic-LDS limit of a kernel once per process and device (not per call: keeps the launch
+// path free of runtime-API calls so it can be captured into a hipGraph); the limit only ever grows.
 template <typename K>
 int set_lds(K kernel, int bytes) {
-    return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess
-               ? SAIS_OK : SAIS_ERR_LAUNCH;
+    static thread_local int granted[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SAIS_ERR_LAUNCH;
+    if (bytes <= granted[dev]) return SAIS_OK;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return SAIS_ERR_LAUNCH;
+    granted[dev] = bytes;
+    return SAIS_OK;
 }
 }  // namespace
 

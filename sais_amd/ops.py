@@ -18,6 +18,43 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Optional live per-kernel timing with HIP events on the launch stream (used by bench.py for the
+    roofline object).  tag -> [(start, end, algorithmic flops, algorithmic bytes)]."""
+
+    def __init__(self):
+        self.recs = {}
+
+    def run(self, tag, flops, nbytes, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.recs.setdefault(tag, []).append((s, e, flops, nbytes))
+
+    def summary(self):
+        out = {}
+        for tag, lst in self.recs.items():
+            ms = [a.elapsed_time(b) for a, b, _, _ in lst]
+            out[tag] = dict(launches=len(lst), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
+                            flops=sum(f for _, _, f, _ in lst) / len(lst), bytes=sum(b for _, _, _, b in lst) / len(lst))
+        return out
+
+
+TIMER = None          # set to a KernelTimer to time the MFMA kernels
+
+
+def _timed(tag, flops, nbytes, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.run(tag, flops, nbytes, fn)
+
+
+_NT_NAMES = {0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_bf16", 5: "dgelu_bf16", 6: "drelu_bf16",
+             7: "patch_f32", 8: "relu_f32", 9: "drelu_f32"}
+
+
 def _chk(t, dtype, name):
     if t is None:
         return
@@ -37,7 +74,9 @@ def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0,
     g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
                    _p(out), out.stride(-2), _p(out2), 0 if out2 is None else out2.stride(-2),
                    _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2])
-    L.call("sais_gemm_nt", ctypes.byref(g), _stream())
+    nbytes = 2 * (M * K + N * K) + out.element_size() * M * N
+    _timed(f"gemm_nt<{_NT_NAMES[epilogue]}>", 2.0 * M * N * K, nbytes,
+           lambda: L.call("sais_gemm_nt", ctypes.byref(g), _stream()))
     return out
 
 
@@ -48,7 +87,8 @@ def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None):
     N, K = w.shape
     g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
                    _p(out), out.stride(-2), None, 0, _p(aux), 0 if aux is None else aux.stride(-2), 0, 0, 0)
-    L.call("sais_gemm_nt_f32", ctypes.byref(g), _stream())
+    _timed(f"gemm_nt_f32x3<{_NT_NAMES[epilogue]}>", 2.0 * M * N * K, 4 * (M * K + N * K + M * N),
+           lambda: L.call("sais_gemm_nt_f32", ctypes.byref(g), _stream()))
     return out
 
 
@@ -61,8 +101,9 @@ def gemm_tn(p, q, dW, db=None, nsplit=None):
     if nsplit is None:
         tiles = (N1 // 128) * (N2 // 128)
         nsplit = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles))
-    L.call("sais_gemm_tn_f32" if f32 else "sais_gemm_tn", _p(p), p.stride(0), _p(q), q.stride(0), M, N1, N2, _p(dW),
-           dW.stride(0), _p(db), nsplit, _stream())
+    _timed("gemm_tn_f32" if f32 else "gemm_tn", 2.0 * M * N1 * N2, p.element_size() * M * (N1 + N2) + 4 * N1 * N2,
+           lambda: L.call("sais_gemm_tn_f32" if f32 else "sais_gemm_tn", _p(p), p.stride(0), _p(q), q.stride(0), M, N1,
+                          N2, _p(dW), dW.stride(0), _p(db), nsplit, _stream()))
 
 
 def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None, rstd=None, ldy16=384, ldy32=384):
@@ -80,12 +121,15 @@ def layernorm_bwd(x, ldx, mean, rstd, gamma, rows, dy16=None, dy32=None, dres=No
 
 def vit_attn_fwd(qkv, frames, out, lse=None, probs=None):
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out")
-    L.call("sais_vit_attn_fwd", _p(qkv), qkv.stride(0), frames, _p(out), out.stride(0), _p(lse), _p(probs), _stream())
+    _timed("vit_attn_fwd", 4.0 * frames * 6 * 197 * 197 * 64, 2 * frames * 197 * 384 * 4,
+           lambda: L.call("sais_vit_attn_fwd", _p(qkv), qkv.stride(0), frames, _p(out), out.stride(0), _p(lse),
+                          _p(probs), _stream()))
 
 
 def vit_attn_bwd(qkv, dout, lse, delta_ws, frames, dqkv):
-    L.call("sais_vit_attn_bwd", _p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(lse), _p(delta_ws), frames,
-           _p(dqkv), dqkv.stride(0), _stream())
+    _timed("vit_attn_bwd", 10.0 * frames * 6 * 197 * 197 * 64, 2 * frames * 197 * 384 * 8,
+           lambda: L.call("sais_vit_attn_bwd", _p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(lse), _p(delta_ws),
+                          frames, _p(dqkv), dqkv.stride(0), _stream()))
 
 
 def patchify(frames_f32, patches):

@@ -24,9 +24,6 @@ class SGD(torch.optim.Optimizer):
         owned = self._owned()
         for group in self.param_groups:
             lr = group["lr"]
-            for e in self.engines:
-                if e.flat is not None and any(id(p) in owned for p in group["params"]):
-                    pass
             for p in group["params"]:
                 if id(p) in owned or p.grad is None:
                     continue

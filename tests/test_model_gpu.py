@@ -234,41 +234,68 @@ def test_e2e_config1_vs_golden(gpu, golden):
 
 
 def test_e2e_train_step_grads_vs_golden(gpu, golden):
+    """Whole fwd+bwd graph: frames -> ViT -> temporal encoder -> prototype loss.
+    Logits / loss / near-loss gradients are checked against the reference's golden vectors.  Gradients
+    deep in the chain are ILL-CONDITIONED with respect to the features (measured with the oracle: a 1 %
+    perturbation of the ViT features moves d frame_cls by 16 % through the ReLU gates), so the chain rule
+    is checked stage by stage with the CPU oracle evaluated at the SAME intermediate tensors:
+      temporal grads  vs  oracle temporal backward at the GPU's own ViT features,
+      ViT grads       vs  oracle ViT backward driven by the GPU's own d loss / d features."""
+    from oracle import sais_oracle as O
     from sais_amd.loss import calcNCELoss, cosine_logits_and_probs
     g = golden("e2e")
     vit = make_vit().train()
     m = make_full(2, "RGB-Flow").train()
     B, T = 2, 4
-    clips = synth.clips(seed=900 + T, B=B, T=T).to(DEV)
-    fclips = synth.clips(seed=950 + T, B=B, T=T).to(DEV)
-    pad = synth.padding_mask([T] * B).to(DEV)
+    clips = synth.clips(seed=900 + T, B=B, T=T)
+    fclips = synth.clips(seed=950 + T, B=B, T=T)
+    frames = torch.cat([clips, fclips]).view(2 * B * T, 3, 224, 224)
+    pad = synth.padding_mask([T] * B)
     protos = protos_dev(2)
-    reps = vit(torch.cat([clips, fclips]).view(2 * B * T, 3, 224, 224)).view(2, B, 1, T, 384)
-    emb, attn = m(reps[0], reps[1], [T] * B, [T] * B, 'Prototypes', pad, pad, None)
-    loss = calcNCELoss(0, emb, synth.labels(seed=800 + T, B=B), ["a", "b"], protos, None)
+    lab = synth.labels(seed=800 + T, B=B)
+    reps = vit(frames.to(DEV))
+    reps.retain_grad()
+    r5 = reps.view(2, B, 1, T, 384)
+    emb, attn = m(r5[0], r5[1], [T] * B, [T] * B, 'Prototypes', pad.to(DEV), pad.to(DEV), None)
+    loss = calcNCELoss(0, emb, lab, ["a", "b"], protos, None)
     loss.backward()
     sim, _ = cosine_logits_and_probs(emb, protos)
-    assert maxabs(sim, g["train/sim"]) <= LOGIT_TOL
+    assert maxabs(sim, g["train/sim"]) <= LOGIT_TOL, maxabs(sim, g["train/sim"])
     assert abs(loss.item() - float(g["train/loss"])) <= LOGIT_TOL
     V, P = dict(vit.named_parameters()), dict(m.named_parameters())
+    for k in protos.keys():                                   # near-loss gradients: well conditioned
+        assert rel_l2(protos[k].grad, g[f"train/grad_proto{k}"]) <= GRAD_REL
+    assert rel_l2(P["linear.bias"].grad, g["train/tgrad/linear.bias"]) <= GRAD_REL
+
+    # stage 1: temporal backward at the GPU's own features
+    reps_cpu = reps.detach().cpu().view(2, B, 1, T, 384)
+    tsd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(2, 2).items()}
+    rx, rf = reps_cpu[0].clone().requires_grad_(True), reps_cpu[1].clone().requires_grad_(True)
+    e_ref, _ = O.temporal_forward(tsd, rx, rf, pad, pad, "RGB-Flow")
+    O.nce_loss(e_ref, lab, pr).backward()
     bad = {}
-    for k in g.files:
-        if k.startswith("train/vgrad/"):
-            r = rel_l2(V[k[12:]].grad, g[k])
-        elif k.startswith("train/vgrad8/"):
-            r = rel_l2(V[k[13:]].grad[:8], g[k])
-        elif k.startswith("train/tgrad/"):
-            r = rel_l2(P[k[12:]].grad, g[k])
-        elif k.startswith("train/grad_proto"):
-            r = rel_l2(protos[k[16:]].grad, g[k])
-        else:
-            continue
-        if r > 6e-2:                      # 12 ViT blocks + 4 temporal layers of bf16 operands
-            bad[k] = r
+    for n in ("linear.weight", "frame_cls", "frame_pos_embeddings.0", "frame_pos_embeddings.3",
+              "transEncoderFrame.layers.0.self_attn.in_proj_weight", "transEncoderFrame.layers.3.norm2.bias",
+              "transEncoderFrame.layers.1.linear1.weight", "transEncoderFrame.layers.2.linear2.bias"):
+        r = rel_l2(P[n].grad, tsd[n].grad.numpy())
+        if r > GRAD_REL:
+            bad[n] = r
+    dreps_ref = torch.cat([rx.grad, rf.grad]).reshape(2 * B * T, 384)
+    r = rel_l2(reps.grad, dreps_ref.numpy())
+    if r > GRAD_REL:
+        bad["d loss / d reps"] = r
     assert not bad, bad
+
+    # stage 2: ViT backward driven by the GPU's own upstream gradient
+    vsd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0).items()}
+    (O.vit_forward(vsd, frames) * reps.grad.detach().cpu()).sum().backward()
+    bad = {}
     for n, q in V.items():
-        nrm = float(g["train/vgnorm/" + n])
-        assert abs(q.grad.norm().item() - nrm) <= 6e-2 * nrm + 1e-7, (n, q.grad.norm().item(), nrm)
+        r = rel_l2(q.grad, vsd[n].grad.numpy())
+        if r > 6e-2:                      # 12 blocks of bf16 operands
+            bad[n] = r
+    assert not bad, bad
 
 
 def test_sgd_step_matches_oracle_update(gpu):
