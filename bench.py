@@ -125,9 +125,13 @@ def cpu_baseline(T, C, threads):
                     if p.grad is not None:
                         p -= 0.1 * p.grad
                         p.grad = None
-    step()
+    t0 = time.time()
+    step()                                                   # warm-up (also sizes the sample)
+    warm = time.time() - t0
+    budget = 20.0                                            # seconds of timed CPU work
+    nmax = max(1, min(10, int(budget / max(warm, 1e-3))))
     n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < 10 and n < 20):
+    while n < nmax:
         step()
         n += 1
     dt = (time.time() - t0) / n
@@ -238,11 +242,17 @@ def main():
                        "parallelism": f"dp{world}"},
             "step_tflops": round(step_flops * world * args.steps / dt / 1e12, 1),
             "frac_of_mfma_roofline": round(step_flops * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "loss": round(float(loss), 6),
+            "loss": round(float(loss.detach()), 6),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(T, C, os.cpu_count() or 1)
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            # fp32 ViT-S on one 32-frame clip stops scaling past a few dozen threads (and oversubscribed
+            # hosts get much slower), so use at most 32 of the host's cores; `cores` reports what was used
+            out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
