@@ -46,46 +46,10 @@ def build(dev, B, T, C, lr):
     return vit, model, protos, opt
 
 
-class GradSync:
-    """Data-parallel gradient exchange: RCCL all-reduce of contiguous slices of the flat gradient buffers,
-    launched from the backward pass as soon as a slice is final (ProcessGroupNCCL runs it on its own stream
-    after the work already queued on the compute stream), waited for right before the SGD step."""
-
-    def __init__(self, world):
-        self.world = world
-        self.pending = []
-
-    def hook(self, flat):
-        def fn(lo, hi):
-            if self.world > 1 and hi > lo:
-                self.pending.append(dist.all_reduce(flat.grad[lo:hi], async_op=True))
-        return fn
-
-    def temporal_hook(self, model, T):
-        def fn(lo, hi):
-            if self.world <= 1:
-                return
-            f = model.flat
-            rngs = [(f.offsets["frame_cls"], f.offsets["frame_cls"] + 384),
-                    (f.offsets["linear.weight"], f.offsets["linear.bias"] + 256),
-                    (f.offsets["frame_pos_embeddings.0"], f.offsets["frame_pos_embeddings.0"] + T * 384),
-                    (f.offsets["transEncoderFrame.layers.0.self_attn.in_proj_weight"],
-                     f.offsets["transEncoderClip.layers.0.self_attn.in_proj_weight"])]
-            for a, b in rngs:
-                self.pending.append(dist.all_reduce(f.grad[a:b], async_op=True))
-        return fn
-
-    def wait(self):
-        for w in self.pending:
-            w.wait()
-        self.pending = []
-
-
 def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world):
     from sais_amd.loss import calcNCELoss
     names = [f"v_{i}" for i in range(B)]
     lens = [T] * B
-    pgrads = None
 
     def step():
         opt.zero_grad()
@@ -94,8 +58,7 @@ def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world):
         loss = calcNCELoss(0, emb, labels, names, protos, None)
         loss.backward()
         if world > 1:
-            for p in protos.values():
-                sync.pending.append(dist.all_reduce(p.grad, async_op=True))
+            sync.reduce_params(protos.values())
             sync.wait()
         opt.step(grad_scale=1.0 / world)
         return loss
@@ -180,11 +143,12 @@ def main():
     frames = synth.clips(seed=rank, B=B, T=T).view(B * T, 3, 224, 224).to(dev)     # resident in HBM
     pad = synth.padding_mask([T] * B).to(dev)
     labels = synth.labels(seed=rank, B=B, nclasses=C)
+    from sais_amd.parallel import GradSync
     sync = GradSync(world)
     step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world)
     vit(frames[:2])                                          # builds the flat buffers
     model._engine(dev)
-    vit.grad_ready_hook = sync.hook(vit.flat)
+    vit.grad_ready_hook = sync.vit_hook(vit)
     model.grad_ready_hook = sync.temporal_hook(model, T)
 
     for _ in range(args.warmup):

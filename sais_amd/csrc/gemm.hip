@@ -114,42 +114,49 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16]) {
     }
 }
 
+// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the
+// 8 XCDs, so hand each XCD a CONTIGUOUS run of logical tiles; tiles are numbered n-fastest, hence the
+// workgroups that share an A row-panel (and walk the small weight matrix) hit the same private L2.
+DEVINL int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): one wave-instruction fills
+// 1 KiB = 8 LDS rows of 128 B linearly, so the XOR swizzle (and the weight-row permutation) is applied to the
+// per-lane SOURCE address: LDS slot (row r, position c') receives global chunk c' ^ (r & 7).
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int ntn = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
 
-    // staging map: 4 x (row = tid>>3 + 32 i, 16-B chunk = tid&7)
-    const int sc = tid & 7, sr = tid >> 3;
-    const bf16* ag[4]; const bf16* bg[4];
-    int a_lds[4], b_lds[4];
-    bool a_ok[4];
+    // wave w issues pieces 4w..4w+3 of each operand tile; piece q = LDS rows 8q..8q+7
+    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
+    const bf16* asrc[4]; const bf16* bsrc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = sr + 32 * i;
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (4 * wid + j) + sub;
         int m = m0 + r;
-        a_ok[i] = m < p.M;
-        ag[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda + sc * 8;
-        bg[i] = p.B + (size_t)(n0 + r) * p.ldb + sc * 8;
-        a_lds[i] = swz(r, sc);
-        b_lds[i] = TILE_BYTES + swz(perm_row(r), sc);
+        m = m < p.M ? m : p.M - 1;                                   // clamp: rows >= M are never stored
+        asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
+        bsrc[j] = p.B + (size_t)(n0 + perm_row(r)) * p.ldb + schunk * 8;
     }
-    u32x4 ra[4], rb[4];
-    auto gload = [&](int k0) {
+    auto issue = [&](int stage, int k0) {
+        char* s = smem + stage * 2 * TILE_BYTES + (4 * wid) * 1024;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = a_ok[i] ? *(const u32x4*)(ag[i] + k0) : u32x4{0, 0, 0, 0};
-            rb[i] = *(const u32x4*)(bg[i] + k0);
-        }
-    };
-    auto lstore = [&](int stage) {
-        char* s = smem + stage * 2 * TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(s + a_lds[i]) = ra[i];
-            *(u32x4*)(s + b_lds[i]) = rb[i];
+        for (int j = 0; j < 4; ++j) {
+            glds16(asrc[j] + k0, s + j * 1024);
+            glds16(bsrc[j] + k0, s + TILE_BYTES + j * 1024);
         }
     };
 
@@ -160,12 +167,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
     const int nk = p.K / BK;
-    gload(0);
-    lstore(0);
+    issue(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK);
         const char* sa = smem + cur * 2 * TILE_BYTES;
         const char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -181,8 +187,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
+        __syncthreads();                      // drains this wave's LDS-DMA (vmcnt(0)) and fences the buffer swap
     }
 
     // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*64 + 16 g + (4 nt + r)
@@ -454,7 +459,7 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     if (g->M <= 0 || g->N % BN || g->K % BK || g->lda % 8 || g->ldb % 8 || g->ldo % 8) return SAIS_ERR_ARG;
     NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
                g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off};
-    dim3 grid(g->N / BN, (g->M + BM - 1) / BM);
+    dim3 grid((g->N / BN) * ((g->M + BM - 1) / BM));
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)

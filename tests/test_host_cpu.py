@@ -1,0 +1,159 @@
+"""CPU-only host logic: state_dict contracts, checkpoint codec, flat parameter storage, the 2-rank
+gradient exchange (gloo), and the loud failure without a device."""
+import os
+
+import pytest
+import torch
+import torch.nn as nn
+
+import synth
+
+
+def test_state_dict_contracts_match_reference_key_lists():
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    v = vit_small(patch_size=16, drop_path_rate=0.1)
+    assert list(v.state_dict().keys()) == [k for k, _, _ in synth.vit_keys()]
+    assert sum(p.numel() for p in v.parameters()) == 21665664                 # SURVEY §8c probe
+    m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB-Flow')
+    want = {k: s for k, s, _ in synth.temporal_keys()}
+    got = {k: tuple(t.shape) for k, t in m.state_dict().items()}
+    assert got == want and len(got) == 4118
+    assert sum(p.numel() for p in m.parameters()) == 19180681                 # SURVEY App. A probe
+    keys = list(m.state_dict().keys())
+    i0 = keys.index("frame_pos_embeddings.0")
+    assert keys[i0:i0 + 12] == [f"frame_pos_embeddings.{i}" for i in range(12)]   # insertion order, not sorted
+
+
+def test_out_of_scope_branches_raise():
+    from sais_amd.temporal import fullModel
+    with pytest.raises(NotImplementedError):
+        fullModel('raw', 2, 'd', 512, 'R3D')
+    with pytest.raises(NotImplementedError):
+        fullModel('reps', 2, 'd', 384, 'ViT', importance_loss=True)
+    m = fullModel('reps', 2, 'd', 384, 'ViT')
+    with pytest.raises(NotImplementedError):
+        m(None, None, None, None, 'MIL', None, None, None)
+
+
+def test_no_cpu_fallback():
+    from sais_amd._lib import SaisHipError
+    from sais_amd.loss import calcNCELoss
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    with pytest.raises(SaisHipError):
+        vit_small()(torch.zeros(1, 3, 224, 224))
+    m = fullModel('reps', 2, 'd', 384, 'ViT', modalities='RGB')
+    with pytest.raises(SaisHipError):
+        m(torch.zeros(1, 1, 4, 384), None, [4], None, 'Prototypes', None, None, None)
+    with pytest.raises(SaisHipError):
+        calcNCELoss(0, torch.zeros(2, 256), torch.tensor([0, 1]), ["a", "b"], synth.prototypes(2, 2), None)
+
+
+def test_checkpoint_codec_roundtrip(tmp_path):
+    from sais_amd import model_io
+    from sais_amd.temporal import fullModel
+    m = fullModel('reps', 3, 'in_vs_out', 384, 'ViT')
+    m.load_state_dict(synth.temporal_state_dict(seed=7))
+    protos = nn.ParameterDict({k: nn.Parameter(v) for k, v in synth.prototypes(3, 3).items()})
+    model_io.save_params_file(m, tmp_path / "params.zip")
+    model_io.save_prototypes_file(protos, tmp_path / "prototypes.zip")
+    raw = torch.load(tmp_path / "params.zip", weights_only=False)
+    assert all(k.startswith("module.") for k in raw) and len(raw) == 4118
+    raw["module.encoder.cls_token"] = torch.zeros(1, 1, 768)                   # timm ballast must be ignored
+    torch.save(raw, tmp_path / "params.zip")
+    md, opt, dev = model_io.loadModel(0, 1, str(tmp_path), 'reps', 3, 'in_vs_out', 384, 'ViT', 'Prototypes', 0,
+                                      lr=0.1, modalities='RGB-Flow', inference=True, device='cpu')
+    sd = md['model'].state_dict()
+    for k, v in synth.temporal_state_dict(seed=7).items():
+        assert torch.equal(sd[k], v), k
+    assert list(md['prototypes'].keys()) == ['0', '1', '2']
+    assert torch.equal(md['prototypes']['2'].detach(), synth.prototypes(3, 3)['2'])
+    # a key without the DDP prefix fails like the reference's split('module.')[1]
+    torch.save({"frame_cls": torch.zeros(1, 384)}, tmp_path / "params.zip")
+    with pytest.raises(IndexError):
+        model_io.load_params_file(tmp_path / "params.zip")
+    # strict: a missing key raises
+    bad = {"module." + k: v for k, v in synth.temporal_state_dict(seed=7).items() if k != "linear.bias"}
+    torch.save(bad, tmp_path / "params.zip")
+    with pytest.raises(RuntimeError):
+        model_io.loadModel(0, 1, str(tmp_path), 'reps', 3, 'in_vs_out', 384, 'ViT', 'Prototypes', 0,
+                           inference=True, device='cpu')
+
+
+def test_flat_params_views_and_grad_attach():
+    from sais_amd.flat import FlatParams
+    from sais_amd.vit import vit_small
+    v = vit_small(depth=2)
+    ref = {k: t.clone() for k, t in v.state_dict().items()}
+    f = FlatParams(v, 'cpu')
+    assert f.intact() and f.numel % 4 == 0
+    for k, t in v.state_dict().items():
+        assert torch.equal(t, ref[k])
+    f.flat.mul_(2.0)                                   # parameters are views of the flat buffer
+    assert torch.equal(v.blocks[1].mlp.fc2.weight.detach(), 2 * ref["blocks.1.mlp.fc2.weight"])
+    f.g("norm.bias").fill_(3.0)                        # p.grad are views of the flat gradient buffer
+    assert float(v.norm.bias.grad.sum()) == 3.0 * 384
+    for p in v.parameters():
+        p.grad = None                                  # optimizer.zero_grad(set_to_none=True)
+    assert f.attach_grads() is True and float(f.grad.abs().sum()) == 0.0
+    assert v.norm.bias.grad.data_ptr() == f.g("norm.bias").data_ptr()
+    lo, hi = 0, 0
+    v.flat = f
+    spans = [v.block_grad_range(i) for i in range(2)]
+    assert spans[0][1] == spans[1][0] and spans[1][1] == f.offsets["norm.weight"]
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sais_amd.flat import FlatParams
+    from sais_amd.parallel import GradSync
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    torch.manual_seed(0)
+    vit, m = vit_small(depth=2), fullModel('reps', 2, 'd', 384, 'ViT', modalities='RGB')
+    vit.flat, m.flat = FlatParams(vit, 'cpu'), FlatParams(m, 'cpu')
+    T = 5
+    sync = GradSync(world)
+    g = torch.Generator().manual_seed(100 + rank)
+    vit.flat.grad.copy_(torch.randn(vit.flat.numel, generator=g))
+    m.flat.grad.copy_(torch.randn(m.flat.numel, generator=g))
+    local_v, local_m = vit.flat.grad.clone(), m.flat.grad.clone()
+    # backward order: temporal first, then final norm, blocks last..first, embedding
+    sync.temporal_hook(m, T)(0, m.flat.numel)
+    hook = sync.vit_hook(vit)
+    hook(vit.flat.offsets["norm.weight"], vit.flat.numel)
+    for i in reversed(range(2)):
+        hook(*vit.block_grad_range(i))
+    hook(0, vit.flat.offsets["blocks.0.norm1.weight"])
+    sync.wait()
+    others_v = [torch.zeros_like(local_v) for _ in range(world)]
+    others_m = [torch.zeros_like(local_m) for _ in range(world)]
+    dist.all_gather(others_v, local_v)
+    dist.all_gather(others_m, local_m)
+    ok_v = torch.allclose(vit.flat.grad, sum(others_v), atol=1e-6)
+    touched = torch.zeros(m.flat.numel, dtype=torch.bool)
+    for a, b in GradSync.temporal_ranges(m, T):
+        touched[a:b] = True
+    ok_m = torch.allclose(m.flat.grad[touched], sum(others_m)[touched], atol=1e-6) and \
+        torch.equal(m.flat.grad[~touched], local_m[~touched])
+    # every parameter the Prototypes path touches lies inside the exchanged ranges
+    names_touched = ["frame_cls", "linear.weight", "linear.bias", "frame_pos_embeddings.4",
+                     "transEncoderFrame.layers.3.norm2.bias", "transEncoderFrame.layers.0.self_attn.in_proj_weight"]
+    cover = all(touched[m.flat.offsets[n]] for n in names_touched) and not touched[m.flat.offsets["frame_pos_embeddings.5"]] \
+        and not touched[m.flat.offsets["transEncoderClip.layers.0.linear1.weight"]]
+    if rank == 0:
+        open(out, "w").write(f"{ok_v} {ok_m} {cover} {sync.bytes}")
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.txt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    ok_v, ok_m, cover, nbytes = open(out).read().split()
+    assert (ok_v, ok_m, cover) == ("True", "True", "True")
+    assert int(nbytes) > 4 * 3_000_000
