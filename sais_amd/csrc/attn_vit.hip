@@ -43,6 +43,15 @@ DEVINL bf16x8 tr_frag(const char* lds, int s, int ct, int g, int li) {
     return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * ROWB));
 }
 
+// raw v_exp_f32 (exp2f() adds a denormal-range fix-up of 4 VALU per element; arguments here are <= ~0 and a
+// flush to zero of results below 2^-126 is exactly what softmax wants)
+DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// 13 sixteen-row tiles over 4 waves: wave w takes tiles w, w+4, w+8; the 13th (5 real rows) rotates over the
+// waves with the (frame, head) index so no SIMD is systematically the last to finish
+DEVINL int tiles_of_wave(int wid, int extra) { return 3 + (wid == extra ? 1 : 0); }
+DEVINL int tile_id(int wid, int i) { return i < 3 ? wid + 4 * i : NKT - 1; }
+
 DEVINL float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
 DEVINL float group_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
 
@@ -86,23 +95,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
     stage_matrix(sV, base + 2 * DM, ldq, tid);
     __syncthreads();
     const float c = scale * LOG2E;
-    for (int qt = wid; qt < NKT; qt += 4) {
+    const int nmine = tiles_of_wave(wid, (f * NH + h) & 3);
+    bf16x8 fq[2], fq_next[2];
+    load_q_frags(base, ldq, tile_id(wid, 0) * 16 + li, g, fq);
+    for (int it = 0; it < nmine; ++it) {
+        const int qt = tile_id(wid, it);
         const int q = qt * 16 + li;
-        bf16x8 fq[2];
-        load_q_frags(base, ldq, q, g, fq);
+        if (it + 1 < nmine) load_q_frags(base, ldq, tile_id(wid, it + 1) * 16 + li, g, fq_next);   // prefetch
         f32x4 s[NKT];
         score_strip(sK, fq, g, li, s);
+        fq[0] = fq_next[0]; fq[1] = fq_next[1];
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) m = fmaxf(m, s[t][r]);
         m = group_max(m);
+        const float mc = -m * c;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { float e = exp2f((s[t][r] - m) * c); s[t][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { float e = fast_exp2(__builtin_fmaf(s[t][r], c, mc)); s[t][r] = e; sum += e; }
         sum = group_sum(sum);
         const float inv = 1.0f / sum;
         f32x4 o[4];
@@ -156,12 +170,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* qkv, long 
     stage_matrix(sV, base + 2 * DM, ldq, tid);
     __syncthreads();
     const float c = scale * LOG2E;
-    for (int qt = wid; qt < NKT; qt += 4) {
+    const int nmine = tiles_of_wave(wid, (f * NH + h) & 3);
+    bf16x8 fq[2], fdo[2], fq_next[2], fdo_next[2];
+    load_q_frags(base, ldq, tile_id(wid, 0) * 16 + li, g, fq);
+    load_q_frags(dob, ldo, tile_id(wid, 0) * 16 + li, g, fdo);
+    for (int it = 0; it < nmine; ++it) {
+        const int qt = tile_id(wid, it);
         const int q = qt * 16 + li, qc = q < NTOK ? q : NTOK - 1;
-        bf16x8 fq[2], fdo[2];
-        load_q_frags(base, ldq, q, g, fq);
-        load_q_frags(dob, ldo, q, g, fdo);
-        const float l2 = lse[((size_t)f * NH + h) * NTOK + qc] * LOG2E;
+        if (it + 1 < nmine) {                                                   // prefetch the next tile's rows
+            load_q_frags(base, ldq, tile_id(wid, it + 1) * 16 + li, g, fq_next);
+            load_q_frags(dob, ldo, tile_id(wid, it + 1) * 16 + li, g, fdo_next);
+        }
+        const float nl2 = -lse[((size_t)f * NH + h) * NTOK + qc] * LOG2E;
         f32x4 s[NKT];
         score_strip(sK, fq, g, li, s);
         float dl = 0.f;
@@ -173,13 +193,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* qkv, long 
             for (int ks = 0; ks < 2; ++ks) a = mfma16(row_frag(sV, 16 * t + li, 4 * ks + g), fdo[ks], a);
             dp[t] = a;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { float p = exp2f(s[t][r] * c - l2); s[t][r] = p; dl += p * a[r]; }
+            for (int r = 0; r < 4; ++r) { float p = fast_exp2(__builtin_fmaf(s[t][r], c, nl2)); s[t][r] = p; dl = __builtin_fmaf(p, a[r], dl); }
         }
+        fq[0] = fq_next[0]; fq[1] = fq_next[1]; fdo[0] = fdo_next[0]; fdo[1] = fdo_next[1];
         dl = group_sum(dl);
+        // dS^T = P (dP - delta); the 1/sqrt(d) factor is applied to the 16 dQ outputs instead of the 52 scores
 #pragma unroll
         for (int t = 0; t < NKT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dl) * scale;
+            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dl);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* qkv, long 
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (bf16)o[dt][r];
+                for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[dt][r] * scale);
                 *(bf16x4*)(orow + 16 * dt) = v;
             }
             if (g == 0) delta[((size_t)f * NH + h) * NTOK + q] = dl;
@@ -254,9 +276,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* qkv, long
                 f32x4 d4 = *(const f32x4*)(sD + qrow + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pv = exp2f(a[r] * c - l4[r]);
+                    float pv = fast_exp2(__builtin_fmaf(a[r], c, -l4[r]));
                     p[u][r] = pv;
-                    ds[u][r] = pv * (b[r] - d4[r]) * scale;
+                    ds[u][r] = pv * (b[r] - d4[r]);                 // x scale at the dK store
                 }
             }
             bf16x8 pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);
@@ -272,7 +294,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* qkv, long
             for (int dt = 0; dt < 4; ++dt) {
                 bf16x4 a, b;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { a[r] = (bf16)dk[dt][r]; b[r] = (bf16)dv[dt][r]; }
+                for (int r = 0; r < 4; ++r) { a[r] = (bf16)(dk[dt][r] * scale); b[r] = (bf16)dv[dt][r]; }
                 *(bf16x4*)(krow + 16 * dt) = a;
                 *(bf16x4*)(krow + DM + 16 * dt) = b;
             }

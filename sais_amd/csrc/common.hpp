@@ -54,9 +54,28 @@ DEVINL float wave_max(float v) {
     return v;
 }
 
-DEVINL float gelu_erf(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU(), vision_transformer.py:49-65) without libm's erff: Abramowitz-Stegun 7.1.26,
+//   erf(x) = 1 - (a1 t + ... + a5 t^5) exp(-x^2),  t = 1/(1 + p x),  |error| <= 1.5e-7  (x >= 0, odd extension)
+// = 1 rcp + 1 exp + ~10 FMA per element, and exp(-x^2) = exp(-u^2/2) is shared with the Gaussian pdf of GELU'.
+DEVINL void erf_parts(float u, float& erf_abs, float& e) {      // erf(|u|/sqrt2), exp(-u^2/2)
+    const float x = fabsf(u) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    e = __expf(-x * x);
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    erf_abs = fmaf(-pl * t, e, 1.0f);
+}
+DEVINL float gelu_erf(float u) {
+    float ea, e;
+    erf_parts(u, ea, e);
+    return 0.5f * u * (1.0f + copysignf(ea, u));
+}
 DEVINL float dgelu_erf(float u) {
-    return 0.5f * (1.0f + erff(u * 0.70710678118654752f)) + u * 0.3989422804014327f * __expf(-0.5f * u * u);
+    float ea, e;
+    erf_parts(u, ea, e);
+    return fmaf(u * 0.3989422804014327f, e, 0.5f * (1.0f + copysignf(ea, u)));
 }
 
 // hipGetLastError is sticky across the whole process (torch included): clear it on entry so that

@@ -358,8 +358,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TTILE];   // 72 KiB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
-    const int n2_0 = blockIdx.x * 128, n1_0 = blockIdx.y * 128;
-    const int mbeg = blockIdx.z * p.rows_per_split;
+    // 1-D grid, XCD-aware order with the M-split as the slow index: the (N1/128)*(N2/128) tiles of one split
+    // run on ONE XCD back to back and share that split's P and Q row slabs through its L2 (the slabs are then
+    // fetched from HBM once instead of once per tile).
+    const int nt2 = p.N2 / 128, ntile = (p.N1 / 128) * nt2;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / ntile, t12 = wg - split * ntile;
+    const int n2_0 = (t12 % nt2) * 128, n1_0 = (t12 / nt2) * 128;
+    const int mbeg = split * p.rows_per_split;
     const int mend = min(p.M, mbeg + p.rows_per_split);
     if (mbeg >= mend) return;
 
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
     }
-    const bool do_bias = p.db != nullptr && blockIdx.x == 0 && wc == 0;
+    const bool do_bias = p.db != nullptr && n2_0 == 0 && wc == 0;
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
@@ -503,7 +509,7 @@ static int launch_tn(const void* P, int ldp, const void* Q, int ldq, int M, int 
     rows = (rows + TK - 1) / TK * TK;
     int ns = (M + rows - 1) / rows;
     TnParams p{P, Q, ldp, ldq, M, N1, N2, dW, ldw, db, rows};
-    dim3 grid(N2 / 128, N1 / 128, ns);
+    dim3 grid((N2 / 128) * (N1 / 128) * ns);
     if (f32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
     return sais_check_launch();

@@ -100,7 +100,9 @@ def gemm_tn(p, q, dW, db=None, nsplit=None):
     N2 = q.shape[1]
     if nsplit is None:
         tiles = (N1 // 128) * (N2 // 128)
-        nsplit = max(1, min((M + 255) // 256, (768 + tiles - 1) // tiles))
+        # measured sweep on MI355X (tools/gemm_bench.py): ~430 workgroups is the sweet spot between chip
+        # fill (2 workgroups/CU) and fp32-atomic traffic (64 KiB per workgroup)
+        nsplit = max(1, min((M + 255) // 256, (432 + tiles - 1) // tiles))
     _timed("gemm_tn_f32" if f32 else "gemm_tn", 2.0 * M * N1 * N2, p.element_size() * M * (N1 + N2) + 4 * N1 * N2,
            lambda: L.call("sais_gemm_tn_f32" if f32 else "sais_gemm_tn", _p(p), p.stride(0), _p(q), q.stride(0), M, N1,
                           N2, _p(dW), dW.stride(0), _p(db), nsplit, _stream()))
