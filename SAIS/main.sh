@@ -1,0 +1,27 @@
+#!/bin/bash
+# Same surface as the reference's SAIS/main.sh (:1-30): run from the repo root  ->  bash ./SAIS/main.sh -f <videoname>
+# Stages that are out of this build's scope are skipped with a note (ffmpeg frame dump, RAFT optical flow:
+# SURVEY.md §2); the two stages on the hot path run on the MI355X kernels.
+while getopts f:s: flag
+do
+    case "${flag}" in
+        f) videoname=${OPTARG};;
+        s) synthetic=${OPTARG};;     # extension: -s N = use N synthetic frames instead of ./SAIS/images/<video>/
+    esac
+done
+SYN=""
+if [ -n "$synthetic" ]; then SYN="--synthetic_frames $synthetic"; fi
+
+# (video_to_frames.sh / generate_paths.py / --optical_flow: not part of this build — frames are read straight from
+#  ./SAIS/images/<video>/ and ./SAIS/flows/<video>/ if they exist)
+
+# extract representations of rgb images
+python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 1024 --data_path ./SAIS/ --data_list Custom --save_type h5 --video $videoname $SYN || exit 1
+
+# extract representations of flow maps
+python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 256 --data_path ./SAIS/ --data_list Custom --save_type h5 --optical_flow_to_reps --video $videoname $SYN || exit 1
+
+# perform inference
+python ./SAIS/scripts/run_experiments.py -p ./SAIS/ -data Custom_Gestures -d Custom -m ViT -enc ViT_SelfSupervised_ImageNet -t Prototypes -mod RGB-Flow -dim 384 -bs 2 -lr 1e-1 -nc 2 -bc -sa -domains in_vs_out -ph Custom_inference -dt reps -e 1 -f 1 --inference || exit 1
+
+# (process_inference_results.py: "next" row)

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Drop-in for the hot-path branch of the reference's SAIS/scripts/extract_representations.py (:351-378, flags
+:410-435): DINO ViT-S/16 CLS features of every frame of a video -> results/<model_type>_[Flow]RepsAndLabels.{h5|npz}.
+The ViT runs on the MI355X kernels (sais_amd.vit) inside a hipGraph.  Flags keep the reference's names; the
+`--arch` choices no longer call torch.hub (a network call at parser build time, :416)."""
+import argparse
+import glob
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from SAIS.scripts._features_io import save_reps  # noqa: E402
+
+MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # :148
+
+
+def load_frames(folder):
+    """SurgDataset.__getitem__ (dino-main/main_dino.py:295-316): CenterCrop(0.8 H, 0.8 W) -> Resize((224,224)) ->
+    ToTensor -> Normalize.  Host-side PIL restatement (torchvision is absent here: unpinned)."""
+    from PIL import Image
+    out = []
+    for p in sorted(glob.glob(os.path.join(folder, '*.jpg'))):
+        img = Image.open(p).convert('RGB')
+        w, h = img.size
+        cw, ch = int(0.8 * w), int(0.8 * h)
+        l, t = (w - cw) // 2, (h - ch) // 2
+        img = img.crop((l, t, l + cw, t + ch)).resize((224, 224), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+        out.append((x - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1))
+    return torch.stack(out) if out else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--arch', default='vit_small', type=str, choices=['vit_tiny', 'vit_small', 'vit_base'])
+    ap.add_argument('--patch_size', default=16, type=int)
+    ap.add_argument('--drop_path_rate', type=float, default=0.1)
+    ap.add_argument('--model_type', default='ViT_SelfSupervised_ImageNet', type=str)
+    ap.add_argument('--batch_size_per_gpu', default=64, type=int)
+    ap.add_argument('--data_path', default='./SAIS/', type=str)
+    ap.add_argument('--data_list', default=['Custom'], nargs='+')
+    ap.add_argument('--save_type', default='h5', choices=['dict', 'h5'])
+    ap.add_argument('--optical_flow', action='store_true')
+    ap.add_argument('--segmentation', action='store_true')
+    ap.add_argument('--optical_flow_to_reps', action='store_true')
+    ap.add_argument('--segmentation_to_reps', action='store_true')
+    ap.add_argument('--local_rank', '--local-rank', default=0, type=int)
+    ap.add_argument('--video', default=None, type=str, help='video label (folder under images/ or flows/)')
+    ap.add_argument('--synthetic_frames', default=0, type=int, help='use N seeded synthetic frames instead of JPEGs')
+    ap.add_argument('--checkpoint', default=None, type=str, help='dino_deitsmall16_pretrain.pth (default: dino-main/outputs/)')
+    args = ap.parse_args()
+    if args.arch != 'vit_small' or args.patch_size != 16:
+        raise SystemExit('the MI355X kernels implement vit_small / patch 16 only')
+    if args.optical_flow or args.segmentation or args.segmentation_to_reps:
+        raise SystemExit('RAFT optical flow / segmentation are out of scope of this build (SURVEY.md §2)')
+    t0 = time.time()
+    from sais_amd.inference import FeatureExtractor
+    from sais_amd.model_io import load_vit
+    dev = torch.device('cuda', args.local_rank)
+    ckpt = args.checkpoint or os.path.join(args.data_path, 'scripts', 'dino-main', 'outputs', 'dino_deitsmall16_pretrain.pth')
+    if not os.path.exists(ckpt):
+        print(f'[extract] {ckpt} not found: using seeded random ViT-S/16 weights (no network in this environment)')
+        ckpt = None
+    torch.manual_seed(0)
+    vit = load_vit(ckpt, device=dev, drop_path_rate=args.drop_path_rate)
+    flow = args.optical_flow_to_reps
+    sub = 'flows' if flow else 'images'
+    videos = [args.video] if args.video else sorted(os.listdir(os.path.join(args.data_path, sub)))
+    fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 64), use_graph=True)
+    reps = {}
+    for v in videos:
+        if args.synthetic_frames:
+            g = torch.Generator().manual_seed(1 if flow else 0)
+            n = max(1, args.synthetic_frames // 15) if flow else args.synthetic_frames     # flow maps: every 15th frame
+            u8 = torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8).float() / 255.0
+            frames = (u8 - torch.tensor(MEAN).view(1, 3, 1, 1)) / torch.tensor(STD).view(1, 3, 1, 1)
+        else:
+            frames = load_frames(os.path.join(args.data_path, sub, v))
+            if frames is None:
+                raise SystemExit(f'no frames under {os.path.join(args.data_path, sub, v)}')
+        reps[v] = fx(frames.to(dev)).cpu().numpy()
+        print(f'[extract] {v}: {reps[v].shape[0]} frames -> {reps[v].shape}')
+    name = '%s_%sRepsAndLabels' % (args.model_type, 'Flow' if flow else '')
+    print('[extract] saved', save_reps(args.data_path, name, reps))
+    print('Time taken (s): %.3f' % (time.time() - t0))
+
+
+if __name__ == '__main__':
+    main()

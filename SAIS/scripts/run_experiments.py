@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Drop-in for the inference surface of the reference's SAIS/scripts/run_experiments.py (:19-121) on MI355X:
+same flags, same params/Fold_<k>/ layout ((params.zip, prototypes.zip) in, reps_and_labels_<ph> / attention_<ph> /
+importance_<ph> out, train.py:113-119).  Only what main.sh:27 exercises is implemented:
+-data Custom_Gestures -m ViT -t Prototypes -dt reps, phases ending in `inference`."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from SAIS.scripts._features_io import load_reps  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument('-p', '--path', type=str)
+    p.add_argument('-data', '--dataset_name', type=str)
+    p.add_argument('-d', '--domain_name', type=str)
+    p.add_argument('-m', '--model', type=str, default='R3D')
+    p.add_argument('-enc', '--encoder_params', type=str, default='ViT_SelfSupervised_ImageNet')
+    p.add_argument('-dim', '--rep_dim', type=int, default=512)
+    p.add_argument('-mod', '--modalities', type=str)
+    p.add_argument('-bs', '--batch_size', type=int, default=1)
+    p.add_argument('-lr', '--learning_rate', type=float)
+    p.add_argument('-tf', '--training_fraction', type=float, default=1)
+    p.add_argument('-fe', '--freeze_encoder', default=False, action='store_true')
+    p.add_argument('-t', '--task', type=str)
+    p.add_argument('-nc', '--nclasses', type=int)
+    p.add_argument('-bc', '--balance_classes', default=False, action='store_true')
+    p.add_argument('-bg', '--balance_groups', default=False, action='store_true')
+    p.add_argument('-sg', '--single_group', default=False, action='store_true')
+    p.add_argument('-sa', '--self_attention', default=False, action='store_true')
+    p.add_argument('-il', '--importance_loss', default=False, action='store_true')
+    p.add_argument('-domains', '--domains', nargs='+', type=str)
+    p.add_argument('-ph', '--phases', nargs='+')
+    p.add_argument('-dt', '--data_type', type=str)
+    p.add_argument('-e', '--nepochs', type=int)
+    p.add_argument('-f', '--nfolds', type=int)
+    p.add_argument('-i', '--inference', default=False, action='store_true')
+    p.add_argument('--local_rank', '--local-rank', type=int, default=0)
+    a = p.parse_args()
+    print('Modalities: %s' % a.modalities)
+    print('Self Attention: %s' % str(a.self_attention))
+    if not a.inference or a.dataset_name != 'Custom_Gestures':
+        raise SystemExit('this build covers the inference surface of main.sh:27 (Custom_Gestures, --inference); '
+                         'training on the private datasets needs prepare_dataset.py, which is out of scope')
+    t0 = time.time()
+    from sais_amd.inference import run_windows, save_inference_outputs, tta_probs
+    from sais_amd.model_io import loadModel
+    rgb = load_reps(a.path, '%s_RepsAndLabels' % a.encoder_params)
+    flow = load_reps(a.path, 'ViT_SelfSupervised_ImageNet_FlowRepsAndLabels')
+    for domain in a.domains:
+        for fold in range(a.nfolds):
+            savepath = os.path.join(a.path, 'params/Fold_%i' % fold)                 # getSavepath :82-83
+            print('***** \n Savepath: %s \n *****' % savepath)
+            md, opt, dev = loadModel(a.local_rank, 1, savepath, a.data_type, a.nclasses, domain, a.rep_dim, a.model,
+                                     a.task, fold, lr=a.learning_rate, modalities=a.modalities,
+                                     freeze_encoder_params=a.freeze_encoder, self_attention=a.self_attention,
+                                     importance_loss=a.importance_loss, inference=True)
+            for phase in a.phases:
+                all_reps, all_attn = {"reps": ([], [], []), "labels": [], "videonames": [], "logits": []}, []
+                for video in sorted(rgb.keys()):
+                    x = torch.from_numpy(rgb[video]).float().to(dev)
+                    f = torch.from_numpy(flow[video]).float().to(dev)
+                    r, attn = run_windows(md['model'], x, f, videoname=video, batch_size=a.batch_size)
+                    for v in range(3):
+                        all_reps["reps"][v].extend(r["reps"][v])
+                    all_reps["labels"] += r["labels"]
+                    all_reps["videonames"] += r["videonames"]
+                    all_attn += attn
+                save_inference_outputs(savepath, phase, all_reps, all_attn)
+                probs = tta_probs(all_reps, md['prototypes'])
+                print('[%s] %i windows; mean class probabilities %s' % (phase, probs.shape[0], probs.mean(0).tolist()))
+    print('Time taken (s): %.3f' % (time.time() - t0))
+
+
+if __name__ == '__main__':
+    main()

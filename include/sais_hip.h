@@ -139,11 +139,15 @@ int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B
 
 /* ---------------------------------------------------------------- head + SupCon / prototype loss
  * fullModel.forward Prototypes branch, prepare_model.py:215,220,381-416:
- *   rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = linear(relu(rep))   (256 outputs)        */
-int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, int B, const float* W /*[256,384]*/,
-                  const float* bias, float* rep /*[B,384] saved*/, float* emb /*[B,256]*/, void* stream);
+ *   rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = linear(relu(rep))   (256 outputs).
+ * The two streams may have different padded lengths (clip strides): at inference the flow stream
+ * has 1-2 frames per 15-frame window (prepare_dataset.py:2660-2666).                              */
+int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, long clip_stride_flow, int B,
+                  const float* W /*[256,384]*/, const float* bias, float* rep /*[B,384] saved*/, float* emb /*[B,256]*/,
+                  void* stream);
 int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb, const float* z_flow,
-                  long clip_stride, int B, float* dW, float* dbias, float* dz_rgb, float* dz_flow, void* stream);
+                  long clip_stride, long clip_stride_flow, int B, float* dW, float* dbias, float* dz_rgb,
+                  float* dz_flow, void* stream);
 /* calcNCELoss / getProbs, prepare_miscellaneous.py:14-46,111-126: sim = s_hat p_hat^T (the class logits),
  * probs = softmax(sim), loss = -mean log probs[i, label_col[i]].  With demb != NULL also the gradients:
  * demb (written) and dprotos (accumulated), both scaled by loss_scale.                            */

@@ -182,13 +182,14 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
 // ---------------------------------------------------------------- head
 // rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = W relu(rep) + bias
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const float* zf, long clip_stride,
-                                                       const float* W, const float* bias, float* rep, float* emb) {
+                                                       long clip_stride_f, const float* W, const float* bias,
+                                                       float* rep, float* emb) {
     __shared__ float sr[D];
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int c = tid; c < D; c += 256) {
         float v = 0.f;
         if (zr) v += fmaxf(zr[(size_t)b * clip_stride + c], 0.f);
-        if (zf) v += fmaxf(zf[(size_t)b * clip_stride + c], 0.f);
+        if (zf) v += fmaxf(zf[(size_t)b * clip_stride_f + c], 0.f);
         rep[(size_t)b * D + c] = v;
         sr[c] = fmaxf(v, 0.f);
     }
@@ -204,8 +205,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const fl
 
 // demb [B,256] -> dW += demb^T relu(rep), db += sum_b demb, dz_rgb[b,0,:] / dz_flow[b,0,:]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const float* W, const float* rep,
-                                                       const float* zr, const float* zf, long clip_stride, int B,
-                                                       float* dW, float* dbias, float* dzr, float* dzf) {
+                                                       const float* zr, const float* zf, long clip_stride,
+                                                       long clip_stride_f, int B, float* dW, float* dbias, float* dzr,
+                                                       float* dzf) {
     __shared__ float sd[EMB];
     const int b = blockIdx.x, tid = threadIdx.x;
     sd[tid] = demb[(size_t)b * EMB + tid];
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const 
         }
         float drep = r > 0.f ? a : 0.f;
         if (zr) dzr[(size_t)b * clip_stride + c] = zr[(size_t)b * clip_stride + c] > 0.f ? drep : 0.f;
-        if (zf) dzf[(size_t)b * clip_stride + c] = zf[(size_t)b * clip_stride + c] > 0.f ? drep : 0.f;
+        if (zf) dzf[(size_t)b * clip_stride_f + c] = zf[(size_t)b * clip_stride_f + c] > 0.f ? drep : 0.f;
     }
 }
 
@@ -357,23 +359,23 @@ extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key
     return sais_check_launch();
 }
 
-extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, int B, const float* W,
-                             const float* bias, float* rep, float* emb, void* stream) {
+extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, long clip_stride_flow, int B,
+                             const float* W, const float* bias, float* rep, float* emb, void* stream) {
     SAIS_ENTER();
     if ((!z_rgb && !z_flow) || !W || !bias || !rep || !emb || B <= 0) return SAIS_ERR_ARG;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride, W, bias,
-                       rep, emb);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride,
+                       clip_stride_flow, W, bias, rep, emb);
     return sais_check_launch();
 }
 
 extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb,
-                             const float* z_flow, long clip_stride, int B, float* dW, float* dbias, float* dz_rgb,
-                             float* dz_flow, void* stream) {
+                             const float* z_flow, long clip_stride, long clip_stride_flow, int B, float* dW,
+                             float* dbias, float* dz_rgb, float* dz_flow, void* stream) {
     SAIS_ENTER();
     if (!demb || !W || !rep || !dW || !dbias || B <= 0) return SAIS_ERR_ARG;
     if ((z_rgb && !dz_rgb) || (z_flow && !dz_flow)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, demb, W, rep, z_rgb, z_flow,
-                       clip_stride, B, dW, dbias, dz_rgb, dz_flow);
+                       clip_stride, clip_stride_flow, B, dW, dbias, dz_rgb, dz_flow);
     return sais_check_launch();
 }
 

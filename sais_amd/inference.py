@@ -1,0 +1,168 @@
+"""Inference surface of SAIS on MI355X: frozen ViT feature extraction (fixed-shape batches replayed from a
+hipGraph) -> Custom_Gestures sliding windows with 3 test-time-augmentation index sets -> temporal encoder ->
+embeddings + attention maps, written in the reference's output formats.
+
+Reference behaviour restated here (paths relative to SAIS/scripts/):
+  extract_representations.extractFeatures :351-378   eval / no_grad loop over frame batches -> [nframes,384]
+  prepare_dataset.py:1705-1727   windows: duration 0.5 s x 30 fps = 15 frames, hop 15:
+                                 nsamples = (total - 15)//15 + 1, StartFrame = 15 n, EndFrame = StartFrame + 15
+  prepare_dataset.py:2642-2666   startIdx = StartFrame-1, endIdx = EndFrame-1, jump = (end-start)//10 = 1;
+                                 TTA index sets arange(start+{0,3,6}, end) -> 15 / 12 / 9 frames; the first window
+                                 starts at -1, which numpy wraps to the LAST frame (App. B.6, reproduced);
+                                 flow rows = unique(idx // 15) kept if < len(flow_reps)  (so -1 -> last row too)
+  prepare_dataset.py:2839-2899   pad_collate, tuple branch: per TTA version zero-pad to the batch max and build the
+                                 bool key-padding mask [B,1,maxT+1]
+  perform_training.py:96-185, train.py:113-119   per-sample reps lists (tuple of 3 under TTA), attention list of
+                                 per-batch [B,T+1,T+1], labels, videonames, logits=[]
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+DURATION_FRAMES, HOP_FRAMES, FLOW_JUMP = 15, 15, 15
+TTA_OFFSETS = (0, 3, 6)
+
+
+# --------------------------------------------------------------------------- window sampler (host logic)
+def gesture_windows(total_frames):
+    """[(StartFrame, EndFrame)] — prepare_dataset.py:1716-1719."""
+    nsamples = (total_frames - DURATION_FRAMES) // HOP_FRAMES + 1
+    return [(n * HOP_FRAMES, n * HOP_FRAMES + DURATION_FRAMES) for n in range(max(nsamples, 0))]
+
+
+def tta_indices(start_frame, end_frame):
+    """Three RGB index sets of one window — prepare_dataset.py:2642-2651 (may contain -1)."""
+    s, e = start_frame - 1, end_frame - 1
+    jump = (e - s) // 10
+    return [list(np.arange(s + off, e, jump)) for off in TTA_OFFSETS]
+
+
+def flow_rows(indices, nflow):
+    """prepare_dataset.py:2660-2666: unique(idx // 15) with idx < len(flow_reps) (negative rows survive the filter)."""
+    rows = np.unique([i // FLOW_JUMP for i in indices])
+    return [int(r) for r in rows if r < nflow]
+
+
+def sample_window(rgb_reps, flow_reps, start_frame, end_frame):
+    """One dataset item: ((x0,x1,x2), (f0,f1,f2)) with x_v [1,T_v,384], f_v [1,Tf_v,384]  (:2653-2700)."""
+    xs, fs = [], []
+    for idx in tta_indices(start_frame, end_frame):
+        xs.append(rgb_reps[idx].unsqueeze(0))                       # negative index wraps, as numpy does there
+        fs.append(flow_reps[flow_rows(idx, flow_reps.shape[0])].unsqueeze(0))
+    return tuple(xs), tuple(fs)
+
+
+def pad_collate_tta(items):
+    """pad_collate, Prototypes / tuple branch (:2841-2873).  items: list of ((x0,x1,x2),(f0,f1,f2)).
+    Returns per version: padded x [B,1,maxT,384], mask [B,1,maxT+1] (True = masked), lens — and the same for flow."""
+    out = {"x": [], "xpad": [], "xlens": [], "f": [], "fpad": [], "flens": []}
+    nver = len(items[0][0])
+    for v in range(nver):
+        for key, which in (("x", 0), ("f", 1)):
+            seqs = [it[which][v] for it in items]                    # each [1,T,384]
+            lens = [s.shape[1] for s in seqs]
+            maxT = max(lens)
+            B = len(seqs)
+            padded = seqs[0].new_zeros(B, 1, maxT, seqs[0].shape[-1])
+            mask = torch.zeros(B, 1, maxT + 1, dtype=torch.bool, device=seqs[0].device)
+            for b, s in enumerate(seqs):
+                padded[b, :, :lens[b]] = s
+                mask[b, :, lens[b] + 1:] = True                       # createPaddingMask :2798-2806
+            out[key].append(padded)
+            out[key + "pad"].append(mask)
+            out[key + "lens"].append(lens)
+    return out
+
+
+# --------------------------------------------------------------------------- ViT feature extraction
+class FeatureExtractor:
+    """extractFeatures (:351-378) with the fixed-shape ViT forward captured once into a hipGraph and replayed per
+    batch (the launch-bound part of inference: ~90 kernel launches per batch collapse into one graph launch)."""
+
+    def __init__(self, vit, batch_size=32, use_graph=True):
+        self.vit = vit.eval()
+        self.bs = batch_size
+        self.use_graph = use_graph
+        self.graph = None
+        self.static_in = None
+        self.static_out = None
+
+    def _capture(self, device):
+        self.static_in = torch.zeros(self.bs, 3, 224, 224, device=device)
+        with torch.no_grad():
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(2):                                    # warm-up: allocator + LDS attributes + shadows
+                    self.vit(self.static_in)
+            torch.cuda.current_stream().wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = self.vit(self.static_in)
+
+    @torch.no_grad()
+    def __call__(self, frames):
+        """frames [N,3,224,224] (device) -> [N,384] fp32."""
+        if not frames.is_cuda:
+            raise L.SaisHipError("FeatureExtractor needs device tensors: the HIP path has no CPU fallback")
+        N = frames.shape[0]
+        out = torch.empty(N, 384, device=frames.device)
+        if self.use_graph and self.graph is None:
+            self._capture(frames.device)
+        for i in range(0, N, self.bs):
+            n = min(self.bs, N - i)
+            if self.use_graph:
+                self.static_in[:n].copy_(frames[i:i + n])
+                if n < self.bs:
+                    self.static_in[n:].zero_()
+                self.graph.replay()
+                out[i:i + n].copy_(self.static_out[:n])
+            else:
+                out[i:i + n] = self.vit(frames[i:i + n].float())
+        return out
+
+
+# --------------------------------------------------------------------------- windowed temporal inference
+@torch.no_grad()
+def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2):
+    """The `Custom_inference` phase of single_epoch (perform_training.py:71-185) over one video.
+    Returns the dict train.py:116 saves as reps_and_labels_<phase> plus the attention list (:117)."""
+    model.eval()
+    wins = gesture_windows(rgb_reps.shape[0])
+    reps = ([], [], [])
+    attention, labels, names = [], [], []
+    for i in range(0, len(wins), batch_size):
+        items = [sample_window(rgb_reps, flow_reps, s, e) for s, e in wins[i:i + batch_size]]
+        c = pad_collate_tta(items)
+        use_f = model.modalities in ("Flow", "RGB-Flow")
+        embs, attn = model(c["x"], c["f"] if use_f else None, c["xlens"], c["flens"], 'Prototypes', c["xpad"],
+                           c["fpad"] if use_f else None, None)
+        for v in range(3):
+            for b in range(len(items)):
+                reps[v].append(embs[v][b].detach().cpu())
+        attention.append(attn.detach().cpu())
+        labels += [torch.tensor(0, dtype=torch.long)] * len(items)          # placeholder label (:2637)
+        names += [videoname] * len(items)
+    return {"reps": reps, "labels": labels, "videonames": names, "logits": []}, attention
+
+
+def save_inference_outputs(savepath, phase, reps_and_labels, attention):
+    """train.py:113-119 — rank 0 writes reps_and_labels_<ph>, attention_<ph>, importance_<ph> with torch.save."""
+    os.makedirs(savepath, exist_ok=True)
+    torch.save(reps_and_labels, os.path.join(savepath, f"reps_and_labels_{phase}"))
+    torch.save(attention, os.path.join(savepath, f"attention_{phase}"))
+    torch.save([], os.path.join(savepath, f"importance_{phase}"))
+
+
+def tta_probs(reps_and_labels, prototypes):
+    """process_inference_results.py:76-91,218: calcProbs per TTA version, then the mean over versions."""
+    from .loss import cosine_logits_and_probs
+    dev = next(iter(prototypes.values())).device
+    probs = []
+    for v in range(3):
+        emb = torch.stack(reps_and_labels["reps"][v]).to(dev)
+        probs.append(cosine_logits_and_probs(emb, prototypes)[1])
+    return torch.stack(probs).mean(0)

@@ -234,13 +234,17 @@ class fullModel(nn.Module):
             if x is None:
                 attn = fattn
         ref = x if x is not None else f
-        B, S = ref.shape[0], ref.shape[2] + 1
-        if zr is not None and zf is not None and zr.shape != zf.shape:
-            raise ValueError("RGB and flow streams must have the same padded length")
+        B = ref.shape[0]
+        # the two streams may have different lengths (inference: 15 RGB frames vs 1-2 flow frames per window)
+        Sx = x.shape[2] + 1 if x is not None else f.shape[2] + 1
+        Sf = f.shape[2] + 1 if f is not None else Sx
+        if x is not None and f is not None and x.shape[0] != f.shape[0]:
+            raise ValueError("RGB and flow streams must have the same batch size")
         rep = torch.empty(B, D, dtype=torch.float32, device=ref.device)
         emb = torch.empty(B, EMB, dtype=torch.float32, device=ref.device)
-        ops.head_fwd(zr, zf, S * D, B, fl.w32("linear.weight"), fl.w32("linear.bias"), rep, emb)
-        saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, S=S) if save else None
+        ops.head_fwd(zr, zf, (Sx if zr is not None else Sf) * D, B, fl.w32("linear.weight"), fl.w32("linear.bias"), rep, emb,
+                     clip_stride_flow=Sf * D)
+        saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, Sx=Sx, Sf=Sf) if save else None
         return emb, attn, saved
 
     def _stream_bwd(self, s, dz, need_dx):
@@ -283,12 +287,12 @@ class fullModel(nn.Module):
     def _backward_kernels(self, saved, demb, needs):
         fl = self.flat
         fl.attach_grads()
-        B, S = saved["B"], saved["S"]
+        B, Sx, Sf = saved["B"], saved["Sx"], saved["Sf"]
         zr, zf = saved["zr"], saved["zf"]
         dzr = torch.zeros_like(zr) if zr is not None else None
         dzf = torch.zeros_like(zf) if zf is not None else None
-        ops.head_bwd(demb, fl.w32("linear.weight"), saved["rep"], zr, zf, S * D, B, fl.g("linear.weight"),
-                     fl.g("linear.bias"), dzr, dzf)
+        ops.head_bwd(demb, fl.w32("linear.weight"), saved["rep"], zr, zf, (Sx if zr is not None else Sf) * D, B,
+                     fl.g("linear.weight"), fl.g("linear.bias"), dzr, dzf, clip_stride_flow=Sf * D)
         dx = self._stream_bwd(saved["sr"], dzr, needs[0]) if zr is not None else None
         df = self._stream_bwd(saved["sf"], dzf, needs[1]) if zf is not None else None
         if self.grad_ready_hook:

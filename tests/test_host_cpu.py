@@ -157,3 +157,23 @@ def test_data_parallel_gradient_exchange_gloo_world2(tmp_path):
     ok_v, ok_m, cover, nbytes = open(out).read().split()
     assert (ok_v, ok_m, cover) == ("True", "True", "True")
     assert int(nbytes) > 4 * 3_000_000
+
+
+def test_window_sampler_and_tta_indices_follow_the_reference_quirks():
+    from sais_amd.inference import flow_rows, gesture_windows, pad_collate_tta, sample_window, tta_indices
+    wins = gesture_windows(512)
+    assert len(wins) == 34 and wins[0] == (0, 15) and wins[-1] == (495, 510)          # (512-15)//15+1
+    assert gesture_windows(14) == []
+    i0, i1, i2 = tta_indices(0, 15)
+    assert i0[0] == -1 and i0[-1] == 13 and [len(i0), len(i1), len(i2)] == [15, 12, 9]   # first window wraps (App. B.6)
+    assert i1[0] == 2 and i2[0] == 5
+    assert flow_rows(i0, 34) == [-1, 0] and flow_rows(tta_indices(15, 30)[0], 34) == [0, 1]
+    assert flow_rows(tta_indices(495, 510)[0], 33) == [32]                               # row 33 filtered: >= len
+    rgb, flow = torch.arange(512.).view(512, 1).repeat(1, 384), torch.arange(34.).view(34, 1).repeat(1, 384)
+    xs, fs = sample_window(rgb, flow, 0, 15)
+    assert xs[0][0, 0, 0].item() == 511.0 and xs[0][0, 1, 0].item() == 0.0              # index -1 -> last frame
+    assert fs[0][0, :, 0].tolist() == [33.0, 0.0]
+    c = pad_collate_tta([sample_window(rgb, flow, *wins[0]), sample_window(rgb, flow, *wins[1])])
+    assert [tuple(t.shape) for t in c["x"]] == [(2, 1, 15, 384), (2, 1, 12, 384), (2, 1, 9, 384)]
+    assert tuple(c["xpad"][0].shape) == (2, 1, 16) and not c["xpad"][0].any()
+    assert c["flens"][0] == [2, 2] and tuple(c["f"][0].shape) == (2, 1, 2, 384)

@@ -1,0 +1,134 @@
+"""BASELINE config 5 (long-video inference: 512 synthetic frames, hipGraph-captured ViT extraction, 34 sliding
+windows x 3 TTA index sets, attention-map export) and the two-stream shapes of config 4, on a real MI355X,
+checked against the CPU oracle; plus the main.sh-equivalent CLI run end to end on synthetic frames."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return True
+
+
+def _models():
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    vit = vit_small(patch_size=16)
+    vit.load_state_dict(synth.vit_state_dict(seed=0))
+    m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB-Flow')
+    m.load_state_dict(synth.temporal_state_dict(seed=1))
+    return vit.to(DEV).eval(), m.to(DEV).eval()
+
+
+def test_long_video_512_frames_graph_extraction_and_windows(gpu):
+    from oracle import sais_oracle as O
+    from sais_amd.inference import FeatureExtractor, gesture_windows, run_windows, sample_window, tta_probs
+    vit, m = _models()
+    N = 512
+    frames = synth.clips(seed=5, B=1, T=N)[0]                       # [512,3,224,224]
+    flow_frames = synth.clips(seed=6, B=1, T=N // 15)[0]            # one flow map per 15 frames
+    fx = FeatureExtractor(vit, batch_size=64, use_graph=True)
+    reps = fx(frames.to(DEV))
+    reps_eager = FeatureExtractor(vit, batch_size=64, use_graph=False)(frames.to(DEV))
+    assert torch.equal(reps, reps_eager), "hipGraph replay must reproduce the eager kernels bit for bit"
+    flow_reps = fx(flow_frames.to(DEV))
+    # spot-check the features of 4 frames against the oracle (cosine against random directions <= 1e-3)
+    idx = [0, 63, 64, 511]
+    with torch.no_grad():
+        ref = O.vit_forward(synth.vit_state_dict(seed=0), frames[idx])
+    p = torch.randn(3, 384, generator=torch.Generator().manual_seed(5))
+    cos = lambda a: (a / a.norm(dim=1, keepdim=True)) @ (p / p.norm(dim=1, keepdim=True)).t()
+    assert (cos(reps[idx].cpu()) - cos(ref)).abs().max().item() <= 1e-3
+
+    out, attention = run_windows(m, reps, flow_reps, videoname="synthetic", batch_size=2)
+    wins = gesture_windows(N)
+    assert len(wins) == 34 and len(out["reps"][0]) == 34 and len(out["videonames"]) == 34
+    attn = torch.cat(attention)
+    assert tuple(attn.shape) == (34, 16, 16)
+    assert torch.allclose(attn.sum(-1), torch.ones(34, 16), atol=1e-4)
+    # temporal half vs the oracle at the GPU's own features, incl. the wrap-around first window (index -1)
+    tsd = synth.temporal_state_dict(seed=1)
+    rc, fc = reps.cpu(), flow_reps.cpu()
+    for w in (0, 1, 33):
+        xs, fs = sample_window(rc, fc, *wins[w])
+        assert [x.shape[1] for x in xs] == [15, 12, 9]
+        for v in range(3):
+            x, f = xs[v].unsqueeze(0), fs[v].unsqueeze(0)            # [1,1,T,384]
+            padx = torch.zeros(1, 1, x.shape[2] + 1, dtype=torch.bool)
+            padf = torch.zeros(1, 1, f.shape[2] + 1, dtype=torch.bool)
+            with torch.no_grad():
+                e_ref, a_ref = O.temporal_forward(tsd, x, f, padx, padf, "RGB-Flow")
+            got = out["reps"][v][w]
+            sim = O.cosine_logits(got.unsqueeze(0), synth.prototypes(2, 2))
+            sim_ref = O.cosine_logits(e_ref, synth.prototypes(2, 2))
+            assert (sim - sim_ref).abs().max().item() <= 1e-3
+            if v == 0:
+                assert (attn[w] - a_ref[0]).abs().max().item() <= 2e-3
+    protos = torch.nn.ParameterDict({k: torch.nn.Parameter(v.to(DEV)) for k, v in synth.prototypes(2, 2).items()})
+    probs = tta_probs(out, protos)
+    assert tuple(probs.shape) == (34, 2) and torch.allclose(probs.sum(1).cpu(), torch.ones(34), atol=1e-5)
+
+
+def test_two_streams_with_different_lengths_and_ragged_batch(gpu):
+    """config 4 shapes at inference: RGB T=15/12, flow T=2/1 in one padded batch."""
+    from oracle import sais_oracle as O
+    _, m = _models()
+    x = synth.reps(seed=21, B=2, T=15)
+    f = synth.reps(seed=22, B=2, T=2)
+    xl, fl = [15, 12], [2, 1]
+    x[1, :, 12:] = 0
+    f[1, :, 1:] = 0
+    xpad, fpad = synth.padding_mask(xl), synth.padding_mask(fl)
+    with torch.no_grad():
+        emb, attn = m(x.to(DEV), f.to(DEV), xl, fl, 'Prototypes', xpad.to(DEV), fpad.to(DEV), None)
+        e_ref, a_ref = O.temporal_forward(synth.temporal_state_dict(seed=1), x, f, xpad, fpad, "RGB-Flow")
+    assert (emb.cpu() - e_ref).abs().max().item() <= 1e-4
+    assert (attn.cpu() - a_ref).abs().max().item() <= 1e-5
+
+
+def test_cli_main_sh_equivalent_on_synthetic_frames(gpu, tmp_path):
+    """extract_representations.py (RGB + flow) -> run_experiments.py --inference, with the reference's flags, file
+    layout and output formats."""
+    from sais_amd import model_io
+    from sais_amd.temporal import fullModel
+    root = tmp_path / "SAIS"
+    fold = root / "params" / "Fold_0"
+    fold.mkdir(parents=True)
+    m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT')
+    m.load_state_dict(synth.temporal_state_dict(seed=1))
+    model_io.save_params_file(m, fold / "params.zip")
+    model_io.save_prototypes_file(synth.prototypes(2, 2), fold / "prototypes.zip")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    ex = [sys.executable, os.path.join(ROOT, "SAIS/scripts/extract_representations.py"), "--arch", "vit_small",
+          "--patch_size", "16", "--model_type", "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "1024",
+          "--data_path", str(root) + "/", "--data_list", "Custom", "--save_type", "h5", "--video", "vid_01",
+          "--synthetic_frames", "64"]
+    subprocess.run(ex, check=True, env=env, cwd=ROOT)
+    subprocess.run(ex + ["--optical_flow_to_reps"], check=True, env=env, cwd=ROOT)
+    run = [sys.executable, os.path.join(ROOT, "SAIS/scripts/run_experiments.py"), "-p", str(root) + "/", "-data",
+           "Custom_Gestures", "-d", "Custom", "-m", "ViT", "-enc", "ViT_SelfSupervised_ImageNet", "-t", "Prototypes",
+           "-mod", "RGB-Flow", "-dim", "384", "-bs", "2", "-lr", "1e-1", "-nc", "2", "-bc", "-sa", "-domains",
+           "in_vs_out", "-ph", "Custom_inference", "-dt", "reps", "-e", "1", "-f", "1", "--inference"]
+    subprocess.run(run, check=True, env=env, cwd=ROOT)
+    r = torch.load(fold / "reps_and_labels_Custom_inference", weights_only=False)
+    attn = torch.load(fold / "attention_Custom_inference", weights_only=False)
+    imp = torch.load(fold / "importance_Custom_inference", weights_only=False)
+    nwin = (64 - 15) // 15 + 1
+    assert isinstance(r["reps"], tuple) and len(r["reps"]) == 3 and len(r["reps"][0]) == nwin
+    assert tuple(r["reps"][0][0].shape) == (256,) and r["logits"] == [] and r["videonames"] == ["vid_01"] * nwin
+    assert r["labels"][0].dtype == torch.int64 and r["labels"][0].dim() == 0
+    assert sum(a.shape[0] for a in attn) == nwin and tuple(attn[0].shape[1:]) == (16, 16)
+    assert imp == []
