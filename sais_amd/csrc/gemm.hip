@@ -35,10 +35,16 @@ DEVINL int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 
 // weight-row permutation inside a 64-row wave panel: n_local = 16a + 4t + b  ->  LDS row 16t + 4a + b
 DEVINL int perm_row(int n) { return (n & 64) | ((n & 0x0c) << 2) | ((n & 0x30) >> 2) | (n & 3); }
 
+// Epilogue in two phases.  vmcnt is in-order and counts stores on CDNA4, so a load issued after a store cannot be
+// consumed before that store has been acknowledged: phase A issues EVERY load a lane needs (bias once, the
+// residual / pre-activation rows of all four 16-row sub-tiles), phase B only does arithmetic and stores.
+struct EpiAux {
+    f32x4 r[4][4];        // f32 aux (residual / position rows): 16 columns x 4 sub-tiles
+    bf16x8 u[4][2];       // bf16 aux (pre-activation)
+};
+
 template <int EPI>
-DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16]) {
-    // one output row m, 16 contiguous columns n..n+15 (n multiple of 16)
-    float b[16];
+DEVINL void epilogue_loads(const NtParams& p, int mbase, int li, int n, float (&b)[16], EpiAux& a) {
     if (p.bias) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -49,6 +55,27 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16]) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) b[i] = 0.f;
     }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int m = mbase + mt * 16 + li;
+        m = m < p.M ? m : p.M - 1;
+        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_PATCH_F32) {
+            size_t row = m;
+            if constexpr (EPI == SAIS_EPI_PATCH_F32) row = (m % p.grp_in) + p.grp_off;
+            const float* r = (const float*)p.aux + row * p.ldaux + n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a.r[mt][i] = *(const f32x4*)(r + 4 * i);
+        } else if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16) {
+            const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;
+            a.u[mt][0] = *(const bf16x8*)u;
+            a.u[mt][1] = *(const bf16x8*)(u + 8);
+        }
+    }
+}
+
+template <int EPI>
+DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16], const float (&b)[16], const EpiAux& a, int mt) {
+    // one output row m, 16 contiguous columns n..n+15 (n multiple of 16)
     float y[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) y[i] = v[i] + b[i];
@@ -75,42 +102,27 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16]) {
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_BIAS_F32) {
         store_f32(p.out, p.ldo, m, y);
-    } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
-        const float* r = (const float*)p.aux + (size_t)m * p.ldaux + n;
+    } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_PATCH_F32) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 t = *(const f32x4*)(r + 4 * i);
-            y[4 * i] += t[0]; y[4 * i + 1] += t[1]; y[4 * i + 2] += t[2]; y[4 * i + 3] += t[3];
-        }
-        store_f32(p.out, p.ldo, m, y);
-        if (p.out2) store_bf16(p.out2, p.ldo2, y);
+        for (int i = 0; i < 16; ++i) y[i] += a.r[mt][i >> 2][i & 3];
+        size_t orow = m;
+        if constexpr (EPI == SAIS_EPI_PATCH_F32) orow = (size_t)(m / p.grp_in) * p.grp_out + (m % p.grp_in) + p.grp_off;
+        store_f32(p.out, p.ldo, orow, y);
+        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32)
+            if (p.out2) store_bf16(p.out2, p.ldo2, y);
     } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
         if (p.out2) store_bf16(p.out2, p.ldo2, y);          // pre-activation u (training)
 #pragma unroll
         for (int i = 0; i < 16; ++i) y[i] = gelu_erf(y[i]);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
-        const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;
-        bf16x8 u0 = *(const bf16x8*)u, u1 = *(const bf16x8*)(u + 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { y[i] *= dgelu_erf((float)u0[i]); y[8 + i] *= dgelu_erf((float)u1[i]); }
+        for (int i = 0; i < 16; ++i) y[i] *= dgelu_erf((float)a.u[mt][i >> 3][i & 7]);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DRELU_BF16) {
-        const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;   // post-ReLU activation
-        bf16x8 u0 = *(const bf16x8*)u, u1 = *(const bf16x8*)(u + 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { y[i] = (float)u0[i] > 0.f ? y[i] : 0.f; y[8 + i] = (float)u1[i] > 0.f ? y[8 + i] : 0.f; }
+        for (int i = 0; i < 16; ++i) y[i] = (float)a.u[mt][i >> 3][i & 7] > 0.f ? y[i] : 0.f;
         store_bf16(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_PATCH_F32) {
-        // input row m = f*grp_in + q  ->  token row f*grp_out + q + grp_off ; + pos[q + grp_off][n]
-        int f = m / p.grp_in, q = m - f * p.grp_in;
-        const float* pos = (const float*)p.aux + (size_t)(q + p.grp_off) * p.ldaux + n;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 t = *(const f32x4*)(pos + 4 * i);
-            y[4 * i] += t[0]; y[4 * i + 1] += t[1]; y[4 * i + 2] += t[2]; y[4 * i + 3] += t[3];
-        }
-        store_f32(p.out, p.ldo, (size_t)f * p.grp_out + q + p.grp_off, y);
     }
 }
 
@@ -191,6 +203,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     }
 
     // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*64 + 16 g + (4 nt + r)
+    float bias[16];
+    EpiAux aux;
+    epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         int m = m0 + wr * 64 + mt * 16 + li;
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-        epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v);
+        epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v, bias, aux, mt);
     }
 }
 
