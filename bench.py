@@ -48,8 +48,10 @@ def build(dev, B, T, C, lr):
 
 def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world):
     from sais_amd.loss import calcNCELoss
+    from sais_amd.loss import label_columns
     names = [f"v_{i}" for i in range(B)]
     lens = [T] * B
+    labels = label_columns(labels, protos, frames.device)       # static device tensor (graph-capturable)
 
     def step():
         opt.zero_grad()
@@ -121,6 +123,8 @@ def main():
     ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the ~700 launches of a step eagerly instead of "
+                                                              "replaying the captured hipGraph (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,6 +155,11 @@ def main():
     vit.grad_ready_hook = sync.vit_hook(vit)
     model.grad_ready_hook = sync.temporal_hook(model, T)
 
+    eager_step = step
+    use_graph = world == 1 and not args.no_graph
+    if use_graph:                                            # DP runs eagerly (RCCL collectives from hooks)
+        from sais_amd.graph import GraphedStep
+        step = GraphedStep(eager_step, warmup=2)
     for _ in range(args.warmup):
         loss = step()
 
@@ -176,7 +185,7 @@ def main():
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
         for _ in range(2):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         summ = ops.TIMER.summary()
         ops.TIMER = None
@@ -203,7 +212,7 @@ def main():
             "config": {"workload": f"BASELINE config 2: ViT-S/16 + 4-layer temporal encoder + SupCon prototype loss, "
                                    f"fwd+bwd+SGD, {B} clips x {T} frames x 224x224 per GPU (global {world * B} clips), "
                                    f"random-init weights, RGB stream", "clips_per_gpu": B, "frames_per_clip": T,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager"},
             "step_tflops": round(step_flops * world * args.steps / dt / 1e12, 1),
             "frac_of_mfma_roofline": round(step_flops * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "loss": round(float(loss.detach()), 6),

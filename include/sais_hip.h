@@ -63,7 +63,9 @@ int sais_gemm_nt(const SaisGemm* g, void* stream);
  * split hi/lo into two bf16 and three MFMA products are accumulated ("bf16x3").  Epilogues:
  * SAIS_EPI_BIAS_F32, _BIAS_RESID_F32 (aux f32), _BIAS_RELU_F32, _DRELU_F32 (aux f32).  This is what the
  * temporal TransformerEncoder's nn.Linear layers run on (prepare_model.py:74-81, called at :213): its
- * activations feed the <=1e-3 logit parity bar directly and are tiny.                            */
+ * activations feed the <=1e-3 logit parity bar directly and are tiny.
+ * Optional split-K for these few-row problems: out2 = caller workspace f32 [ldo2][M][N], ldo2 = number of K
+ * splits (must divide K/64); partial sums land there and a second tiny kernel reduces + applies the epilogue. */
 int sais_gemm_nt_f32(const SaisGemm* g, void* stream);
 
 /* dW[N1,N2] += P[M,N1]^T . Q[M,N2]  and (db != NULL)  db[N1] += column sums of P.

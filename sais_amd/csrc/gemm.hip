@@ -229,6 +229,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 template <int EPI>
 DEVINL void epilogue_f32(const NtParams& p, int m, int n, const float (&v)[16]) {
     float y[16];
+    if (p.grp_in > 1) {
+        // split-K: raw partial sums go to the workspace slab of this split; splitk_reduce_kernel applies the epilogue
+        float* o = (float*)p.out2 + ((size_t)blockIdx.z * p.M + m) * p.N + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(o + 4 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) y[i] = v[i] + (p.bias ? p.bias[n + i] : 0.f);
     if constexpr (EPI == SAIS_EPI_BIAS_RELU_F32) {
@@ -300,13 +307,15 @@ __global__ __launch_bounds__(256) void gemm_nt_f32x3_kernel(NtParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    const int nk = p.K / BK;
-    gload(0);
+    // split-K: grp_in = number of K splits (gridDim.z); this workgroup owns K-tiles [kbeg, kbeg + nk)
+    const int nk = p.K / BK / (p.grp_in > 1 ? p.grp_in : 1);
+    const int kbeg = blockIdx.z * nk;
+    gload(kbeg * BK);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                       // previous tile fully consumed
         lstore();
         __syncthreads();
-        if (kt + 1 < nk) gload((kt + 1) * BK);
+        if (kt + 1 < nk) gload((kbeg + kt + 1) * BK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 ah[4], al[4], bh[4], bl[4];
@@ -495,6 +504,37 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     return sais_check_launch();
 }
 
+// out[m][n] = epilogue( sum_z ws[z][m][n] + bias[n] , aux[m][n] )  — second half of the split-K fp32 GEMM
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int ks, int M, int N, const float* bias,
+                                                            const float* aux, int ldaux, float* out, int ldo) {
+    const int n4 = N >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)M * n4; i += (long)gridDim.x * 256) {
+        const int m = i / n4, n = (i - (long)m * n4) * 4;
+        f32x4 y = *(const f32x4*)(ws + (size_t)m * N + n);
+        for (int z = 1; z < ks; ++z) y += *(const f32x4*)(ws + ((size_t)z * M + m) * N + n);
+        if (bias) y += *(const f32x4*)(bias + n);
+        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) y += *(const f32x4*)(aux + (size_t)m * ldaux + n);
+        if constexpr (EPI == SAIS_EPI_BIAS_RELU_F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+        }
+        if constexpr (EPI == SAIS_EPI_DRELU_F32) {
+            const f32x4 u = *(const f32x4*)(aux + (size_t)m * ldaux + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = u[j] > 0.f ? y[j] : 0.f;
+        }
+        *(f32x4*)(out + (size_t)m * ldo + n) = y;
+    }
+}
+
+#define LAUNCH_RED(E)                                                                                             \
+    case E:                                                                                                       \
+        hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream,              \
+                           (const float*)g->out2, ks, g->M, g->N, g->bias, (const float*)g->aux, g->ldaux,        \
+                           (float*)g->out, g->ldo);                                                               \
+        break;
+
 #define LAUNCH_NT32(E)                                                                            \
     case E:                                                                                       \
         hipLaunchKernelGGL(gemm_nt_f32x3_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
@@ -505,14 +545,34 @@ extern "C" int sais_gemm_nt_f32(const SaisGemm* g, void* stream) {
     if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
     if (g->M <= 0 || g->N % BN || g->K % BK || g->lda % 4 || g->ldb % 4 || g->ldo % 4) return SAIS_ERR_ARG;
     NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
-               g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off};
+               g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, 1, 0, 0};
     dim3 grid(g->N / BN, (g->M + BM - 1) / BM);
+    // Few output tiles (M = clips*(T+1) rows): split K over gridDim.z into the caller's workspace (out2 = f32
+    // [ldo2][M][N], ldo2 = number of splits) and finish with a tiny reduce+epilogue kernel, so that dozens of CUs
+    // work instead of <= 9 and the exposed per-K-tile load latency is paid K/64/ks times instead of K/64.
+    int ks = 1;
+    if (g->out2 && g->ldo2 > 1) {
+        ks = g->ldo2;
+        if ((g->K / BK) % ks) return SAIS_ERR_ARG;
+        p.grp_in = ks;
+        grid.z = ks;
+    }
     switch (g->epilogue) {
         LAUNCH_NT32(SAIS_EPI_BIAS_F32)
         LAUNCH_NT32(SAIS_EPI_BIAS_RESID_F32)
         LAUNCH_NT32(SAIS_EPI_BIAS_RELU_F32)
         LAUNCH_NT32(SAIS_EPI_DRELU_F32)
         default: return SAIS_ERR_ARG;
+    }
+    if (ks > 1) {
+        long n = (long)g->M * (g->N / 4);
+        int rgrid = (int)((n + 255) / 256);
+        switch (g->epilogue) {
+            LAUNCH_RED(SAIS_EPI_BIAS_F32)
+            LAUNCH_RED(SAIS_EPI_BIAS_RESID_F32)
+            LAUNCH_RED(SAIS_EPI_BIAS_RELU_F32)
+            LAUNCH_RED(SAIS_EPI_DRELU_F32)
+        }
     }
     return sais_check_launch();
 }

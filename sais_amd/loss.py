@@ -14,6 +14,12 @@ def _stack(prototypes):
     return torch.cat([prototypes[k].reshape(1, -1) for k in keys], dim=0).float().contiguous(), keys
 
 
+def label_columns(labels, gesture_prototypes, device):
+    """int32 device tensor of prototype column indices for `labels` (pass it to calcNCELoss as `labels` to keep the
+    call free of host-side work, e.g. inside a captured hipGraph)."""
+    return _label_cols(labels, list(gesture_prototypes.keys()), device)
+
+
 def _label_cols(labels, keys, device):
     # column of the prototype whose key == str(label)  (prepare_miscellaneous.py:31-37)
     cols = [keys.index(str(int(l))) for l in (labels.tolist() if torch.is_tensor(labels) else labels)]
@@ -45,7 +51,10 @@ def calcNCELoss(rank, snip_sequence, labels, videoname, gesture_prototypes, doma
     if not snip_sequence.is_cuda:
         raise L.SaisHipError("calcNCELoss needs device tensors: the HIP path has no CPU fallback")
     keys = list(gesture_prototypes.keys())
-    cols = _label_cols(labels, keys, snip_sequence.device)
+    if torch.is_tensor(labels) and labels.is_cuda and labels.dtype == torch.int32:
+        cols = labels          # already prototype COLUMN indices on the device (no host work: graph-capturable)
+    else:
+        cols = _label_cols(labels, keys, snip_sequence.device)
     return _NCEFn.apply(snip_sequence, cols, *[gesture_prototypes[k] for k in keys])
 
 

@@ -85,8 +85,18 @@ def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None):
     _chk(a, F32, "A"); _chk(w, F32, "B"); _chk(bias, F32, "bias"); _chk(out, F32, "out"); _chk(aux, F32, "aux")
     M = a.shape[0] if M is None else M
     N, K = w.shape
+    # few output tiles: split K so that ~48+ workgroups run (workspace from the caching allocator)
+    tiles, nk, ks, ws = (N // 128) * ((M + 127) // 128), K // 64, 1, None
+    if tiles < 48:
+        for cand in (8, 6, 4, 3, 2):
+            if nk % cand == 0 and nk // cand >= 1 and tiles * cand <= 256:
+                ks = cand
+                break
+    if ks > 1:
+        ws = torch.empty(ks, M, N, dtype=F32, device=a.device)
     g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
-                   _p(out), out.stride(-2), None, 0, _p(aux), 0 if aux is None else aux.stride(-2), 0, 0, 0)
+                   _p(out), out.stride(-2), _p(ws), ks if ws is not None else 0, _p(aux),
+                   0 if aux is None else aux.stride(-2), 0, 0, 0)
     _timed(f"gemm_nt_f32x3<{_NT_NAMES[epilogue]}>", 2.0 * M * N * K, 4 * (M * K + N * K + M * N),
            lambda: L.call("sais_gemm_nt_f32", ctypes.byref(g), _stream()))
     return out
