@@ -73,7 +73,18 @@ int sais_gemm_nt_f32(const SaisGemm* g, void* stream);
  * atomics into dW/db (caller zeroes them: optimizer.zero_grad(), perform_training.py:155).        */
 int sais_gemm_tn(const void* P, int ldp, const void* Q, int ldq, int M, int N1, int N2,
                  float* dW, int ldw, float* db, int nsplit, void* stream);
-/* same with f32 P and Q (rounded to bf16 while staging; f32 accumulation) */
+/* Several weight-gradient GEMMs over the same M rows in ONE launch (all bf16): the four nn.Linear of a ViT
+ * block give 108 output tiles, so a few M-splits fill the chip and the atomic traffic shrinks accordingly. */
+#define SAIS_TN_MAX_ITEMS 8
+typedef struct SaisTnItem {
+    const void* P; int ldp;        /* bf16 [M,N1]  (dY)  */
+    const void* Q; int ldq;        /* bf16 [M,N2]  (X)   */
+    int N1, N2;
+    float* dW; int ldw;            /* f32 [N1,N2], accumulated */
+    float* db;                     /* f32 [N1] or NULL         */
+} SaisTnItem;
+int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream);
+/* same as sais_gemm_tn with f32 P and Q (rounded to bf16 while staging; f32 accumulation) */
 int sais_gemm_tn_f32(const void* P, int ldp, const void* Q, int ldq, int M, int N1, int N2,
                      float* dW, int ldw, float* db, int nsplit, void* stream);
 

@@ -23,6 +23,11 @@ class SaisGemm(ctypes.Structure):
                 ("grp_in", c_int), ("grp_out", c_int), ("grp_off", c_int)]
 
 
+class SaisTnItem(ctypes.Structure):
+    _fields_ = [("P", c_void_p), ("ldp", c_int), ("Q", c_void_p), ("ldq", c_int), ("N1", c_int), ("N2", c_int),
+                ("dW", c_void_p), ("ldw", c_int), ("db", c_void_p)]
+
+
 EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
 EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
@@ -34,6 +39,7 @@ SIGNATURES = {
     "sais_gemm_nt_f32": [ctypes.POINTER(SaisGemm), c_void_p],
     "sais_gemm_tn_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_transpose_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "sais_gemm_tn_grouped": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p],
     "sais_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_layernorm_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p,
                            c_long, c_void_p, c_void_p, c_void_p],

@@ -377,21 +377,11 @@ DEVINL u32x4 load8_bf16(const float* p) {
     return __builtin_bit_cast(u32x4, v);
 }
 
+// one 128x128 output tile over rows [mbeg, mend) of P / Q
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TTILE];   // 72 KiB
+DEVINL void tn_tile(const TnParams& p, int n1_0, int n2_0, int mbeg, int mend, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
-    // 1-D grid, XCD-aware order with the M-split as the slow index: the (N1/128)*(N2/128) tiles of one split
-    // run on ONE XCD back to back and share that split's P and Q row slabs through its L2 (the slabs are then
-    // fetched from HBM once instead of once per tile).
-    const int nt2 = p.N2 / 128, ntile = (p.N1 / 128) * nt2;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = wg / ntile, t12 = wg - split * ntile;
-    const int n2_0 = (t12 % nt2) * 128, n1_0 = (t12 / nt2) * 128;
-    const int mbeg = split * p.rows_per_split;
-    const int mend = min(p.M, mbeg + p.rows_per_split);
-    if (mbeg >= mend) return;
 
     // staging: tile = 64 rows x 128 cols bf16 = 64 x 16 chunks; thread -> chunk tid&15, rows tid>>4 + 16 i
     const int sc = tid & 15, sr = tid >> 4;
@@ -474,6 +464,129 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
             for (int jt = 0; jt < 4; ++jt) atomicAdd(row + jt * 16, acc[it][jt][r]);
             if (do_bias && li == 0) atomicAdd(p.db + n1, accb[it][r]);
         }
+}
+
+// LDS-DMA variant of tn_tile for bf16 operands when every M-split is a whole number of 64-row steps:
+// unpadded 256-B rows, 32-B units XOR-swizzled by (row & 7) on the SOURCE address (a half-wave's transposed read
+// touches 8 consecutive rows x 32 B -> 8 distinct units = all 64 banks), two 32-KiB stages.
+DEVINL const char* tr_addr(const char* tile, int row, int col) {       // col multiple of 4
+    return tile + row * 256 + ((((col >> 4) ^ (row & 7)) << 5) | ((col & 15) << 1));
+}
+
+DEVINL void tn_tile_dma(const TnParams& p, int n1_0, int n2_0, int mbeg, int mend, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
+    constexpr int T16 = 64 * 256;                                       // 16 KiB per operand per stage
+    // pieces 4w..4w+3 of each operand: piece = 4 rows; lane -> row 4*piece + (lane>>4), position lane&15
+    const bf16* psrc[4]; const bf16* qsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 4 * (4 * wid + j) + (lane >> 4);
+        const int c = lane & 15, u = (c >> 1) ^ (r & 7);
+        psrc[j] = (const bf16*)p.P + (size_t)(mbeg + r) * p.ldp + n1_0 + u * 16 + (c & 1) * 8;
+        qsrc[j] = (const bf16*)p.Q + (size_t)(mbeg + r) * p.ldq + n2_0 + u * 16 + (c & 1) * 8;
+    }
+    auto issue = [&](int stage, int step) {
+        char* s = smem + stage * 2 * T16 + (4 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            glds16(psrc[j] + (size_t)step * 64 * p.ldp, s + j * 1024);
+            glds16(qsrc[j] + (size_t)step * 64 * p.ldq, s + T16 + j * 1024);
+        }
+    };
+    f32x4 acc[4][4];
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    }
+    const bool do_bias = p.db != nullptr && n2_0 == 0 && wc == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+    const int q4 = li >> 2, p4 = li & 3;
+    const int nsteps = (mend - mbeg) / TK;
+    issue(0, 0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps) issue(cur ^ 1, st + 1);
+        const char* sp = smem + cur * 2 * T16;
+        const char* sq = sp + T16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fp[4], fq[4];
+            const int row = ks * 32 + 4 * g + q4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int cp = wr * 64 + t * 16 + 4 * p4, cq = wc * 64 + t * 16 + 4 * p4;
+                fp[t] = cat4(lds_read_tr16(tr_addr(sp, row, cp)), lds_read_tr16(tr_addr(sp, row + 16, cp)));
+                fq[t] = cat4(lds_read_tr16(tr_addr(sq, row, cq)), lds_read_tr16(tr_addr(sq, row + 16, cq)));
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma16(fp[it], fq[jt], acc[it][jt]);
+            if (do_bias) {
+#pragma unroll
+                for (int it = 0; it < 4; ++it) accb[it] = mfma16(fp[it], ones, accb[it]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int n1 = n1_0 + wr * 64 + it * 16 + 4 * g + r;
+            float* row = p.dW + (size_t)n1 * p.ldw + n2_0 + wc * 64 + li;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) atomicAdd(row + jt * 16, acc[it][jt][r]);
+            if (do_bias && li == 0) atomicAdd(p.db + n1, accb[it][r]);
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TTILE];   // 72 KiB
+    // 1-D grid, XCD-aware order with the M-split as the slow index: the (N1/128)*(N2/128) tiles of one split
+    // run on ONE XCD back to back and share that split's P and Q row slabs through its L2 (the slabs are then
+    // fetched from HBM once instead of once per tile).
+    const int nt2 = p.N2 / 128, ntile = (p.N1 / 128) * nt2;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / ntile, t12 = wg - split * ntile;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    if (mbeg >= mend) return;
+    tn_tile<T>(p, (t12 / nt2) * 128, (t12 % nt2) * 128, mbeg, mend, smem);
+}
+
+// Several weight-gradient GEMMs over the SAME M rows in one launch (the four nn.Linear of a ViT block): 108 tiles
+// instead of 9-36, so 4 M-splits fill the chip where the per-GEMM launches needed 12-48, and the fp32 atomic
+// traffic (64 KiB per workgroup) drops by the same factor.
+struct TnGroup {
+    TnParams item[SAIS_TN_MAX_ITEMS];
+    int tile_end[SAIS_TN_MAX_ITEMS];          // prefix sums of tiles per item
+    int nitems, ntiles;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup gp) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TTILE];
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / gp.ntiles;
+    int t = wg - split * gp.ntiles, it = 0;
+    while (it + 1 < gp.nitems && t >= gp.tile_end[it]) ++it;
+    if (it > 0) t -= gp.tile_end[it - 1];
+    const TnParams& p = gp.item[it];
+    const int nt2 = p.N2 / 128;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    if (mbeg >= mend) return;
+    if ((mend - mbeg) % TK == 0) tn_tile_dma(p, (t / nt2) * 128, (t % nt2) * 128, mbeg, mend, smem);
+    else tn_tile<bf16>(p, (t / nt2) * 128, (t % nt2) * 128, mbeg, mend, smem);
 }
 
 }  // namespace
@@ -587,6 +700,27 @@ static int launch_tn(const void* P, int ldp, const void* Q, int ldq, int M, int 
     dim3 grid((N2 / 128) * (N1 / 128) * ns);
     if (f32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    return sais_check_launch();
+}
+
+extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream) {
+    SAIS_ENTER();
+    if (!items || nitems <= 0 || nitems > SAIS_TN_MAX_ITEMS || M <= 0 || nsplit <= 0) return SAIS_ERR_ARG;
+    int rows = (M + nsplit - 1) / nsplit;
+    rows = (rows + TK - 1) / TK * TK;
+    const int ns = (M + rows - 1) / rows;
+    TnGroup gp;
+    gp.nitems = nitems;
+    int total = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const SaisTnItem& t = items[i];
+        if (!t.P || !t.Q || !t.dW || t.N1 % 128 || t.N2 % 128 || t.ldp % 8 || t.ldq % 8) return SAIS_ERR_ARG;
+        gp.item[i] = TnParams{t.P, t.Q, t.ldp, t.ldq, M, t.N1, t.N2, t.dW, t.ldw, t.db, rows};
+        total += (t.N1 / 128) * (t.N2 / 128);
+        gp.tile_end[i] = total;
+    }
+    gp.ntiles = total;
+    hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total * ns), dim3(256), 0, (hipStream_t)stream, gp);
     return sais_check_launch();
 }
 

@@ -118,6 +118,22 @@ def gemm_tn(p, q, dW, db=None, nsplit=None):
                           N2, _p(dW), dW.stride(0), _p(db), nsplit, _stream()))
 
 
+def gemm_tn_grouped(items, M, nsplit=None):
+    """items: list of (p bf16[M,N1], q bf16[M,N2], dW f32[N1,N2], db f32[N1] | None); all accumulate (+=)."""
+    arr = (L.SaisTnItem * len(items))()
+    tiles, flops, nbytes = 0, 0.0, 0
+    for i, (p, q, dW, db) in enumerate(items):
+        _chk(p, BF16, "P"); _chk(q, BF16, "Q"); _chk(dW, F32, "dW"); _chk(db, F32, "db")
+        N1, N2 = p.shape[1], q.shape[1]
+        arr[i] = L.SaisTnItem(_p(p), p.stride(0), _p(q), q.stride(0), N1, N2, _p(dW), dW.stride(0), _p(db))
+        tiles += (N1 // 128) * (N2 // 128)
+        flops += 2.0 * M * N1 * N2
+        nbytes += 2 * M * (N1 + N2) + 4 * N1 * N2
+    if nsplit is None:
+        nsplit = max(1, min((M + 255) // 256, (432 + tiles - 1) // tiles))
+    _timed("gemm_tn_grouped", flops, nbytes, lambda: L.call("sais_gemm_tn_grouped", arr, len(items), M, nsplit, _stream()))
+
+
 def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None, rstd=None, ldy16=384, ldy32=384):
     _chk(x, F32, "x"); _chk(y16, BF16, "y16"); _chk(y32, F32, "y32")
     L.call("sais_layernorm_fwd", _p(x), ldx, rows, 384, _p(gamma), _p(beta), eps, _p(y16), ldy16, _p(y32), ldy32,

@@ -243,26 +243,32 @@ class VisionTransformer(nn.Module):
         ops.cast_bf16(dx, dx16)
         du, dxn, dao, dqkv = e16(M, HID), e16(M, D), e16(M, D), e16(M, 3 * D)
         delta = torch.empty(Fr, HEADS, NTOK, dtype=torch.float32, device=dev)
+        # three rotating bf16 copies of the gradient stream: the weight-gradient GEMMs of a block are issued together at
+        # its end (one grouped launch) and need dx as it was at the MLP stage (dxa) AND at the attention stage (dxb)
+        dxa, dxb, dxc = dx16, e16(M, D), e16(M, D)
         if self.grad_ready_hook:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
         for i in reversed(range(self.depth)):
             p = f"blocks.{i}."
             s = saved["blocks"][i]
             # MLP branch
-            ops.gemm_nt(dx16, f.wt16[p + "mlp.fc2.weight"], L.EPI_DGELU_BF16, du, aux=s["u"])
-            ops.gemm_tn(dx16, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias"))
+            ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_DGELU_BF16, du, aux=s["u"])
             ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
-            ops.gemm_tn(du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias"))
             ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
-                              dx32=dx, dx16=dx16, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))
+                              dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))
             # attention branch
-            ops.gemm_nt(dx16, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
-            ops.gemm_tn(dx16, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias"))
+            ops.gemm_nt(dxb, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
             ops.vit_attn_bwd(s["qkv"], dao, s["lse"], delta, Fr, dqkv)
             ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn)
-            ops.gemm_tn(dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))
+            # all four weight / bias gradients of the block in one launch (108 output tiles)
+            ops.gemm_tn_grouped([
+                (dxa, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
+                (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
+                (dxb, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias")),
+                (dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
             ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,
-                              dx32=dx, dx16=dx16, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
+                              dx32=dx, dx16=dxc, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
+            dxa, dxc = dxc, dxa
             saved["blocks"][i] = None
             if self.grad_ready_hook:
                 self.grad_ready_hook(*self.block_grad_range(i))

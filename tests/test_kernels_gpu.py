@@ -358,3 +358,21 @@ def test_nce_loss_and_grads(ops, B, C):
     assert abs(loss.item() - ref.item()) < 1e-6
     assert_close(demb, e.grad, atol=1e-7)
     assert_close(dpro, torch.cat([pd[str(c)].grad for c in range(C)]), atol=1e-7)
+
+
+def test_gemm_tn_grouped_matches_individual(ops):
+    """The four weight-gradient GEMMs of a ViT block in one launch == four separate launches."""
+    M = 197 * 16
+    shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]
+    items, refs = [], []
+    for i, (n1, n2) in enumerate(shapes):
+        p = rnd(M, n1, seed=100 + i, dtype=torch.bfloat16)
+        q = rnd(M, n2, seed=110 + i, dtype=torch.bfloat16)
+        dW, db = torch.zeros(n1, n2, device=DEV), torch.zeros(n1, device=DEV)
+        items.append((p, q, dW, db if i != 2 else None))
+        refs.append((p.float().t() @ q.float(), p.float().sum(0)))
+    ops.gemm_tn_grouped(items, M)
+    for (p, q, dW, db), (rw, rb) in zip(items, refs):
+        assert_close(dW, rw, atol=2e-3 * math.sqrt(M), rtol=1e-4)
+        if db is not None:
+            assert_close(db, rb, atol=1e-3 * math.sqrt(M))
