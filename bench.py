@@ -192,8 +192,12 @@ def main():
         kern = max(summ, key=lambda k: summ[k]["total_ms"])
         k = summ[kern]
         ach = k["flops"] / (k["avg_ms"] * 1e-3) / 1e12
+        pmc = load_pmc_traffic(kern)
         roof = dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=load_pmc_traffic(kern),
+                    frac=round(ach / MFMA_PEAK_TFLOPS, 4),
+                    traffic=(pmc or {}).get("hbm_bytes_per_launch"),      # PMC (profiles/pmc_traffic.json), bytes/launch
+                    algorithmic_bytes=int(k["bytes"]),
+                    hbm_gbps_algorithmic=round(k["bytes"] / (k["avg_ms"] * 1e-3) / 1e9, 1),
                     avg_launch_us=round(k["avg_ms"] * 1e3, 1), launches_per_step=k["launches"] // 2,
                     all_kernels={n: dict(ms_per_step=round(v["total_ms"] / 2, 3),
                                          tflops=round(v["flops"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
