@@ -12,6 +12,7 @@
 // Operands are swapped in the MFMA (weights as "A", activations as "B") and weight rows are permuted
 // while staging so that every lane ends up with 16 CONTIGUOUS output columns of one output row:
 // epilogue stores are 32-B (bf16) / 64-B (fp32) per lane, a full 128-B line per row per wave.
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/sais_hip.h"
 
@@ -596,10 +597,20 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup gp) {
         hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
         break;
 
+extern "C" int sais_gemm_nt_ws_(const SaisGemm* g, void* stream);       // gemm_ws.hip: wave-specialised, persistent
+
 extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     SAIS_ENTER();
     if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
     if (g->M <= 0 || g->N % BN || g->K % BK || g->lda % 8 || g->ldb % 8 || g->ldo % 8) return SAIS_ERR_ARG;
+    // The wave-specialised persistent kernel (gemm_ws.hip) is correct but, as measured in round 1, not yet faster
+    // than the 128x128 kernel below (its consumers stall ~7.8k cycles per tile issuing the epilogue stores): it is
+    // opt-in (SAIS_GEMM_WS=1) until the store hand-off to the idle loader waves lands.
+    static const bool use_ws = [] { const char* e = getenv("SAIS_GEMM_WS"); return e && e[0] == '1'; }();
+    if (use_ws && g->M >= 8192) {
+        int rc = sais_gemm_nt_ws_(g, stream);
+        return rc ? rc : sais_check_launch();
+    }
     NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
                g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off};
     dim3 grid((g->N / BN) * ((g->M + BM - 1) / BM));

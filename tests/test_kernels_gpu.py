@@ -376,3 +376,26 @@ def test_gemm_tn_grouped_matches_individual(ops):
         assert_close(dW, rw, atol=2e-3 * math.sqrt(M), rtol=1e-4)
         if db is not None:
             assert_close(db, rb, atol=1e-3 * math.sqrt(M))
+
+
+def test_gemm_nt_wave_specialised_variant_matches(ops):
+    """The opt-in persistent loader/consumer GEMM (SAIS_GEMM_WS=1, gemm_ws.hip) against the default kernel."""
+    import ctypes
+    from sais_amd import _lib as L
+    lib = L.load()
+    lib.sais_gemm_nt_ws_.argtypes = [ctypes.POINTER(L.SaisGemm), ctypes.c_void_p]
+    lib.sais_gemm_nt_ws_.restype = ctypes.c_int
+    M, N, K = 197 * 64, 384, 1152
+    a = rnd(M, K, seed=120, dtype=torch.bfloat16)
+    w = rnd(N, K, seed=121, scale=0.05, dtype=torch.bfloat16)
+    bias, res = rnd(N, seed=122), rnd(M, N, seed=123)
+    for epi, f32 in ((L.EPI_BIAS_BF16, False), (L.EPI_BIAS_RESID_F32, True), (L.EPI_BIAS_GELU_BF16, False)):
+        dt = torch.float32 if f32 else torch.bfloat16
+        ref, out = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=dt, device=DEV)
+        aux = res if f32 else None
+        ops.gemm_nt(a, w, epi, ref, bias=bias, aux=aux)
+        g = L.SaisGemm(a.data_ptr(), K, w.data_ptr(), K, M, N, K, epi, bias.data_ptr(), out.data_ptr(), N, None, 0,
+                       None if aux is None else aux.data_ptr(), N if aux is not None else 0, 0, 0, 0)
+        assert lib.sais_gemm_nt_ws_(ctypes.byref(g), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        torch.cuda.synchronize()
+        assert_close(out, ref, atol=1e-2 if not f32 else 1e-3, rtol=1e-2, name=f"ws epi {epi}")
