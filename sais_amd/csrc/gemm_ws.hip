@@ -17,8 +17,18 @@
 namespace {
 constexpr int BM = 256, BN = 128, BK = 64;
 constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;   // 32 + 16 KiB
-constexpr int NSTAGE = 3;
 constexpr int PPW = 12;                         // LDS-DMA pieces per loader wave per K-tile (8 of A, 4 of B)
+constexpr int STG_BYTES = BM * BN * 2;          // bf16 output staging of one tile (hand-off variant): 64 KiB
+
+// Store hand-off (bf16-output epilogues).  Measured: the consumers spent ~7.8k cycles per tile issuing their 16
+// epilogue stores (HBM-write back-pressure) with the matrix pipe idle, while each loader wave idled 1-2k cycles per
+// K-tile at the barrier.  So the consumers only finish the arithmetic and drop the bf16 tile into an LDS staging
+// buffer (chunk index XOR row: conflict-free both ways); the LOADERS write it to HBM as whole 256-B row segments,
+// a few per K-tile of the NEXT tile, behind their LDS-DMA issue (the counted vmcnt leaves exactly those stores in
+// flight).  For the GELU epilogue the loaders also evaluate GELU on the staged pre-activation and write both
+// tensors.  LDS: 2-stage ring (96 KiB) + staging (64 KiB) = 160 KiB.
+template <bool HANDOFF> struct Cfg { static constexpr int NSTAGE = HANDOFF ? 2 : 3; };
+DEVINL int stg_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
 
 struct NtParams {
     const bf16* A; const bf16* B;
@@ -108,9 +118,11 @@ DEVINL void epilogue_row(const NtParams& p, int m, int n, float (&y)[32], const 
     }
 }
 
-template <int EPI>
+template <int EPI, bool HANDOFF>
 __global__ __launch_bounds__(512) void gemm_nt_ws_kernel(NtParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // NSTAGE * 48 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // ring (NSTAGE * 48 KiB) [+ 64 KiB staging]
+    constexpr int NSTAGE = Cfg<HANDOFF>::NSTAGE;
+    char* const stg = smem + NSTAGE * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);         // 0..3 consumers, 4..7 loaders
     const int nk = p.K / BK;
@@ -152,13 +164,73 @@ __global__ __launch_bounds__(512) void gemm_nt_ws_kernel(NtParams p) {
             istage = istage == NSTAGE - 1 ? 0 : istage + 1;
         };
         int issued = 0;
-        for (; issued < 2 && issued < total; ++issued) issue_next();
-        for (int q = 0; q < total; ++q) {
-            // my pieces of K-tile q have landed (those of q+1 may still be in flight)
-            if (q + 1 < issued) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                             // consumers are done with K-tile q-1
-            if (issued < total) { issue_next(); ++issued; }           // refill its stage with K-tile q+2
+        for (; issued < NSTAGE - 1 && issued < total; ++issued) issue_next();
+        if constexpr (!HANDOFF) {
+            for (int q = 0; q < total; ++q) {
+                // my pieces of K-tile q have landed (those of q+1 may still be in flight)
+                if (q + 1 < issued) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                         // consumers are done with K-tile q-1
+                if (issued < total) { issue_next(); ++issued; }       // refill its stage with K-tile q+2
+            }
+        } else {
+            // one K-tile ahead + store job of the previous tile spread over the K-tiles of the current one
+            const int Q = nk > 16 ? 1 : (nk > 8 ? 2 : (nk > 4 ? 4 : 16)); // chunk rounds per K-tile: Q (nk-1) >= 16
+            const int srow = lw * 64 + (lane >> 4), schk = lane & 15;  // round c: row srow + 4 c, 16-B chunk schk
+            int done = 16, m0s = 0, n0s = 0, prev_st = 0, kt = 0, ti = 0;
+            auto store_rounds = [&](int nrounds) {
+                int n = 0;
+                for (int c = done; c < done + nrounds; ++c) {
+                    const int row = srow + 4 * c, m = m0s + row;
+                    const bf16x8 v = *(const bf16x8*)(stg + stg_off(row, schk));
+                    if (m < p.M) {
+                        if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
+                            if (p.out2) *(bf16x8*)((bf16*)p.out2 + (size_t)m * p.ldo2 + n0s + 8 * schk) = v;
+                            bf16x8 h;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) h[e] = (bf16)gelu_erf((float)v[e]);
+                            *(bf16x8*)((bf16*)p.out + (size_t)m * p.ldo + n0s + 8 * schk) = h;
+                        } else {
+                            *(bf16x8*)((bf16*)p.out + (size_t)m * p.ldo + n0s + 8 * schk) = v;
+                        }
+                    }
+                    ++n;
+                }
+                done += nrounds;
+                return n;
+            };
+            const int per_round = (EPI == SAIS_EPI_BIAS_GELU_BF16 && p.out2) ? 2 : 1;
+            for (int q = 0; q < total; ++q) {
+                // K-tile q landed; the (at most 8) stores issued after its DMA may stay in flight
+                switch (prev_st) {
+                    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                }
+                __builtin_amdgcn_s_barrier();                         // consumers done with K-tile q-1 (+ staging of the
+                if (issued < total) { issue_next(); ++issued; }       //   previous tile complete when kt == 0)
+                if (kt == 0 && ti > 0) {                              // previous tile's output is staged: new store job
+                    const int tile = first + (ti - 1) * G;
+                    m0s = (tile / p.ntn) * BM; n0s = (tile % p.ntn) * BN; done = 0;
+                }
+                prev_st = 0;
+                if (done < 16 && kt < nk - 1) {                       // never in the tile's last K-tile: the consumers
+                    const int r = (16 - done) < Q ? (16 - done) : Q;  //   overwrite the staging right after it
+                    prev_st = store_rounds(r) * per_round;
+                    if (prev_st == 3 || (prev_st > 4 && prev_st != 8)) prev_st = 0;   // unreachable with Q in {1,2,4}
+                    if (m0s + BM > p.M) prev_st = 0;      // ragged last panel: some store instructions may be fully masked
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                if (++kt == nk) { kt = 0; ++ti; }
+            }
+            __builtin_amdgcn_s_barrier();                             // last tile staged
+            if (cnt > 0) {
+                const int tile = first + (cnt - 1) * G;
+                m0s = (tile / p.ntn) * BM; n0s = (tile % p.ntn) * BN; done = 0;
+                store_rounds(16);
+            }
         }
         return;
     }
@@ -208,29 +280,66 @@ __global__ __launch_bounds__(512) void gemm_nt_ws_kernel(NtParams p) {
 #pragma unroll
             for (int c = 0; c < 32; ++c) bias[c] = 0.f;
         }
+        if constexpr (HANDOFF) {
+            // arithmetic only; the bf16 row segment (32 columns = 4 chunks) goes to the staging buffer
+            bf16x8 uaux[4][4];
+            if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wid * 64 + mt * 16 + li;
-            if (m >= p.M) continue;
-            float y[32];
+                for (int mt = 0; mt < 4; ++mt) {
+                    int m = m0 + wid * 64 + mt * 16 + li;
+                    m = m < p.M ? m : p.M - 1;
+                    const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
+                    for (int c = 0; c < 4; ++c) uaux[mt][c] = *(const bf16x8*)(u + 8 * c);
+                }
+            }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[4 * nt + r] = acc[mt][nt][r];
-            epilogue_row<EPI>(p, m, n, y, bias);
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wid * 64 + mt * 16 + li;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float y = acc[mt][2 * c + (e >> 2)][e & 3] + bias[8 * c + e];
+                        if constexpr (EPI == SAIS_EPI_BIAS_RELU_BF16) y = fmaxf(y, 0.f);
+                        if constexpr (EPI == SAIS_EPI_DGELU_BF16) y *= dgelu_erf((float)uaux[mt][c][e]);
+                        if constexpr (EPI == SAIS_EPI_DRELU_BF16) y = (float)uaux[mt][c][e] > 0.f ? y : 0.f;
+                        v[e] = (bf16)y;
+                    }
+                    *(bf16x8*)(stg + stg_off(row, 4 * g + c)) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // staged before the next barrier
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wid * 64 + mt * 16 + li;
+                if (m >= p.M) continue;
+                float y[32];
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[4 * nt + r] = acc[mt][nt][r];
+                epilogue_row<EPI>(p, m, n, y, bias);
+            }
         }
     }
+    if constexpr (HANDOFF) __builtin_amdgcn_s_barrier();              // tells the loaders the last tile is staged
 }
 
 template <int EPI>
 int launch(const NtParams& p, hipStream_t stream) {
+    constexpr bool HANDOFF = EPI == SAIS_EPI_BIAS_BF16 || EPI == SAIS_EPI_BIAS_RELU_BF16 || EPI == SAIS_EPI_BIAS_GELU_BF16 ||
+                             EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16;
     static thread_local bool ready[16] = {false};
     static thread_local int ncu[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SAIS_ERR_LAUNCH;
-    constexpr int lds = NSTAGE * STAGE;
+    constexpr int lds = Cfg<HANDOFF>::NSTAGE * STAGE + (HANDOFF ? STG_BYTES : 0);
+    if (p.K / BK < 2) return SAIS_ERR_ARG;
     if (!ready[dev]) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_ws_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        if (hipFuncSetAttribute((const void*)gemm_nt_ws_kernel<EPI, HANDOFF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
             hipSuccess)
             return SAIS_ERR_LAUNCH;
         ready[dev] = true;
@@ -241,7 +350,7 @@ int launch(const NtParams& p, hipStream_t stream) {
         ncu[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int grid = p.ntiles < ncu[dev] ? p.ntiles : ncu[dev];
-    hipLaunchKernelGGL(gemm_nt_ws_kernel<EPI>, dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_ws_kernel<EPI, HANDOFF>), dim3(grid), dim3(512), lds, stream, p);
     return SAIS_OK;
 }
 }  // namespace
