@@ -161,6 +161,17 @@ int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, lon
 int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb, const float* z_flow,
                   long clip_stride, long clip_stride_flow, int B, float* dW, float* dbias, float* dz_rgb,
                   float* dz_flow, void* stream);
+/* Optional importance head (-il): importance_function = Linear(384 -> 1) on the ReLU'd encoder output sequence,
+ * prepare_model.py:55-56,419-421.  out[m] = w . relu(z[m,:]) + b.  bwd ACCUMULATES into dz / dw / db.        */
+int sais_importance_fwd(const float* z /*[M,384] pre-ReLU*/, const float* w, const float* b, int M, float* out, void* stream);
+int sais_importance_bwd(const float* dlogit /*[M]*/, const float* z, const float* w, int M, float* dz, float* dw,
+                        float* db, void* stream);
+/* calcImportanceLoss, prepare_miscellaneous.py:48-60 (quirks kept: scalar mean BCE broadcast against the inverted
+ * mask with its last entry dropped; mean over label-0 samples, NaN if none).  logits [B,T+1] (slot 0 = CLS),
+ * target [B,T], ipad [B,T+1] (1 = masked).  dlogits (optional) [B,T+1] = scale * d loss / d logits.           */
+int sais_importance_loss(const float* logits, const float* target, const unsigned char* ipad, const int* labels,
+                         int B, int T, float* loss, float* dlogits, float scale, void* stream);
+
 /* calcNCELoss / getProbs, prepare_miscellaneous.py:14-46,111-126: sim = s_hat p_hat^T (the class logits),
  * probs = softmax(sim), loss = -mean log probs[i, label_col[i]].  With demb != NULL also the gradients:
  * demb (written) and dprotos (accumulated), both scaled by loss_scale.                            */

@@ -193,6 +193,18 @@ def nce_loss(emb, labels, prototypes):
     return -(e[torch.arange(len(cols)), cols] / e.sum(dim=1)).log().mean()
 
 
+def importance_loss(output_importances, importances, ipad, labels):
+    """calcImportanceLoss — prepare_miscellaneous.py:48-60, quirks kept: the BCE is reduced to its MEAN over every
+    (sample, frame) first, that scalar is then broadcast against the inverted padding mask (whose LAST entry is dropped,
+    so frame t is masked by slot t, not t+1), and the mean is taken over the low-skill (label 0) rows only
+    (NaN when there are none)."""
+    out = output_importances[:, :, 1:, 0]                                   # drop the CLS slot
+    bce = F.binary_cross_entropy_with_logits(out, importances, reduction='none').mean()
+    mask = (~ipad)[:, :, :-1]
+    low = torch.nonzero(labels == 0).flatten()
+    return (bce * mask)[low, :].mean()
+
+
 def probs_from_logits(sim):
     """getProbs / calcProbs — prepare_miscellaneous.py:111-126, process_inference_results.py:76-91."""
     e = sim.exp()

@@ -64,6 +64,9 @@ SIGNATURES = {
     "sais_head_fwd": [c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sais_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_void_p,
                       c_void_p, c_void_p, c_void_p],
+    "sais_importance_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "sais_importance_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sais_importance_loss": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p],
     "sais_nce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                  c_float, c_void_p],
 }

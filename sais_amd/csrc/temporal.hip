@@ -227,6 +227,74 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const 
     }
 }
 
+// ---------------------------------------------------------------- importance head (-il): Linear(384 -> 1) on relu(z)
+__global__ __launch_bounds__(256) void importance_fwd_kernel(const float* z, const float* w, const float* b, int M, float* out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float a = 0.f;
+    for (int c = lane; c < D; c += 64) a += w[c] * fmaxf(z[(size_t)row * D + c], 0.f);
+    a = wave_sum(a);
+    if (lane == 0) out[row] = a + b[0];
+}
+
+// dz[m,c] += dl[m] w[c] (z>0) ; dw[c] += sum_m dl[m] relu(z[m,c]) ; db += sum_m dl[m]
+__global__ __launch_bounds__(384) void importance_bwd_kernel(const float* dl, const float* z, const float* w, int M,
+                                                            float* dz, float* dw, float* db) {
+    const int c = threadIdx.x;
+    float aw = 0.f, ab = 0.f;
+    const float wc = w[c];
+    for (int m = blockIdx.x; m < M; m += gridDim.x) {
+        const float g = dl[m], zz = z[(size_t)m * D + c];
+        if (zz > 0.f) { dz[(size_t)m * D + c] += g * wc; aw += g * zz; }
+        ab += g;
+    }
+    atomicAdd(dw + c, aw);
+    if (c == 0) atomicAdd(db, ab);
+}
+
+// calcImportanceLoss (prepare_miscellaneous.py:48-60), quirks kept; one workgroup.  logits [B,S] (slot 0 = CLS),
+// target [B,T], ipad [B,S] (1 = masked), labels [B].  loss = mean_bce * sum_{b low, t<T} !ipad[b,t] / (nlow T);
+// dlogits[b,1+t] = frac * (sigmoid(x) - target) / (B T) * scale, dlogits[b,0] = 0.
+__global__ __launch_bounds__(256) void importance_loss_kernel(const float* logits, const float* target,
+                                                              const unsigned char* ipad, const int* labels, int B, int T,
+                                                              float* loss, float* dlogits, float scale) {
+    __shared__ float red[256];
+    __shared__ float s_frac, s_bce;
+    const int S = T + 1, tid = threadIdx.x;
+    float a = 0.f, cnt = 0.f, nlow = 0.f;
+    for (int i = tid; i < B * T; i += 256) {
+        const int b = i / T, t = i - b * T;
+        const float x = logits[b * S + 1 + t], y = target[i];
+        a += fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)));
+        if (labels[b] == 0 && !ipad[b * S + t]) cnt += 1.f;
+    }
+    for (int b = tid; b < B; b += 256) nlow += labels[b] == 0 ? 1.f : 0.f;
+    for (int pass = 0; pass < 3; ++pass) {
+        red[tid] = pass == 0 ? a : (pass == 1 ? cnt : nlow);
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        if (tid == 0) { if (pass == 0) a = red[0]; else if (pass == 1) cnt = red[0]; else nlow = red[0]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        s_bce = a / (float)(B * T);
+        s_frac = cnt / (nlow * (float)T);          // 0/0 = NaN when no low-skill sample: torch.mean of an empty tensor
+        if (loss) *loss = s_bce * s_frac;
+    }
+    __syncthreads();
+    if (!dlogits) return;
+    const float k = s_frac * scale / (float)(B * T);
+    for (int i = tid; i < B * S; i += 256) {
+        const int b = i / S, s = i - b * S;
+        float g = 0.f;
+        if (s > 0) {
+            const float x = logits[i];
+            g = k * (1.0f / (1.0f + __expf(-x)) - target[b * T + s - 1]);
+        }
+        dlogits[i] = g;
+    }
+}
+
 // ---------------------------------------------------------------- SupCon / prototype loss; one workgroup
 __global__ __launch_bounds__(256) void nce_kernel(const float* emb, const float* protos, const int* label_col, int B,
                                                   int C, float* sim, float* probs, float* loss, float* demb,
@@ -376,6 +444,32 @@ extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep
     if ((z_rgb && !dz_rgb) || (z_flow && !dz_flow)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, demb, W, rep, z_rgb, z_flow,
                        clip_stride, clip_stride_flow, B, dW, dbias, dz_rgb, dz_flow);
+    return sais_check_launch();
+}
+
+extern "C" int sais_importance_fwd(const float* z, const float* w, const float* b, int M, float* out, void* stream) {
+    SAIS_ENTER();
+    if (!z || !w || !b || !out || M <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(importance_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, w, b, M, out);
+    return sais_check_launch();
+}
+
+extern "C" int sais_importance_bwd(const float* dlogit, const float* z, const float* w, int M, float* dz, float* dw,
+                                   float* db, void* stream) {
+    SAIS_ENTER();
+    if (!dlogit || !z || !w || !dz || !dw || !db || M <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(importance_bwd_kernel, dim3(M < 64 ? M : 64), dim3(384), 0, (hipStream_t)stream, dlogit, z, w, M, dz,
+                       dw, db);
+    return sais_check_launch();
+}
+
+extern "C" int sais_importance_loss(const float* logits, const float* target, const unsigned char* ipad,
+                                    const int* labels, int B, int T, float* loss, float* dlogits, float scale,
+                                    void* stream) {
+    SAIS_ENTER();
+    if (!logits || !target || !ipad || !labels || B <= 0 || T <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(importance_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, ipad, labels, B,
+                       T, loss, dlogits, scale);
     return sais_check_launch();
 }
 

@@ -67,3 +67,33 @@ def cosine_logits_and_probs(snip_sequence, gesture_prototypes):
     probs = torch.empty_like(sim)
     ops.nce(emb, p.detach(), None, sim, probs, None, None, None, 1.0)
     return sim, probs
+
+
+class _ImportanceLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ipad_u8, labels_i32):
+        B, S = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dlog = torch.empty_like(logits)
+        ops.importance_loss(logits, target, ipad_u8, labels_i32, B, S - 1, loss, dlog, 1.0)
+        ctx.save_for_backward(dlog)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None, None, None
+
+
+def calcImportanceLoss(output_importances, importances, ipad, labels):
+    """Same signature as prepare_miscellaneous.calcImportanceLoss (:48-60): output_importances [B,1,T+1,1] (from
+    fullModel with importance_loss=True), importances [B,1,T] targets, ipad bool [B,1,T+1] (True = masked), labels [B]."""
+    if not output_importances.is_cuda:
+        raise L.SaisHipError("calcImportanceLoss needs device tensors: the HIP path has no CPU fallback")
+    dev = output_importances.device
+    B, S = output_importances.shape[0], output_importances.shape[2]
+    logits = output_importances.reshape(B, S).float().contiguous()
+    target = importances.reshape(B, S - 1).to(dev, torch.float32).contiguous()
+    mask = ipad.reshape(B, S).to(dev, torch.uint8).contiguous()
+    lab = labels.to(dev, torch.int32).contiguous()
+    return _ImportanceLossFn.apply(logits, target, mask, lab)

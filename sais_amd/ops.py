@@ -222,6 +222,19 @@ def head_bwd(demb, W, rep, z_rgb, z_flow, clip_stride, B, dW, dbias, dz_rgb, dz_
            _p(dz_rgb), _p(dz_flow), _stream())
 
 
+def importance_fwd(z, w, b, M, out):
+    L.call("sais_importance_fwd", _p(z), _p(w), _p(b), M, _p(out), _stream())
+
+
+def importance_bwd(dlogit, z, w, M, dz, dw, db):
+    L.call("sais_importance_bwd", _p(dlogit), _p(z), _p(w), M, _p(dz), _p(dw), _p(db), _stream())
+
+
+def importance_loss(logits, target, ipad_u8, labels_i32, B, T, loss=None, dlogits=None, scale=1.0):
+    L.call("sais_importance_loss", _p(logits), _p(target), _p(ipad_u8), _p(labels_i32), B, T, _p(loss), _p(dlogits),
+           scale, _stream())
+
+
 def nce(emb, protos, label_col, sim=None, probs=None, loss=None, demb=None, dprotos=None, loss_scale=1.0):
     B, C = emb.shape[0], protos.shape[0]
     L.call("sais_nce", _p(emb), _p(protos), _p(label_col), B, C, _p(sim), _p(probs), _p(loss), _p(demb), _p(dprotos),

@@ -39,15 +39,19 @@ def _make_encoder(rep_dim):
 class _TemporalFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, f, xpad, fpad, anchor):
-        emb, attn, saved = model._forward_kernels(x, f, xpad, fpad, save=True)
+        emb, attn, imp, saved = model._forward_kernels(x, f, xpad, fpad, save=True)
         ctx.model, ctx.saved = model, saved
         ctx.needs = (x is not None and x.requires_grad, f is not None and f.requires_grad)
         ctx.mark_non_differentiable(attn)
-        return emb, attn
+        if imp is None:
+            imp = emb.new_zeros(1)
+            ctx.mark_non_differentiable(imp)
+        return emb, attn, imp
 
     @staticmethod
-    def backward(ctx, demb, _dattn):
-        dx, df = ctx.model._backward_kernels(ctx.saved, demb.contiguous(), ctx.needs)
+    def backward(ctx, demb, _dattn, dimp):
+        dimp = dimp.contiguous() if ctx.model.importance_loss and dimp is not None else None
+        dx, df = ctx.model._backward_kernels(ctx.saved, demb.contiguous(), ctx.needs, dimp)
         ctx.saved = None
         return None, dx, df, None, None, None
 
@@ -60,8 +64,9 @@ class fullModel(nn.Module):
         if data_type != 'reps' or encoder_type != 'ViT' or rep_dim != D or not self_attention:
             raise NotImplementedError("MI355X hot path = fullModel('reps', ..., 384, 'ViT', self_attention=True); "
                                       "raw / R3D / I3D branches are out of scope (SURVEY §2)")
-        if importance_loss:
-            raise NotImplementedError("importance head (-il, prepare_model.py:55-56) is a 'next' row (SURVEY §8 a13)")
+        if importance_loss and modalities == 'Flow':
+            raise NotImplementedError("importance head with the Flow-only stream: the reference itself fails there "
+                                      "(full_snip_sequence is undefined, prepare_model.py:419-421)")
         if modalities not in ('RGB', 'Flow', 'RGB-Flow'):
             raise ValueError(modalities)
         # registration order mirrors the reference so state_dict ordering matches too
@@ -69,6 +74,8 @@ class fullModel(nn.Module):
         if '+' in domain:
             self.linearB = nn.Linear(rep_dim, EMB)
         self.linear2 = nn.Linear(EMB, 3)                                 # :50 (dead on this path, App. B.5)
+        if importance_loss:
+            self.importance_function = nn.Linear(rep_dim, 1)             # :55-56 (a13, optional -il)
         self.frame_cls = nn.Parameter(torch.rand(1, rep_dim))
         self.clip_cls = nn.Parameter(torch.rand(1, rep_dim))
         # filled one key at a time (as the reference does, :64-69): ParameterDict(dict) would SORT the keys
@@ -138,15 +145,16 @@ class fullModel(nn.Module):
             raise NotImplementedError(f"task {task!r}: only 'Prototypes' is on the MI355X hot path")
         if isinstance(x, (list, tuple)) or isinstance(f, (list, tuple)):          # TTA versions, :331-346
             n = len(x) if x is not None else len(f)
-            embs, attn0 = [], None
+            embs, attn0, imp0 = [], None, None
             for v in range(n):
-                e, a = self._forward_one(None if x is None else x[v], None if f is None else f[v],
-                                         None if xpad is None else xpad[v], None if fpad is None else fpad[v])
+                e, a, im = self._forward_one(None if x is None else x[v], None if f is None else f[v],
+                                             None if xpad is None else xpad[v], None if fpad is None else fpad[v])
                 embs.append(e)
                 if v == 0:
-                    attn0 = a
-            return embs, attn0
-        return self._forward_one(x, f, xpad, fpad)
+                    attn0, imp0 = a, im
+            return (imp0, embs, attn0) if self.importance_loss else (embs, attn0)
+        emb, attn, imp = self._forward_one(x, f, xpad, fpad)
+        return (imp, emb, attn) if self.importance_loss else (emb, attn)          # :444-448
 
     def _forward_one(self, x, f, xpad, fpad):
         use_x = self.modalities in ('RGB', 'RGB-Flow')
@@ -158,9 +166,10 @@ class fullModel(nn.Module):
         fpad = self._mask(fpad, f, dev) if use_f else None
         self._engine(dev)
         if torch.is_grad_enabled() and self.linear.weight.requires_grad:
-            return _TemporalFn.apply(self, x, f, xpad, fpad, self._anchor)
-        emb, attn, _ = self._forward_kernels(x, f, xpad, fpad, save=False)
-        return emb, attn
+            emb, attn, imp = _TemporalFn.apply(self, x, f, xpad, fpad, self._anchor)
+            return emb, attn, (imp if self.importance_loss else None)
+        emb, attn, imp, _ = self._forward_kernels(x, f, xpad, fpad, save=False)
+        return emb, attn, imp
 
     @staticmethod
     def _check(t, name):
@@ -244,8 +253,12 @@ class fullModel(nn.Module):
         emb = torch.empty(B, EMB, dtype=torch.float32, device=ref.device)
         ops.head_fwd(zr, zf, (Sx if zr is not None else Sf) * D, B, fl.w32("linear.weight"), fl.w32("linear.bias"), rep, emb,
                      clip_stride_flow=Sf * D)
+        imp = None
+        if self.importance_loss:                              # importance_function(full RGB sequence), :419-421
+            imp = torch.empty(B, 1, Sx, 1, dtype=torch.float32, device=ref.device)
+            ops.importance_fwd(zr, fl.w32("importance_function.weight"), fl.w32("importance_function.bias"), B * Sx, imp)
         saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, Sx=Sx, Sf=Sf) if save else None
-        return emb, attn, saved
+        return emb, attn, imp, saved
 
     def _stream_bwd(self, s, dz, need_dx):
         """dz: f32 [M,384] gradient wrt the stream's final (pre-ReLU) encoder output."""
@@ -284,7 +297,7 @@ class fullModel(nn.Module):
                                  False, fl.grad[o:o + T * D], fl.g("frame_cls"))
         return dx
 
-    def _backward_kernels(self, saved, demb, needs):
+    def _backward_kernels(self, saved, demb, needs, dimp=None):
         fl = self.flat
         fl.attach_grads()
         B, Sx, Sf = saved["B"], saved["Sx"], saved["Sf"]
@@ -293,6 +306,9 @@ class fullModel(nn.Module):
         dzf = torch.zeros_like(zf) if zf is not None else None
         ops.head_bwd(demb, fl.w32("linear.weight"), saved["rep"], zr, zf, (Sx if zr is not None else Sf) * D, B,
                      fl.g("linear.weight"), fl.g("linear.bias"), dzr, dzf, clip_stride_flow=Sf * D)
+        if dimp is not None:
+            ops.importance_bwd(dimp, zr, fl.w32("importance_function.weight"), B * Sx, dzr,
+                               fl.g("importance_function.weight"), fl.g("importance_function.bias"))
         dx = self._stream_bwd(saved["sr"], dzr, needs[0]) if zr is not None else None
         df = self._stream_bwd(saved["sf"], dzf, needs[1]) if zf is not None else None
         if self.grad_ready_hook:

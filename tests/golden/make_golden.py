@@ -255,6 +255,50 @@ def golden_temporal(prepare_model, misc, out):
     print("temporal.npz keys", len(g))
 
 
+def golden_importance(prepare_model, misc, out):
+    """Optional importance head (-il): fullModel(..., importance_loss=True) returns (importances, emb, attn)
+    (prepare_model.py:419-421,444-446); calcImportanceLoss (prepare_miscellaneous.py:48-60)."""
+    g = {}
+    for modal in ("RGB", "RGB-Flow"):
+        m = build_full(prepare_model, 2, modal, importance=True, seed=3)
+        lens = [9, 6, 9, 4]
+        B, T = len(lens), 9
+        x = synth.reps(seed=810, B=B, T=T)
+        f = synth.reps(seed=811, B=B, T=T)
+        for b, n in enumerate(lens):
+            x[b, :, n:] = 0
+            f[b, :, n:] = 0
+        pad = synth.padding_mask(lens)
+        protos = nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in synth.prototypes(seed=2, nclasses=2).items()})
+        lab = torch.tensor([0, 1, 0, 0])
+        target = (torch.rand(B, 1, T, generator=torch.Generator().manual_seed(812)) > 0.5).float()
+        x_in = x.clone().requires_grad_(True)
+        imp, emb, attn = m(x_in * 1.0, f.clone(), lens, lens, 'Prototypes', pad.clone(), pad.clone(), None)
+        iloss = misc.calcImportanceLoss(imp, target, pad.clone(), lab)
+        loss = misc.calcNCELoss(0, emb, lab, [f"v_{i}" for i in range(B)], protos, None) + iloss
+        loss.backward()
+        key = modal + "/"
+        g[key + "lens"] = np.array(lens)
+        g[key + "labels"] = lab.numpy()
+        g[key + "target"] = target.numpy()
+        g[key + "imp"] = imp.detach().numpy()
+        g[key + "emb"] = emb.detach().numpy()
+        g[key + "attn"] = attn.detach().numpy()
+        g[key + "iloss"] = np.float32(iloss.item())
+        g[key + "loss"] = np.float32(loss.item())
+        g[key + "grad_x"] = x_in.grad.numpy()
+        P = dict(m.named_parameters())
+        for n in ("importance_function.weight", "importance_function.bias", "linear.bias", "frame_cls",
+                  "transEncoderFrame.layers.3.norm2.bias", "transEncoderFrame.layers.0.self_attn.in_proj_bias"):
+            g[key + "grad/" + n] = P[n].grad.numpy()
+    # no low-skill sample in the batch: the reference takes the mean of an empty tensor
+    imp = torch.randn(2, 1, 5, 1)
+    nanloss = misc.calcImportanceLoss(imp, torch.zeros(2, 1, 4), synth.padding_mask([4, 4]), torch.tensor([1, 1]))
+    g["empty_low_skill_is_nan"] = np.float32(nanloss.item())
+    np.savez_compressed(os.path.join(out, "importance.npz"), **g)
+    print("importance.npz keys", len(g))
+
+
 def golden_collate(out):
     import prepare_dataset
     dl = prepare_dataset.loadDataloader.__new__(prepare_dataset.loadDataloader)
@@ -341,6 +385,7 @@ def main():
     golden_temporal(prepare_model, misc, HERE)
     golden_collate(HERE)
     golden_e2e(vits, prepare_model, misc, HERE)
+    golden_importance(prepare_model, misc, HERE)
 
 
 if __name__ == "__main__":

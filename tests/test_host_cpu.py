@@ -30,7 +30,9 @@ def test_out_of_scope_branches_raise():
     with pytest.raises(NotImplementedError):
         fullModel('raw', 2, 'd', 512, 'R3D')
     with pytest.raises(NotImplementedError):
-        fullModel('reps', 2, 'd', 384, 'ViT', importance_loss=True)
+        fullModel('reps', 2, 'd', 384, 'ViT', modalities='Flow', importance_loss=True)
+    mi = fullModel('reps', 2, 'd', 384, 'ViT', importance_loss=True)           # -il adds importance_function.{weight,bias}
+    assert {k: tuple(t.shape) for k, t in mi.state_dict().items()} == {k: s for k, s, _ in synth.temporal_keys(importance=True)}
     m = fullModel('reps', 2, 'd', 384, 'ViT')
     with pytest.raises(NotImplementedError):
         m(None, None, None, None, 'MIL', None, None, None)

@@ -212,6 +212,42 @@ def test_loss_logits_and_grads_vs_golden(gpu, golden, C):
     assert float(P["linear2.weight"].grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("modal", ["RGB", "RGB-Flow"])
+def test_importance_head_vs_golden(gpu, golden, modal):
+    """Optional -il head: importances, importance loss and the gradients it sends into the encoder."""
+    from sais_amd.loss import calcImportanceLoss, calcNCELoss
+    from sais_amd.temporal import fullModel
+    g = golden("importance")
+    key = modal + "/"
+    m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities=modal, importance_loss=True)
+    m.load_state_dict(synth.temporal_state_dict(seed=3, importance=True), strict=True)
+    m = m.to(DEV).train()
+    lens = [int(v) for v in g[key + "lens"]]
+    B, T = len(lens), 9
+    x, f = synth.reps(seed=810, B=B, T=T), synth.reps(seed=811, B=B, T=T)
+    for b, n in enumerate(lens):
+        x[b, :, n:] = 0
+        f[b, :, n:] = 0
+    x = x.to(DEV).requires_grad_(True)
+    pad = synth.padding_mask(lens).to(DEV)
+    protos = protos_dev(2)
+    lab = torch.from_numpy(g[key + "labels"])
+    target = torch.from_numpy(g[key + "target"]).to(DEV)
+    imp, emb, attn = m(x, f.to(DEV), lens, lens, 'Prototypes', pad, pad, None)
+    iloss = calcImportanceLoss(imp, target, pad, lab)
+    loss = calcNCELoss(0, emb, lab, [f"v_{i}" for i in range(B)], protos, None) + iloss
+    loss.backward()
+    assert tuple(imp.shape) == (B, 1, T + 1, 1)
+    assert maxabs(imp, g[key + "imp"]) <= 1e-4
+    assert abs(iloss.item() - float(g[key + "iloss"])) <= 1e-5 and abs(loss.item() - float(g[key + "loss"])) <= LOGIT_TOL
+    assert rel_l2(x.grad, g[key + "grad_x"]) <= GRAD_REL
+    P = dict(m.named_parameters())
+    bad = {k: rel_l2(P[k[len(key + "grad/"):]].grad, g[k]) for k in g.files if k.startswith(key + "grad/")}
+    assert not {k: v for k, v in bad.items() if v > GRAD_REL}, bad
+    nan = calcImportanceLoss(imp.detach(), target, pad, torch.ones(B, dtype=torch.long))
+    assert torch.isnan(nan)                                   # no low-skill sample: mean of an empty tensor, as the reference
+
+
 # ------------------------------------------------------------------ end-to-end composition (SURVEY §3.4)
 def test_e2e_config1_vs_golden(gpu, golden):
     """BASELINE config 1: B=1, T=16, 1-layer temporal encoder, RGB — logits within 1e-3 of the reference."""

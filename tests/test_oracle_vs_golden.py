@@ -181,3 +181,34 @@ def test_e2e_train_grads(golden):
             close(tsd[k[len("train/tgrad/"):]].grad, g[k], 2e-4)
         elif k.startswith("train/grad_proto"):
             close(protos[k[len("train/grad_proto"):]].grad, g[k], 2e-4)
+
+
+def test_importance_head_and_loss(golden):
+    g = golden("importance")
+    for modal in ("RGB", "RGB-Flow"):
+        key = modal + "/"
+        sd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=3, importance=True).items()}
+        lens = [int(v) for v in g[key + "lens"]]
+        B, T = len(lens), 9
+        x, f = synth.reps(seed=810, B=B, T=T), synth.reps(seed=811, B=B, T=T)
+        for b, n in enumerate(lens):
+            x[b, :, n:] = 0
+            f[b, :, n:] = 0
+        x.requires_grad_(True)
+        pad = synth.padding_mask(lens)
+        protos = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(seed=2, nclasses=2).items()}
+        lab = torch.from_numpy(g[key + "labels"])
+        target = torch.from_numpy(g[key + "target"])
+        imp, emb, attn = O.temporal_forward(sd, x, f, pad, pad, modal, importance=True)
+        iloss = O.importance_loss(imp, target, pad, lab)
+        loss = O.nce_loss(emb, lab, protos) + iloss
+        loss.backward()
+        close(imp, g[key + "imp"])
+        close(emb, g[key + "emb"])
+        assert abs(iloss.item() - float(g[key + "iloss"])) < 1e-6 and abs(loss.item() - float(g[key + "loss"])) < 1e-6
+        close(x.grad, g[key + "grad_x"], 1e-6)
+        for k in g.files:
+            if k.startswith(key + "grad/"):
+                close(sd[k[len(key + "grad/"):]].grad, g[k], 1e-6)
+    nan = O.importance_loss(torch.randn(2, 1, 5, 1), torch.zeros(2, 1, 4), synth.padding_mask([4, 4]), torch.tensor([1, 1]))
+    assert torch.isnan(nan) and np.isnan(g["empty_low_skill_is_nan"])
