@@ -12,8 +12,11 @@ done
 SYN=""
 if [ -n "$synthetic" ]; then SYN="--synthetic_frames $synthetic"; fi
 
-# (video_to_frames.sh / generate_paths.py / --optical_flow: not part of this build — frames are read straight from
+# (video_to_frames.sh / --optical_flow: not part of this build — frames are read straight from
 #  ./SAIS/images/<video>/ and ./SAIS/flows/<video>/ if they exist)
+
+# generate paths to frames and flows and save as csv files
+python ./SAIS/scripts/generate_paths.py -f $videoname -p ./SAIS/ $SYN || exit 1
 
 # extract representations of rgb images
 python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 1024 --data_path ./SAIS/ --data_list Custom --save_type h5 --video $videoname $SYN || exit 1
@@ -24,4 +27,5 @@ python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 1
 # perform inference
 python ./SAIS/scripts/run_experiments.py -p ./SAIS/ -data Custom_Gestures -d Custom -m ViT -enc ViT_SelfSupervised_ImageNet -t Prototypes -mod RGB-Flow -dim 384 -bs 2 -lr 1e-1 -nc 2 -bc -sa -domains in_vs_out -ph Custom_inference -dt reps -e 1 -f 1 --inference || exit 1
 
-# (process_inference_results.py: "next" row)
+# process inference results to generate valid predictions
+python ./SAIS/scripts/process_inference_results.py -p ./SAIS/ || exit 1
