@@ -130,6 +130,16 @@ int sais_sgd_step(float* param, const float* grad, void* shadow_bf16, long n, fl
 int sais_cast_bf16(const float* src, void* dst_bf16, long n, void* stream);
 int sais_transpose_cast_bf16(const float* src, int rows, int cols, void* dst_bf16 /*[cols,rows]*/, void* stream);
 int sais_transpose_f32(const float* src, int rows, int cols, float* dst /*[cols,rows]*/, void* stream);
+/* All transposed weight shadows of a model in ONE launch (the per-weight launches above are ~5 us each and a ViT-S
+ * has 48 of them per optimizer step).  `items` is a DEVICE array, built once per model: the addresses are fixed.  */
+typedef struct SaisTransposeItem {
+    const float* src;        /* [rows, cols] f32                                              */
+    void*        dst;        /* [cols, rows] bf16 (dst_is_f32 == 0) or f32                     */
+    int rows, cols;
+    int tile_begin;          /* prefix sum of ceil(rows/32)*ceil(cols/32) over preceding items */
+    int reserved;
+} SaisTransposeItem;
+int sais_transpose_batch(const SaisTransposeItem* items_dev, int nitems, int total_tiles, int dst_is_f32, void* stream);
 int sais_scale_f32(float* p, long n, float s, void* stream);
 
 /* ---------------------------------------------------------------- temporal encoder glue (dim 384, 4 heads x 96)

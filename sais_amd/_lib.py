@@ -54,6 +54,7 @@ SIGNATURES = {
     "sais_sgd_step": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_void_p],
     "sais_cast_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "sais_transpose_cast_bf16": [c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "sais_transpose_batch": [c_void_p, c_int, c_int, c_int, c_void_p],
     "sais_scale_f32": [c_void_p, c_long, c_float, c_void_p],
     "sais_temporal_prepare_fwd": [c_void_p, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p],

@@ -117,6 +117,33 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, T
     }
 }
 
+// every transposed shadow of a model in one launch: workgroup -> (item, 32x32 tile) through the tile prefix sums
+template <typename TO>
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const SaisTransposeItem* items, int nitems) {
+    __shared__ float tile[32][33];
+    const int wg = blockIdx.x;
+    int lo = 0, hi = nitems - 1;                       // last item whose tile_begin <= wg
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile_begin <= wg) lo = mid; else hi = mid - 1;
+    }
+    const SaisTransposeItem it = items[lo];
+    const int R = it.rows, C = it.cols, tc = (C + 31) / 32, t = wg - it.tile_begin;
+    const int c0 = (t % tc) * 32, r0 = (t / tc) * 32;
+    const float* src = it.src;
+    TO* dst = (TO*)it.dst;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, r = r0 + tx;
+        if (c < C && r < R) dst[(size_t)c * R + r] = (TO)tile[tx][j];
+    }
+}
+
 __global__ void scale_kernel(float* p, long n, float s) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= s;
 }
@@ -193,6 +220,19 @@ extern "C" int sais_transpose_f32(const float* src, int rows, int cols, float* d
     if (!src || !dst || rows <= 0 || cols <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(transpose_cast_kernel<float>, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
                        (hipStream_t)stream, src, dst, rows, cols);
+    return sais_check_launch();
+}
+
+extern "C" int sais_transpose_batch(const SaisTransposeItem* items_dev, int nitems, int total_tiles, int dst_is_f32,
+                                    void* stream) {
+    SAIS_ENTER();
+    if (!items_dev || nitems <= 0 || total_tiles <= 0) return SAIS_ERR_ARG;
+    if (dst_is_f32)
+        hipLaunchKernelGGL(transpose_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                           items_dev, nitems);
+    else
+        hipLaunchKernelGGL(transpose_batch_kernel<bf16>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                           items_dev, nitems);
     return sais_check_launch();
 }
 

@@ -29,6 +29,7 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.w16 = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
         self.wt16 = {}                                   # name -> transposed bf16 copy [in, out]
+        self._tr_key, self._tr_table = None, None         # descriptor table of the batched transpose
         with torch.no_grad():
             for n, p in named:
                 o = self.offsets[n]
@@ -85,16 +86,23 @@ class FlatParams:
         return (self.epoch,) + tuple(self.params[self._idx[n]]._version for n in sentinels)
 
     def _transposes(self, names):
-        for n in names:
-            p = self.params[self._idx[n]]
-            rows, cols = p.shape
-            if n not in self.wt16:
-                self.wt16[n] = torch.empty(cols, rows, device=self.device,
-                                           dtype=torch.float32 if self.f32_transposes else torch.bfloat16)
-            if self.f32_transposes:
-                ops.transpose_f32(self.w32(n), rows, cols, self.wt16[n])
-            else:
-                ops.transpose_cast_bf16(self.w32(n), rows, cols, self.wt16[n])
+        """Refresh every transposed shadow in one launch; the descriptor table lives on the device and is rebuilt only
+        when the set of names changes (addresses are fixed: flat buffer + persistent shadow tensors)."""
+        names = tuple(names)
+        if not names:
+            return
+        if self._tr_key != names:
+            entries = []
+            for n in names:
+                p = self.params[self._idx[n]]
+                rows, cols = p.shape
+                if n not in self.wt16:
+                    self.wt16[n] = torch.empty(cols, rows, device=self.device,
+                                               dtype=torch.float32 if self.f32_transposes else torch.bfloat16)
+                entries.append((self.w32(n), self.wt16[n]))
+            self._tr_table = ops.transpose_table(entries, self.device)
+            self._tr_key = names
+        ops.transpose_batch(*self._tr_table, self.f32_transposes)
 
     def refresh_shadows(self, transposed_names):
         if not self.f32_transposes:

@@ -189,6 +189,26 @@ def transpose_f32(src, rows, cols, dst):
     L.call("sais_transpose_f32", _p(src), rows, cols, _p(dst), _stream())
 
 
+def transpose_table(entries, device):
+    """Device descriptor table for transpose_batch: entries = [(src f32 [rows,cols], dst [cols,rows])].
+    Layout = SaisTransposeItem (include/sais_hip.h): two pointers, rows, cols, tile_begin, reserved = 4 x int64."""
+    import numpy as np
+    tab = np.zeros((len(entries), 4), np.int64)
+    tiles = 0
+    for i, (src, dst) in enumerate(entries):
+        rows, cols = src.shape
+        assert tuple(dst.shape) == (cols, rows) and src.dtype == F32 and src.is_contiguous() and dst.is_contiguous()
+        tab[i, 0], tab[i, 1] = src.data_ptr(), dst.data_ptr()
+        tab[i, 2] = rows | (cols << 32)
+        tab[i, 3] = tiles
+        tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+    return torch.from_numpy(tab).to(device), len(entries), tiles
+
+
+def transpose_batch(table, nitems, tiles, dst_is_f32):
+    L.call("sais_transpose_batch", _p(table), nitems, tiles, 1 if dst_is_f32 else 0, _stream())
+
+
 def scale_(t, s):
     L.call("sais_scale_f32", _p(t), t.numel(), s, _stream())
 

@@ -242,6 +242,19 @@ def test_sgd_cast_transpose(ops):
     assert torch.equal(c.view(1152, 384).cpu(), w.to(torch.bfloat16).cpu())
 
 
+def test_transpose_batch(ops):
+    """Every shadow of a model in one launch: ragged shapes (not multiples of 32), bf16 and f32 destinations."""
+    shapes = [(1152, 384), (384, 384), (37, 65), (1, 384), (256, 384), (33, 31)]
+    srcs = [rnd(r, c, seed=300 + i) for i, (r, c) in enumerate(shapes)]
+    for dt in (torch.bfloat16, torch.float32):
+        dsts = [torch.full((c, r), 7.0, dtype=dt, device=DEV) for (r, c) in shapes]
+        table, n, tiles = ops.transpose_table(list(zip(srcs, dsts)), DEV)
+        assert n == len(shapes) and tiles == sum(((r + 31) // 32) * ((c + 31) // 32) for r, c in shapes)
+        ops.transpose_batch(table, n, tiles, dt == torch.float32)
+        for s, d in zip(srcs, dsts):
+            assert torch.equal(d.cpu(), s.t().contiguous().to(dt).cpu())
+
+
 # ------------------------------------------------------------------ temporal glue + head + loss
 def test_temporal_prepare(ops):
     B, T = 3, 9
