@@ -18,20 +18,33 @@ from SAIS.scripts._features_io import save_reps  # noqa: E402
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # :148
 
 
-def load_frames(folder):
-    """SurgDataset.__getitem__ (dino-main/main_dino.py:295-316): CenterCrop(0.8 H, 0.8 W) -> Resize((224,224)) ->
-    ToTensor -> Normalize.  Host-side PIL restatement (torchvision is absent here: unpinned)."""
+def frame_batches(folder, dev, chunk=64):
+    """SurgDataset.__getitem__ (dino-main/main_dino.py:295-316) + the transform of :158-162, with the arithmetic on the
+    GPU: JPEGs are decoded on the host (PIL), pushed as uint8 and turned into the float32 [n,3,224,224] ViT input by
+    sais_amd.preprocess (CenterCrop(0.8 H, 0.8 W) -> Resize((224,224)) -> ToTensor -> Normalize, bit-identical to the
+    torchvision 0.9.0 / Pillow pipeline of the reference).  Yields device tensors of up to `chunk` frames."""
     from PIL import Image
-    out = []
+    from sais_amd.preprocess import FramePreprocessor
+    plans, buf, geom = {}, [], None
+
+    def flush():
+        h, w = geom
+        if geom not in plans:
+            plans[geom] = FramePreprocessor(h, w, 0.8, 0.8, MEAN, STD, device=dev)
+        return plans[geom](torch.from_numpy(np.stack(buf)))
+
     for p in sorted(glob.glob(os.path.join(folder, '*.jpg'))):
-        img = Image.open(p).convert('RGB')
-        w, h = img.size
-        cw, ch = int(0.8 * w), int(0.8 * h)
-        l, t = (w - cw) // 2, (h - ch) // 2
-        img = img.crop((l, t, l + cw, t + ch)).resize((224, 224), Image.BILINEAR)
-        x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
-        out.append((x - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1))
-    return torch.stack(out) if out else None
+        with Image.open(p) as img:
+            if img.mode != 'RGB':                    # the reference drops the result of img.convert('RGB') (:297)
+                raise SystemExit(f'{p}: mode {img.mode}; the pipeline expects RGB frames')
+            a = np.asarray(img)
+        if buf and (a.shape[:2] != geom or len(buf) == chunk):
+            yield flush()
+            buf = []
+        geom = a.shape[:2]
+        buf.append(a)
+    if buf:
+        yield flush()
 
 
 def main():
@@ -79,9 +92,12 @@ def main():
             u8 = torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8).float() / 255.0
             frames = (u8 - torch.tensor(MEAN).view(1, 3, 1, 1)) / torch.tensor(STD).view(1, 3, 1, 1)
         else:
-            frames = load_frames(os.path.join(args.data_path, sub, v))
-            if frames is None:
+            parts = [fx(b).cpu() for b in frame_batches(os.path.join(args.data_path, sub, v), dev)]
+            if not parts:
                 raise SystemExit(f'no frames under {os.path.join(args.data_path, sub, v)}')
+            reps[v] = torch.cat(parts).numpy()
+            print(f'[extract] {v}: {reps[v].shape[0]} frames -> {reps[v].shape}')
+            continue
         reps[v] = fx(frames.to(dev)).cpu().numpy()
         print(f'[extract] {v}: {reps[v].shape[0]} frames -> {reps[v].shape}')
     name = '%s_%sRepsAndLabels' % (args.model_type, 'Flow' if flow else '')

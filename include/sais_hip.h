@@ -142,6 +142,19 @@ typedef struct SaisTransposeItem {
 int sais_transpose_batch(const SaisTransposeItem* items_dev, int nitems, int total_tiles, int dst_is_f32, void* stream);
 int sais_scale_f32(float* p, long n, float s, void* stream);
 
+/* ---------------------------------------------------------------- frame preprocessing (uint8 frames -> ViT input)
+ * SurgDataset.__getitem__, dino-main/main_dino.py:295-316 + the transform of extract_representations.py:158-162:
+ * CenterCrop((height_frac*H, width_frac*W)) -> Resize((224,224)) -> ToTensor -> Normalize(mean, std), bit-identical to
+ * torchvision 0.9.0 + Pillow's 8-bit bilinear resampler.  A plan holds the per-geometry coefficient tables on the
+ * device (built once: allocation + upload); sais_preprocess_run only launches, so it can be graph-captured.
+ * frames: device uint8 [F, H, W, 3] (RGB, as decoded); out: device float32 [F, 3, 224, 224].                      */
+typedef struct SaisPreprocessPlan SaisPreprocessPlan;
+int  sais_preprocess_plan_create(int H, int W, double height_frac, double width_frac, const float* mean3,
+                                 const float* std3, SaisPreprocessPlan** plan);
+int  sais_preprocess_plan_box(const SaisPreprocessPlan* plan, int* box4 /* left, top, right, bottom */);
+int  sais_preprocess_run(const SaisPreprocessPlan* plan, const unsigned char* frames, int nframes, float* out, void* stream);
+void sais_preprocess_plan_destroy(SaisPreprocessPlan* plan);
+
 /* ---------------------------------------------------------------- temporal encoder glue (dim 384, 4 heads x 96)
  * prepareInputForTransformer, prepare_model.py:179-195: z[b,0] = frame_cls, z[b,1+t] = x[b,t] + pos[t]
  * (out of place: the reference's in-place += on the caller's tensor is NOT reproduced).          */

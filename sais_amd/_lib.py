@@ -55,6 +55,11 @@ SIGNATURES = {
     "sais_cast_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "sais_transpose_cast_bf16": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_transpose_batch": [c_void_p, c_int, c_int, c_int, c_void_p],
+    "sais_preprocess_plan_create": [c_int, c_int, ctypes.c_double, ctypes.c_double, c_void_p, c_void_p,
+                                    ctypes.POINTER(c_void_p)],
+    "sais_preprocess_plan_box": [c_void_p, c_void_p],
+    "sais_preprocess_run": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "sais_preprocess_plan_destroy": [c_void_p],
     "sais_scale_f32": [c_void_p, c_long, c_float, c_void_p],
     "sais_temporal_prepare_fwd": [c_void_p, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p],
@@ -93,6 +98,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.sais_preprocess_plan_destroy.restype = None
     lib.sais_last_error.restype = ctypes.c_char_p
     lib.sais_last_error.argtypes = []
     _lib = lib

@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         ge.build()
     hdr = open(os.path.join(ROOT, "include", "sais_hip.h")).read()
-    declared = set(re.findall(r"^int\s+(sais_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void)\s+(sais_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 20
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -32,3 +32,5 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_layernorm_fwd(None, 384, 4, 384, None, None, 1e-6, None, 384, None, 384, None, None, None) == -1
     assert lib.sais_vit_attn_fwd(None, 1152, 1, None, 384, None, None, None) == -1
     assert lib.sais_temporal_attn_fwd(None, None, 1, 1000, None, None, None) == -1
+    assert lib.sais_preprocess_plan_create(0, 10, 0.8, 0.8, None, None, None) == -1
+    assert lib.sais_preprocess_run(None, None, 1, None, None) == -1

@@ -132,3 +132,64 @@ def test_cli_main_sh_equivalent_on_synthetic_frames(gpu, tmp_path):
     assert r["labels"][0].dtype == torch.int64 and r["labels"][0].dim() == 0
     assert sum(a.shape[0] for a in attn) == nwin and tuple(attn[0].shape[1:]) == (16, 16)
     assert imp == []
+
+
+def test_main_sh_on_jpeg_frames_end_to_end(gpu, tmp_path):
+    """bash SAIS/main.sh's stages on real JPEG files: generate_paths -> extract (decode on host, crop/resize/normalise
+    on the GPU) -> flow reps -> inference -> post-processing CSV.  The RGB features must equal what the ViT gives on
+    frames preprocessed by Pillow on the host (the reference's CPU pipeline)."""
+    import numpy as np
+    from PIL import Image
+    from sais_amd import model_io
+    from sais_amd.temporal import fullModel
+    from SAIS.scripts._features_io import load_reps
+    root = tmp_path / "SAIS"
+    fold = root / "params" / "Fold_0"
+    fold.mkdir(parents=True)
+    m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT')
+    m.load_state_dict(synth.temporal_state_dict(seed=1))
+    model_io.save_params_file(m, fold / "params.zip")
+    model_io.save_prototypes_file(synth.prototypes(2, 2), fold / "prototypes.zip")
+    nframes, h, w = 45, 180, 320
+    g = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for sub, n in (("images", nframes), ("flows", nframes // 15)):
+        (root / sub / "vid_01").mkdir(parents=True)
+        for i in range(n):
+            img = np.stack([127 + 100 * np.sin(xx / (11.0 + c) + i) * np.cos(yy / 17.0 - c) for c in range(3)], -1)
+            img = np.clip(img + g.normal(0, 5, img.shape), 0, 255).astype(np.uint8)
+            stem = "frames" if sub == "images" else "flows"
+            Image.fromarray(img).save(root / sub / "vid_01" / f"{stem}_{i:08d}.jpg", quality=92)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    data = str(root) + "/"
+    sc = lambda name: os.path.join(ROOT, "SAIS/scripts", name)
+    subprocess.run([sys.executable, sc("generate_paths.py"), "-f", "vid_01", "-p", data], check=True, env=env, cwd=ROOT)
+    ex = [sys.executable, sc("extract_representations.py"), "--arch", "vit_small", "--patch_size", "16", "--model_type",
+          "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "1024", "--data_path", data, "--data_list", "Custom",
+          "--save_type", "h5", "--video", "vid_01"]
+    subprocess.run(ex, check=True, env=env, cwd=ROOT)
+    subprocess.run(ex + ["--optical_flow_to_reps"], check=True, env=env, cwd=ROOT)
+    subprocess.run([sys.executable, sc("run_experiments.py"), "-p", data, "-data", "Custom_Gestures", "-d", "Custom", "-m",
+                    "ViT", "-enc", "ViT_SelfSupervised_ImageNet", "-t", "Prototypes", "-mod", "RGB-Flow", "-dim", "384",
+                    "-bs", "2", "-lr", "1e-1", "-nc", "2", "-bc", "-sa", "-domains", "in_vs_out", "-ph",
+                    "Custom_inference", "-dt", "reps", "-e", "1", "-f", "1", "--inference"], check=True, env=env, cwd=ROOT)
+    # prototypes along +/- the mean embedding: every window becomes a confident class-0 prediction, so it survives the
+    # entropy gate of the post-processing stage (random prototypes give p ~ 0.5 and an empty table)
+    r = torch.load(fold / "reps_and_labels_Custom_inference", weights_only=False)
+    mean_emb = torch.stack(r["reps"][0]).mean(0, keepdim=True)
+    model_io.save_prototypes_file({"0": mean_emb, "1": -mean_emb}, fold / "prototypes.zip")
+    subprocess.run([sys.executable, sc("process_inference_results.py"), "-p", data], check=True, env=env, cwd=ROOT)
+    # features: same seeded ViT, frames preprocessed by Pillow on the host
+    rgb = load_reps(data, "ViT_SelfSupervised_ImageNet_RepsAndLabels")["vid_01"]
+    assert rgb.shape == (nframes, 384)
+    from tests.test_preprocess import _pil_pipeline
+    torch.manual_seed(0)
+    vit = model_io.load_vit(None, device=torch.device("cuda:0"), drop_path_rate=0.1)
+    files = sorted((root / "images" / "vid_01").glob("*.jpg"))
+    host = np.stack([_pil_pipeline(np.asarray(Image.open(p))) for p in files])
+    with torch.no_grad():
+        ref = vit(torch.from_numpy(host).cuda()).cpu().numpy()
+    np.testing.assert_allclose(rgb, ref, rtol=0, atol=1e-5)
+    lines = open(root / "results" / "Custom_inference_gestures.csv").read().strip().split("\n")
+    assert lines[0] == ",0,1,StartFrame,EndFrame,Entropy,pred,StartTime,EndTime,Gesture,Video,Path"
+    assert len(lines) >= 2 and lines[1].endswith("vid_01,images/vid_01")
