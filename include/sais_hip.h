@@ -41,6 +41,9 @@ enum {
     SAIS_EPI_DRELU_BF16 = 6,      /* out bf16 = acc * (aux bf16 > 0)                                 */
     SAIS_EPI_BIAS_RELU_F32 = 8,   /* (f32 GEMM only) out f32 = relu(acc + bias)                      */
     SAIS_EPI_DRELU_F32 = 9,       /* (f32 GEMM only) out f32 = acc * (aux f32 > 0)                   */
+    SAIS_EPI_BIAS_GELU_GRAD_BF16 = 10, /* out bf16 = gelu_erf(acc + bias) ; out2 bf16 = gelu'(acc + bias): the training
+                                     forward stores the derivative instead of the pre-activation, so that ...     */
+    SAIS_EPI_MUL_BF16 = 11,       /* ... the backward is out bf16 = acc * aux(bf16), with no erf/exp in its epilogue */
     SAIS_EPI_PATCH_F32 = 7        /* patch-embed: row f*grp_in+q -> token row f*grp_out+q+grp_off,
                                      out f32 = acc + bias + aux(f32 pos)[q+grp_off]                  */
 };

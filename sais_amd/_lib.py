@@ -31,6 +31,7 @@ class SaisTnItem(ctypes.Structure):
 EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
 EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
+EPI_BIAS_GELU_GRAD_BF16, EPI_MUL_BF16 = 10, 11
 
 # name -> argtypes; every symbol include/sais_hip.h declares (checked by tests/test_abi.py)
 SIGNATURES = {

@@ -78,6 +78,14 @@ DEVINL float dgelu_erf(float u) {
     return fmaf(u * 0.3989422804014327f, e, 0.5f * (1.0f + copysignf(ea, u)));
 }
 
+DEVINL void gelu_and_grad(float u, float& y, float& dy) {      // both from one erf/exp evaluation
+    float ea, e;
+    erf_parts(u, ea, e);
+    const float cdf = 0.5f * (1.0f + copysignf(ea, u));
+    y = u * cdf;
+    dy = fmaf(u * 0.3989422804014327f, e, cdf);
+}
+
 // hipGetLastError is sticky across the whole process (torch included): clear it on entry so that
 // sais_check_launch() reports only this call's own launch status.
 #define SAIS_ENTER() (void)hipGetLastError()

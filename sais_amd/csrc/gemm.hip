@@ -66,7 +66,7 @@ DEVINL void epilogue_loads(const NtParams& p, int mbase, int li, int n, float (&
             const float* r = (const float*)p.aux + row * p.ldaux + n;
 #pragma unroll
             for (int i = 0; i < 4; ++i) a.r[mt][i] = *(const f32x4*)(r + 4 * i);
-        } else if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16) {
+        } else if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16 || EPI == SAIS_EPI_MUL_BF16) {
             const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;
             a.u[mt][0] = *(const bf16x8*)u;
             a.u[mt][1] = *(const bf16x8*)(u + 8);
@@ -115,6 +115,16 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16], cons
         if (p.out2) store_bf16(p.out2, p.ldo2, y);          // pre-activation u (training)
 #pragma unroll
         for (int i = 0; i < 16; ++i) y[i] = gelu_erf(y[i]);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) {
+        float d[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gelu_and_grad(y[i], y[i], d[i]);
+        store_bf16(p.out2, p.ldo2, d);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[i] *= (float)a.u[mt][i >> 3][i & 7];
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
 #pragma unroll
@@ -607,7 +617,11 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // than the 128x128 kernel below (its consumers stall ~7.8k cycles per tile issuing the epilogue stores): it is
     // opt-in (SAIS_GEMM_WS=1) until the store hand-off to the idle loader waves lands.
     static const bool use_ws = [] { const char* e = getenv("SAIS_GEMM_WS"); return e && e[0] == '1'; }();
-    if (use_ws && g->M >= 8192) {
+    if (g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 && !g->out2) return SAIS_ERR_ARG;
+    if ((g->epilogue == SAIS_EPI_MUL_BF16 || g->epilogue == SAIS_EPI_DGELU_BF16 || g->epilogue == SAIS_EPI_DRELU_BF16 ||
+         g->epilogue == SAIS_EPI_BIAS_RESID_F32) && !g->aux)
+        return SAIS_ERR_ARG;
+    if (use_ws && g->M >= 8192 && g->epilogue != SAIS_EPI_BIAS_GELU_GRAD_BF16 && g->epilogue != SAIS_EPI_MUL_BF16) {
         int rc = sais_gemm_nt_ws_(g, stream);
         return rc ? rc : sais_check_launch();
     }
@@ -623,6 +637,8 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
         LAUNCH_NT(SAIS_EPI_DGELU_BF16)
         LAUNCH_NT(SAIS_EPI_DRELU_BF16)
         LAUNCH_NT(SAIS_EPI_PATCH_F32)
+        LAUNCH_NT(SAIS_EPI_BIAS_GELU_GRAD_BF16)
+        LAUNCH_NT(SAIS_EPI_MUL_BF16)
         default: return SAIS_ERR_ARG;
     }
     return sais_check_launch();

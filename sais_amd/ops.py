@@ -52,7 +52,7 @@ def _timed(tag, flops, nbytes, fn):
 
 
 _NT_NAMES = {0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_bf16", 5: "dgelu_bf16", 6: "drelu_bf16",
-             7: "patch_f32", 8: "relu_f32", 9: "drelu_f32"}
+             7: "patch_f32", 8: "relu_f32", 9: "drelu_f32", 10: "gelu_grad_bf16", 11: "mul_bf16"}
 
 
 def _chk(t, dtype, name):

@@ -219,13 +219,14 @@ class VisionTransformer(nn.Module):
             ops.layernorm_fwd(x_mid, M, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2,
                               mean=mean2, rstd=rstd2)
             u = e16(M, HID) if save else None
-            ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_BF16, h, bias=f.w32(p + "mlp.fc1.bias"), out2=u)
+            ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
+                        bias=f.w32(p + "mlp.fc1.bias"), out2=u)
             x_out = e32(M, D) if save else x
             ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"),
                         aux=x_mid)
             if save:
                 saved["blocks"].append(dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=lse,
-                                            x_mid=x_mid, mean2=mean2, rstd2=rstd2, xn2=xn2, u=u, h=h))
+                                            x_mid=x_mid, mean2=mean2, rstd2=rstd2, xn2=xn2, dgelu=u, h=h))
             x = x_out
         reps = e32(Fr, D)
         meanN = e32(Fr) if save else None
@@ -284,7 +285,7 @@ class VisionTransformer(nn.Module):
             dxa, dxc = A[k], A[(k + 1) % 3]
             dxb, du, dqkv = B[k % nset], U[k % nset], Q[k % nset]
             # MLP branch
-            ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_DGELU_BF16, du, aux=s["u"])
+            ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
             ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
             ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
                               dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))

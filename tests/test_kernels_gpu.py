@@ -91,6 +91,19 @@ def test_gemm_nt_epilogues(ops, M, N, K):
     assert_close(out, (ref - bias) * pf.grad, name="dgelu", **tol)
     ops.gemm_nt(a, w, L.EPI_DRELU_BF16, out, aux=pre)
     assert_close(out, (ref - bias) * (pre.float() > 0), name="drelu", **tol)
+    # training pair: forward stores gelu'(pre-activation), backward is a plain multiply
+    dg = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(a, w, L.EPI_BIAS_GELU_GRAD_BF16, out, bias=bias, out2=dg)
+    rf = ref.clone().requires_grad_(True)
+    F.gelu(rf).sum().backward()
+    assert_close(out, F.gelu(ref), name="gelu(+grad)", **tol)
+    assert_close(dg, rf.grad, name="gelu_grad", **tol)
+    ops.gemm_nt(a, w, L.EPI_MUL_BF16, out, aux=pre)
+    assert_close(out, (ref - bias) * pre.float(), name="mul", **tol)
+    with pytest.raises(L.SaisHipError):
+        ops.gemm_nt(a, w, L.EPI_BIAS_GELU_GRAD_BF16, out, bias=bias)             # out2 is mandatory
+    with pytest.raises(L.SaisHipError):
+        ops.gemm_nt(a, w, L.EPI_MUL_BF16, out)                                   # aux is mandatory
 
 
 def test_gemm_patch_epilogue(ops):

@@ -12,8 +12,8 @@ from sais_amd import ops  # noqa: E402
 
 M = 50432
 NT = [("qkv      N1152 K384 ", 1152, 384, L.EPI_BIAS_BF16), ("proj     N384  K384 ", 384, 384, L.EPI_BIAS_RESID_F32),
-      ("fc1+gelu N1536 K384 ", 1536, 384, L.EPI_BIAS_GELU_BF16), ("fc2+res  N384  K1536", 384, 1536, L.EPI_BIAS_RESID_F32),
-      ("dX fc2   N1536 K384 ", 1536, 384, L.EPI_DGELU_BF16), ("dX fc1   N384  K1536", 384, 1536, L.EPI_BIAS_BF16),
+      ("fc1+gelu N1536 K384 ", 1536, 384, L.EPI_BIAS_GELU_GRAD_BF16), ("fc2+res  N384  K1536", 384, 1536, L.EPI_BIAS_RESID_F32),
+      ("dX fc2   N1536 K384 ", 1536, 384, L.EPI_MUL_BF16), ("dX fc1   N384  K1536", 384, 1536, L.EPI_BIAS_BF16),
       ("dX qkv   N384  K1152", 384, 1152, L.EPI_BIAS_BF16), ("dX proj  N384  K384 ", 384, 384, L.EPI_BIAS_BF16)]
 TN = [("dW qkv  1152x384 ", 1152, 384), ("dW proj 384x384  ", 384, 384), ("dW fc1  1536x384 ", 1536, 384),
       ("dW fc2  384x1536 ", 384, 1536)]
@@ -38,8 +38,8 @@ def main():
         a, w, bias = r16(M, K), r16(N, K) * 0.05, torch.randn(N, device=dev)
         f32 = epi in (L.EPI_BIAS_RESID_F32,)
         out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
-        aux = torch.randn(M, N, device=dev) if f32 else (r16(M, N) if epi == L.EPI_DGELU_BF16 else None)
-        out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == L.EPI_BIAS_GELU_BF16 else None
+        aux = torch.randn(M, N, device=dev) if f32 else (r16(M, N) if epi == L.EPI_MUL_BF16 else None)
+        out2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == L.EPI_BIAS_GELU_GRAD_BF16 else None
         fn = lambda: ops.gemm_nt(a, w, epi, out, bias=bias, out2=out2, aux=aux)
         fn(); ms = timeit(fn)
         fl = 2.0 * M * N * K
