@@ -10,7 +10,7 @@ import torch  # noqa: F401  -- must come first: libsais_hip.so has to bind to th
 #                             otherwise two runtimes coexist and launches fail with "no ROCm-capable device"
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsais_hip.so")
+LIB_PATH = os.environ.get("SAIS_HIP_LIB") or os.path.join(_HERE, "libsais_hip.so")      # override: profiling builds
 
 c_void_p, c_int, c_long, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
