@@ -231,6 +231,168 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Register-stationary NT GEMM for K = 384 (every D-wide contraction of the ViT: qkv, proj, fc1, and the dX GEMMs
+// of fc2 and proj).  With K that small the 128x128 kernel above spends its time re-filling LDS: 196 KiB of A and W
+// per 12.6-MFLOP tile, a prologue and an epilogue for only six K-steps.  Here a workgroup owns a 128-row panel of A
+// and KEEPS IT IN REGISTERS (each wave: its 64 rows x 384 k as 48 MFMA fragments = 192 VGPRs, loaded straight from
+// global memory in fragment layout, never through LDS) while it walks the panel's 128-column tiles; only the weight
+// tiles stream through LDS, as one continuous sequence of 16-KiB chunks (128 weight rows x 64 k) in a four-slot
+// ring that keeps running across tile boundaries, so the next tile's first chunks land during the epilogue.
+// One wave per SIMD (the registers do not allow more): global->VGPR->LDS staging, whose issue does not stall the
+// wave the way LDS-DMA does.  Per chunk and wave: 4 ds_write_b128 (chunk q+2), 4 global loads (chunk q+3),
+// 8 ds_read_b128, 32 MFMAs, one s_barrier.
+// Work units: one per panel for the first multiple-of-256 panels, the remaining panels split into column pieces so
+// that the last round of workgroups is short (host picks the split).
+struct RsSched {
+    int full_panels;      // units [0, full_panels): whole panel, all N tiles
+    int pieces;           // later units: panel = full_panels + v / pieces, tiles [ (v % pieces) * tpp, ... )
+    int tpp;              // tiles per piece
+};
+
+constexpr int RS_KSTEPS = 12;           // 384 / 32
+constexpr int RS_CHUNK = 128 * 128;     // bytes: 128 weight rows x 64 k x bf16
+
+template <int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_rs_kernel(NtParams p, RsSched sc) {
+    __shared__ __attribute__((aligned(16))) char ring[4 * RS_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
+    const int ntn = p.N / BN;
+    int panel, t0, t1;
+    if ((int)blockIdx.x < sc.full_panels) { panel = blockIdx.x; t0 = 0; t1 = ntn; }
+    else {
+        const int v = blockIdx.x - sc.full_panels;
+        panel = sc.full_panels + v / sc.pieces;
+        t0 = (v % sc.pieces) * sc.tpp;
+        t1 = min(ntn, t0 + sc.tpp);
+    }
+    const int m0 = panel * BM;
+
+    // weight chunk q of this unit = tile t0 + q/6, k range (q%6)*64: this wave stages LDS rows 32w .. 32w+31.
+    // Three staging register sets (chunk index mod 3; six chunks per tile keep that static): a chunk is loaded five
+    // iterations before it is consumed and written to LDS two iterations before, so neither the L2 latency (~2k cycles
+    // under load, i.e. more than two chunk times) nor the ds_write sits on the MFMA path.
+    const int srow = lane >> 3, schunk = lane & 7;
+    u32x4 st[3][4];
+    const int nq = (t1 - t0) * 6;
+    // buffer loads: address = descriptor base + SGPR offset (tile, k) + a per-lane byte offset fixed for the whole
+    // kernel, so a chunk load costs no vector arithmetic (one wave per SIMD: every VALU cycle is taken from the MFMAs)
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.N * p.ldb * 2, 0x00020000);      // raw buffer over W
+    unsigned loff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) loff[i] = (unsigned)(perm_row(32 * wid + 8 * i + srow) * p.ldb + schunk * 8) * 2u;
+    auto gload = [&](int q, u32x4 (&dst)[4]) {
+        q = q < nq ? q : nq - 1;                       // past the end: re-load the last chunk (never consumed); keeps
+        const int tile = t0 + q / 6, c = q - (q / 6) * 6;   // the loop free of branches around memory instructions
+        const int soff = __builtin_amdgcn_readfirstlane((tile * BN * p.ldb + c * 64) * 2);      // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, loff[i], soff, 0);
+    };
+    auto lwrite = [&](int q, const u32x4 (&src)[4]) {
+        char* slot = ring + (q & 3) * RS_CHUNK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(slot + swz(32 * wid + 8 * i + srow, schunk)) = src[i];
+    };
+    gload(0, st[0]);
+    gload(1, st[1]);
+    gload(2, st[2]);
+
+    // the panel: fa[ks][mt] = rows m0 + wr*64 + mt*16 + li, k = 32 ks + 8 g .. +7
+    bf16x8 fa[RS_KSTEPS][4];
+#pragma unroll
+    for (int ks = 0; ks < RS_KSTEPS; ++ks)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int m = m0 + wr * 64 + mt * 16 + li;
+            m = m < p.M ? m : p.M - 1;                                   // clamp: rows >= M are never stored
+            fa[ks][mt] = *(const bf16x8*)(p.A + (size_t)m * p.lda + ks * 32 + g * 8);
+        }
+    lwrite(0, st[0]);
+    lwrite(1, st[1]);
+    gload(3, st[0]);
+    gload(4, st[1]);
+    // no blanket vmcnt(0) here: the compiler puts a counted wait at the first use of every A fragment, so the first
+    // tile starts as soon as its first two k-steps have arrived and the rest of the panel lands under its MFMAs
+    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): chunks 0 and 1 are in LDS
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    // fragments are read one half-chunk ahead: fb0 always holds (chunk q, k 0..31) on entry; chunk q+1 has been
+    // visible since the barrier that ended iteration q-1, so its first fragments are fetched under the second MFMA
+    // block of chunk q and no LDS latency is left between the barrier and the first MFMA
+    bf16x8 fb0[4], fb1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fb0[t] = *(const bf16x8*)(ring + swz(wc * 64 + t * 16 + li, g));
+    int q = 0;
+    for (int tile = t0; tile < t1; ++tile) {
+        const int n0 = tile * BN;
+        float bias[16];
+        EpiAux aux;
+#pragma unroll
+        for (int c = 0; c < 6; ++c, ++q) {
+            // the epilogue's own loads (bias, residual / multiplier rows) go out two chunks early
+            if (c == 4) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
+            const char* sb = ring + (q & 3) * RS_CHUNK;
+            const char* sn = ring + ((q + 1) & 3) * RS_CHUNK;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb1[t] = *(const bf16x8*)(sb + swz(wc * 64 + t * 16 + li, 4 + g));
+            lwrite(q + 2, st[(c + 2) % 3]);           // past the end it lands in a slot nobody reads any more
+            gload(q + 5, st[(c + 2) % 3]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb0[nt], fa[2 * c][mt], acc[mt][nt]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ds_read (fb1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // ds_write (chunk q+2)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // global load (chunk q+4)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fb0[t] = *(const bf16x8*)(sn + swz(wc * 64 + t * 16 + li, g));
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb1[nt], fa[2 * c + 1][mt], acc[mt][nt]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ds_read (fb0 of chunk q+1)
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave's ds_writes are in LDS (vmcnt/expcnt untouched)
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wr * 64 + mt * 16 + li;
+            float v[16];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[4 * nt + r] = acc[mt][nt][r]; acc[mt][nt][r] = 0.f; }
+            epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v, bias, aux, mt);       // whole panels only: no row guard
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NT with fp32 operands at ~fp32 accuracy on the bf16 matrix cores ("bf16x3"): every operand is split
 // while staging into hi = bf16(x), lo = bf16(x - hi) and the product is accumulated as
 // a_hi b_hi + a_hi b_lo + a_lo b_hi (the dropped lo*lo term is ~2^-18 relative).  Used for the temporal
@@ -627,6 +789,55 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     }
     NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
                g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off};
+    // Opt-in (SAIS_NT_RS=1).  Measured on MI355X (round 1, M = 50 432): at parity or slightly ahead of the 128x128
+    // kernel on the N = 1536 shapes (dX fc2 133 vs 142 us, fc1+gelu 182 vs 181 us), behind on qkv (90 vs 74 us) and on
+    // the N = 384 shapes whose units are only three tiles long (77 vs 62, 53 vs 36 us).  s_memtime stamps per
+    // workgroup: 15k cycles until the panel is in registers, then ~900 cycles per chunk for 512 cycles of MFMA and
+    // 2.4k cycles of epilogue per tile, all serial because the registers allow one wave per SIMD; ablations: LDS
+    // fragment reads cost nothing, weight staging 19 %, barriers 8 %.  See DESIGN.md §4.1.
+    static const bool use_rs = [] { const char* e = getenv("SAIS_NT_RS"); return e && e[0] == '1'; }();
+    if (use_rs && g->K == 384 && g->M >= 8192 && g->epilogue != SAIS_EPI_PATCH_F32) {
+        // unit schedule: whole panels for the first multiple of 256, the rest split into column pieces; pick the
+        // split that minimises (rounds x tiles per piece) + an A-panel load (~0.7 tile) per round
+        const int ntn = g->N / BN, P = g->M / BM, CUS = 256;          // whole panels; a ragged tail goes to the kernel below
+        RsSched sc{(P / CUS) * CUS, 1, ntn};
+        const int tail = P - sc.full_panels;
+        if (tail > 0) {
+            double best = 1e30;
+            for (int pp = 1; pp <= ntn; ++pp) {
+                const int tpp = (ntn + pp - 1) / pp, pieces = (ntn + tpp - 1) / tpp;
+                const int rounds = (tail * pieces + CUS - 1) / CUS;
+                const double cost = rounds * (tpp + 0.7);
+                if (cost < best) { best = cost; sc.pieces = pieces; sc.tpp = tpp; }
+            }
+        }
+        dim3 rgrid(sc.full_panels + tail * sc.pieces);
+        switch (g->epilogue) {
+#define LAUNCH_RS(E) case E: hipLaunchKernelGGL(gemm_nt_rs_kernel<E>, rgrid, dim3(256), 0, (hipStream_t)stream, p, sc); break;
+            LAUNCH_RS(SAIS_EPI_BIAS_BF16)
+            LAUNCH_RS(SAIS_EPI_BIAS_RELU_BF16)
+            LAUNCH_RS(SAIS_EPI_BIAS_F32)
+            LAUNCH_RS(SAIS_EPI_BIAS_RESID_F32)
+            LAUNCH_RS(SAIS_EPI_BIAS_GELU_BF16)
+            LAUNCH_RS(SAIS_EPI_DGELU_BF16)
+            LAUNCH_RS(SAIS_EPI_DRELU_BF16)
+            LAUNCH_RS(SAIS_EPI_BIAS_GELU_GRAD_BF16)
+            LAUNCH_RS(SAIS_EPI_MUL_BF16)
+#undef LAUNCH_RS
+            default: return SAIS_ERR_ARG;
+        }
+        const int done = P * BM;
+        if (done == g->M) return sais_check_launch();
+        if (sais_check_launch() != SAIS_OK) return SAIS_ERR_LAUNCH;
+        SaisGemm rest = *g;
+        rest.A = (const char*)g->A + (size_t)done * g->lda * 2;
+        rest.M = g->M - done;
+        const size_t osz = (g->epilogue == SAIS_EPI_BIAS_F32 || g->epilogue == SAIS_EPI_BIAS_RESID_F32) ? 4 : 2;
+        rest.out = (char*)g->out + (size_t)done * g->ldo * osz;
+        if (g->out2) rest.out2 = (char*)g->out2 + (size_t)done * g->ldo2 * 2;
+        if (g->aux) rest.aux = (const char*)g->aux + (size_t)done * g->ldaux * (g->epilogue == SAIS_EPI_BIAS_RESID_F32 ? 4 : 2);
+        return sais_gemm_nt(&rest, stream);            // M < 128 now: takes the 128x128 path
+    }
     dim3 grid((g->N / BN) * ((g->M + BM - 1) / BM));
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
