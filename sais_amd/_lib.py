@@ -48,7 +48,8 @@ SIGNATURES = {
                            c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                            c_void_p],
     "sais_vit_attn_fwd": [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
-    "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p],
+    "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p,
+                          c_long, c_void_p],
     "sais_patchify": [c_void_p, c_int, c_void_p, c_void_p],
     "sais_vit_cls_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "sais_vit_embed_bwd": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

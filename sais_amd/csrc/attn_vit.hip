@@ -154,11 +154,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
 }
 
 // ------------------------------------------------------------------------------------------ backward, dQ
-// Same orientation as forward (query on the lane).  P^T is rebuilt from the saved log-sum-exp,
-// dP^T = V dO^T, delta_q = sum_k P dP, dS^T = P (dP - delta) scale, dQ^T = K^T dS^T.
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
-                                                          const float* lse, float* delta, bf16* dqkv, long lddq,
-                                                          float scale) {
+// Same orientation as forward (query on the lane).  P^T is rebuilt from the saved log-sum-exp, dP^T = V dO^T,
+// dS^T = P (dP - delta) scale, dQ^T = K^T dS^T, with delta_q = sum_d dO[q,d] O[q,d] (= sum_k P dP, taken from the saved
+// forward output so that it is known BEFORE the key sweep).  That makes the sweep streaming: 32 keys at a time are
+// scored, turned into dS and fed to the dQ MFMAs, and nothing but the 16 dQ accumulators outlives a step.  The first
+// version kept the full 16 x 208 P and dP strips (104 fp32 registers + their copies out of the accumulator file):
+// 378 VGPRs, one wave per SIMD, 105 us per ViT block; this one fits two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+                                                             const bf16* out, long ldout, const float* lse,
+                                                             float* delta, bf16* dqkv, long lddq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = smem + MAT_BYTES;
@@ -166,52 +170,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* qkv, long 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
     const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
+    const bf16* ob = out + (size_t)f * NTOK * ldout + h * HD;
     stage_matrix(sK, base + DM, ldq, tid);
     stage_matrix(sV, base + 2 * DM, ldq, tid);
     __syncthreads();
     const float c = scale * LOG2E;
     const int nmine = tiles_of_wave(wid, (f * NH + h) & 3);
-    bf16x8 fq[2], fdo[2], fq_next[2], fdo_next[2];
+    bf16x8 fq[2], fdo[2], fo[2], fq_next[2], fdo_next[2], fo_next[2];
     load_q_frags(base, ldq, tile_id(wid, 0) * 16 + li, g, fq);
     load_q_frags(dob, ldo, tile_id(wid, 0) * 16 + li, g, fdo);
+    load_q_frags(ob, ldout, tile_id(wid, 0) * 16 + li, g, fo);
     for (int it = 0; it < nmine; ++it) {
         const int qt = tile_id(wid, it);
         const int q = qt * 16 + li, qc = q < NTOK ? q : NTOK - 1;
         if (it + 1 < nmine) {                                                   // prefetch the next tile's rows
             load_q_frags(base, ldq, tile_id(wid, it + 1) * 16 + li, g, fq_next);
             load_q_frags(dob, ldo, tile_id(wid, it + 1) * 16 + li, g, fdo_next);
+            load_q_frags(ob, ldout, tile_id(wid, it + 1) * 16 + li, g, fo_next);
         }
         const float nl2 = -lse[((size_t)f * NH + h) * NTOK + qc] * LOG2E;
-        f32x4 s[NKT];
-        score_strip(sK, fq, g, li, s);
         float dl = 0.f;
-        f32x4 dp[NKT];
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) {
-            f32x4 a = {0, 0, 0, 0};
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) a = mfma16(row_frag(sV, 16 * t + li, 4 * ks + g), fdo[ks], a);
-            dp[t] = a;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { float p = fast_exp2(__builtin_fmaf(s[t][r], c, nl2)); s[t][r] = p; dl = __builtin_fmaf(p, a[r], dl); }
-        }
-        fq[0] = fq_next[0]; fq[1] = fq_next[1]; fdo[0] = fdo_next[0]; fdo[1] = fdo_next[1];
+            for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)fdo[ks][e], (float)fo[ks][e], dl);
         dl = group_sum(dl);
-        // dS^T = P (dP - delta); the 1/sqrt(d) factor is applied to the 16 dQ outputs instead of the 52 scores
-#pragma unroll
-        for (int t = 0; t < NKT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - dl);
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
-        const f32x4 z4 = {0, 0, 0, 0};
-#pragma unroll
+#pragma unroll 1
         for (int ks = 0; ks < NKS; ++ks) {
-            bf16x8 pf = pack_p(s[2 * ks], (2 * ks + 1 < NKT) ? s[2 * ks + 1] : z4);
+            f32x4 ds[2];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int t = 2 * ks + half;
+                if (t >= NKT) { ds[half] = f32x4{0, 0, 0, 0}; continue; }
+                f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    sc = mfma16(row_frag(sK, 16 * t + li, 4 * kk + g), fq[kk], sc);
+                    dp = mfma16(row_frag(sV, 16 * t + li, 4 * kk + g), fdo[kk], dp);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = fast_exp2(__builtin_fmaf(sc[r], c, nl2));
+                    if (t == NKT - 1 && 192 + 4 * g + r >= NTOK) p = 0.f;      // keys past 197 (zero rows of K, V)
+                    ds[half][r] = p * (dp[r] - dl);
+                }
+            }
+            // the 1/sqrt(d) factor is applied to the 16 dQ outputs instead of the scores
+            const bf16x8 pf = pack_p(ds[0], ds[1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(sK, ks, dt, g, li), pf, o[dt]);
         }
+        fq[0] = fq_next[0]; fq[1] = fq_next[1]; fdo[0] = fdo_next[0]; fdo[1] = fdo_next[1];
+        fo[0] = fo_next[0]; fo[1] = fo_next[1];
         if (q < NTOK) {
             bf16* orow = dqkv + ((size_t)f * NTOK + q) * lddq + h * HD + 4 * g;
 #pragma unroll
@@ -330,14 +343,17 @@ extern "C" int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* 
     return sais_check_launch();
 }
 
-extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const float* lse,
-                                 float* delta_ws, int frames, void* dqkv, long lddqkv, void* stream) {
+extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout,
+                                 const float* lse, float* delta_ws, int frames, void* dqkv, long lddqkv,
+                                 void* stream) {
     SAIS_ENTER();
-    if (!qkv || !dout || !lse || !delta_ws || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) || (lddqkv & 3))
+    if (!qkv || !dout || !out || !lse || !delta_ws || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) ||
+        (ldout & 7) || (lddqkv & 3))
         return SAIS_ERR_ARG;
     if (set_lds(attn_bwd_dq_kernel, FWD_LDS) || set_lds(attn_bwd_dkv_kernel, DKV_LDS)) return SAIS_ERR_LAUNCH;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(NH, frames), dim3(256), FWD_LDS, (hipStream_t)stream,
-                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, lse, delta_ws, (bf16*)dqkv, lddqkv, 0.125f);
+                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, delta_ws,
+                       (bf16*)dqkv, lddqkv, 0.125f);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(NH, frames), dim3(256), DKV_LDS, (hipStream_t)stream,
                        (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, lse, delta_ws, (bf16*)dqkv, lddqkv, 0.125f);
     return sais_check_launch();

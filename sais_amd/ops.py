@@ -154,10 +154,12 @@ def vit_attn_fwd(qkv, frames, out, lse=None, probs=None):
                           _p(probs), _stream()))
 
 
-def vit_attn_bwd(qkv, dout, lse, delta_ws, frames, dqkv):
-    _timed("vit_attn_bwd", 10.0 * frames * 6 * 197 * 197 * 64, 2 * frames * 197 * 384 * 8,
-           lambda: L.call("sais_vit_attn_bwd", _p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(lse), _p(delta_ws),
-                          frames, _p(dqkv), dqkv.stride(0), _stream()))
+def vit_attn_bwd(qkv, dout, out, lse, delta_ws, frames, dqkv):
+    """out = the forward attention output (bf16 [frames*197, 384]) saved by vit_attn_fwd."""
+    _chk(out, BF16, "out")
+    _timed("vit_attn_bwd", 10.0 * frames * 6 * 197 * 197 * 64, 2 * frames * 197 * 384 * 9,
+           lambda: L.call("sais_vit_attn_bwd", _p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(out), out.stride(0),
+                          _p(lse), _p(delta_ws), frames, _p(dqkv), dqkv.stride(0), _stream()))
 
 
 def patchify(frames_f32, patches):

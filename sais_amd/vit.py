@@ -291,7 +291,7 @@ class VisionTransformer(nn.Module):
                               dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))
             # attention branch
             ops.gemm_nt(dxb, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
-            ops.vit_attn_bwd(s["qkv"], dao, s["lse"], delta, Fr, dqkv)
+            ops.vit_attn_bwd(s["qkv"], dao, s["ao"], s["lse"], delta, Fr, dqkv)
             # all four weight / bias gradients of the block in one launch (108 output tiles)
             if overlap:
                 ev = torch.cuda.Event()

@@ -198,7 +198,7 @@ def test_vit_attention_fwd_bwd(ops):
     ref.backward(dout.float())
     dqkv = torch.full((frames * 197, 1152), float("nan"), dtype=torch.bfloat16, device=DEV)
     delta = torch.empty(frames, 6, 197, device=DEV)
-    ops.vit_attn_bwd(qkv, dout, lse, delta, frames, dqkv)
+    ops.vit_attn_bwd(qkv, dout, out, lse, delta, frames, dqkv)
     g = qr.grad
     scale = g.abs().max().item()
     assert_close(dqkv, g, atol=2e-2 * scale, rtol=2e-2, name="dqkv")

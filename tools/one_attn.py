@@ -18,5 +18,5 @@ delta = torch.empty(F, 6, 197, device="cuda")
 dqkv = torch.empty(F * 197, 1152, device="cuda", dtype=torch.bfloat16)
 for _ in range(3):
     ops.vit_attn_fwd(qkv, F, out, lse)
-    ops.vit_attn_bwd(qkv, dout, lse, delta, F, dqkv)
+    ops.vit_attn_bwd(qkv, dout, out, lse, delta, F, dqkv)
 torch.cuda.synchronize()
