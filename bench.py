@@ -46,7 +46,7 @@ def build(dev, B, T, C, lr):
     return vit, model, protos, opt
 
 
-def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world):
+def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on=False):
     from sais_amd.loss import calcNCELoss
     from sais_amd.loss import label_columns
     names = [f"v_{i}" for i in range(B)]
@@ -59,7 +59,7 @@ def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world):
         emb, attn = model(reps, None, lens, None, 'Prototypes', pad, None, None)
         loss = calcNCELoss(0, emb, labels, names, protos, None)
         loss.backward()
-        if world > 1:
+        if dist_on:
             sync.reduce_params(protos.values())
             sync.wait()
         opt.step(grad_scale=1.0 / world)
@@ -130,14 +130,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # SAIS_BENCH_FORCE_DIST=1 (with torchrun --nproc-per-node 1) takes the distributed code path on a 1-GPU box:
+    # RCCL init, gradient all-reduce from the backward hooks, barriers, max-over-ranks timing
+    dist_on = world > 1 or (os.environ.get("SAIS_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if dist_on:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import synth
@@ -148,15 +151,15 @@ def main():
     pad = synth.padding_mask([T] * B).to(dev)
     labels = synth.labels(seed=rank, B=B, nclasses=C)
     from sais_amd.parallel import GradSync
-    sync = GradSync(world)
-    step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world)
+    sync = GradSync(world, active=dist_on)
+    step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on)
     vit(frames[:2])                                          # builds the flat buffers
     model._engine(dev)
     vit.grad_ready_hook = sync.vit_hook(vit)
     model.grad_ready_hook = sync.temporal_hook(model, T)
 
     eager_step = step
-    use_graph = world == 1 and not args.no_graph
+    use_graph = not dist_on and not args.no_graph
     if use_graph:                                            # DP runs eagerly (RCCL collectives from hooks)
         from sais_amd.graph import GraphedStep
         step = GraphedStep(eager_step, warmup=2)
@@ -165,7 +168,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +178,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
@@ -202,7 +205,7 @@ def main():
                     all_kernels={n: dict(ms_per_step=round(v["total_ms"] / 2, 3),
                                          tflops=round(v["flops"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
                                          gbps=round(v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9, 1)) for n, v in summ.items()})
-    if world > 1:
+    if dist_on:
         dist.barrier()
 
     if rank == 0:
@@ -231,7 +234,7 @@ def main():
             # hosts get much slower), so use at most 32 of the host's cores; `cores` reports what was used
             out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
