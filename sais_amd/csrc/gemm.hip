@@ -762,6 +762,115 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup gp) {
     else tn_tile<bf16>(p, (t / nt2) * 128, (t % nt2) * 128, mbeg, mend, smem);
 }
 
+// Wide variant of the grouped dW kernel: 128 (P columns) x 384 (Q columns) output tile per 512-thread workgroup
+// (8 waves as 2 x 4, 64 x 96 per wave), used when every item has N2 % 384 == 0 (all four dW of a ViT block do).
+// The 128x128 kernel above is paced by its global->LDS fill stream (ablation in DESIGN.md 4.1: 2.8 GB of fills per
+// launch, DMA-only 223 us vs 166 us of MFMA work); this tile needs a third fewer fill bytes per flop: 64 KiB per
+// 64-row step (P 16 KiB + three 128-column blocks of Q) for 2 x 128 x 384 x 64 flop.  Two 64-KiB stages = 128 KiB of
+// LDS, one workgroup per CU; 36 tiles x 7 M-splits = 252 workgroups fill the 256 CUs in one round.
+constexpr int WQ = 384;
+constexpr int WBLK = 64 * 256;                 // one 64-row x 128-column block, 16 KiB
+constexpr int WSTAGE = 4 * WBLK;               // P block + 3 Q blocks
+
+struct TnWideGroup {
+    TnParams item[SAIS_TN_MAX_ITEMS];
+    int tile_end[SAIS_TN_MAX_ITEMS];
+    int nitems, ntiles;
+};
+
+__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
+    extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / gp.ntiles;
+    int t = wg - split * gp.ntiles, it0 = 0;
+    while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;
+    if (it0 > 0) t -= gp.tile_end[it0 - 1];
+    const TnParams& p = gp.item[it0];
+    const int nt2 = p.N2 / WQ;
+    const int n1_0 = (t / nt2) * 128, n2_0 = (t % nt2) * WQ;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    if (mbeg >= mend) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
+    // LDS-DMA: wave w fills half (w & 1) of block (w >> 1) of every stage: 8 pieces of 4 rows x 256 B
+    const int blk = wid >> 1;
+    const bf16* src0 = blk == 0 ? (const bf16*)p.P + n1_0 : (const bf16*)p.Q + n2_0 + (blk - 1) * 128;
+    const int ld = blk == 0 ? p.ldp : p.ldq;
+    const bf16* psrc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 4 * (8 * (wid & 1) + j) + (lane >> 4);
+        const int c = lane & 15, u = (c >> 1) ^ (r & 7);
+        psrc[j] = src0 + (size_t)(mbeg + r) * ld + u * 16 + (c & 1) * 8;
+    }
+    const int nsteps = (mend - mbeg) / TK;                        // host guarantees whole 64-row steps
+    auto issue = [&](int stage, int step) {
+        char* s = wsmem + stage * WSTAGE + blk * WBLK + (8 * (wid & 1)) * 1024;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) glds16(psrc[j] + (size_t)step * TK * ld, s + j * 1024);
+    };
+    f32x4 acc[4][6];
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    }
+    const bool do_bias = p.db != nullptr && n2_0 == 0 && wc == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+    const int q4 = li >> 2, p4 = li & 3;
+    issue(0, 0);
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps) issue(cur ^ 1, st + 1);
+        const char* sp = wsmem + cur * WSTAGE;
+        const char* sq = sp + WBLK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fp[4], fq[6];
+            const int row = ks * 32 + 4 * g + q4;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int cp = wr * 64 + tt * 16 + 4 * p4;
+                fp[tt] = cat4(lds_read_tr16(tr_addr(sp, row, cp)), lds_read_tr16(tr_addr(sp, row + 16, cp)));
+            }
+#pragma unroll
+            for (int tt = 0; tt < 6; ++tt) {
+                const int c = wc * 96 + tt * 16;
+                const char* qb = sq + (c >> 7) * WBLK;
+                const int cq = (c & 127) + 4 * p4;
+                fq[tt] = cat4(lds_read_tr16(tr_addr(qb, row, cq)), lds_read_tr16(tr_addr(qb, row + 16, cq)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16(fp[i], fq[j], acc[i][j]);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) accb[i] = mfma16(fp[i], ones, accb[i]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n1 = n1_0 + wr * 64 + i * 16 + 4 * g + r;
+            float* row = p.dW + (size_t)n1 * p.ldw + n2_0 + wc * 96 + li;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) atomicAdd(row + j * 16, acc[i][j][r]);
+            if (do_bias && li == 0) atomicAdd(p.db + n1, accb[i][r]);
+        }
+}
+
 }  // namespace
 
 #define LAUNCH_NT(E)                                                                        \
@@ -958,6 +1067,34 @@ extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, 
         gp.tile_end[i] = total;
     }
     gp.ntiles = total;
+    // wide tiles (128 x 384) when every item allows them and M is a whole number of 64-row steps
+    static const bool allow_wide = [] { const char* e = getenv("SAIS_TN_WIDE"); return !(e && e[0] == '0'); }();
+    bool wide = allow_wide && M % TK == 0 && M >= 8192;
+    for (int i = 0; i < nitems && wide; ++i) wide = items[i].N2 % WQ == 0;
+    if (wide) {
+        TnWideGroup wg;
+        wg.nitems = nitems;
+        int wt = 0;
+        for (int i = 0; i < nitems; ++i) {
+            wt += (items[i].N1 / 128) * (items[i].N2 / WQ);
+            wg.tile_end[i] = wt;
+        }
+        wg.ntiles = wt;
+        // one workgroup per CU: as many M-splits as keep the grid within one round of 256
+        int wns = 256 / wt < 1 ? 1 : 256 / wt;
+        int wrows = ((M + wns - 1) / wns + TK - 1) / TK * TK;
+        wns = (M + wrows - 1) / wrows;
+        for (int i = 0; i < nitems; ++i) { wg.item[i] = gp.item[i]; wg.item[i].rows_per_split = wrows; }
+        static thread_local bool lds_set = false;
+        if (!lds_set) {
+            if (hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    2 * WSTAGE) != hipSuccess)
+                return SAIS_ERR_LAUNCH;
+            lds_set = true;
+        }
+        hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg);
+        return sais_check_launch();
+    }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total * ns), dim3(256), 0, (hipStream_t)stream, gp);
     return sais_check_launch();
 }
