@@ -803,14 +803,24 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int r = 4 * (8 * (wid & 1) + j) + (lane >> 4);
-        const int c = lane & 15, u = (c >> 1) ^ (r & 7);
-        psrc[j] = src0 + (size_t)(mbeg + r) * ld + u * 16 + (c & 1) * 8;
+        const int c = lane & 15;
+        psrc[j] = src0 + (size_t)(mbeg + r) * ld + c * 8;           // natural order: the swizzle is applied on the LDS side
     }
     const int nsteps = (mend - mbeg) / TK;                        // host guarantees whole 64-row steps
-    auto issue = [&](int stage, int step) {
-        char* s = wsmem + stage * WSTAGE + blk * WBLK + (8 * (wid & 1)) * 1024;
+    // global -> VGPR -> LDS staging: a plain vector load does not hold the wave the way an LDS-DMA issue does, so the
+    // MFMAs of the current step start at once and the next tile lands in registers underneath them
+    u32x4 stg[8];
+    auto gload = [&](int step) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) glds16(psrc[j] + (size_t)step * TK * ld, s + j * 1024);
+        for (int j = 0; j < 8; ++j) stg[j] = *(const u32x4*)(psrc[j] + (size_t)step * TK * ld);
+    };
+    auto lwrite = [&](int stage) {
+        char* s = wsmem + stage * WSTAGE + blk * WBLK;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 4 * (8 * (wid & 1) + j) + (lane >> 4), c = lane & 15;
+            *(u32x4*)(s + r * 256 + ((((c >> 1) ^ (r & 7)) << 5) | ((c & 1) << 4))) = stg[j];
+        }
     };
     f32x4 acc[4][6];
     f32x4 accb[4];
@@ -825,11 +835,12 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
     const int q4 = li >> 2, p4 = li & 3;
-    issue(0, 0);
+    gload(0);
+    lwrite(0);
     __syncthreads();
     for (int st = 0; st < nsteps; ++st) {
         const int cur = st & 1;
-        if (st + 1 < nsteps) issue(cur ^ 1, st + 1);
+        if (st + 1 < nsteps) gload(st + 1);
         const char* sp = wsmem + cur * WSTAGE;
         const char* sq = sp + WBLK;
 #pragma unroll
@@ -857,6 +868,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
                 for (int i = 0; i < 4; ++i) accb[i] = mfma16(fp[i], ones, accb[i]);
             }
         }
+        if (st + 1 < nsteps) lwrite(cur ^ 1);          // stage cur^1 was last read in step st-1 (barrier since)
         __syncthreads();
     }
 #pragma unroll
