@@ -799,27 +799,25 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
     const int blk = wid >> 1;
     const bf16* src0 = blk == 0 ? (const bf16*)p.P + n1_0 : (const bf16*)p.Q + n2_0 + (blk - 1) * 128;
     const int ld = blk == 0 ? p.ldp : p.ldq;
-    const bf16* psrc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int r = 4 * (8 * (wid & 1) + j) + (lane >> 4);
-        const int c = lane & 15;
-        psrc[j] = src0 + (size_t)(mbeg + r) * ld + c * 8;           // natural order: the swizzle is applied on the LDS side
-    }
+    // one per-lane base pointer; piece j and the step add a wave-uniform row offset
+    const bf16* pbase = src0 + (size_t)(mbeg + 32 * (wid & 1) + (lane >> 4)) * ld + (lane & 15) * 8;
     const int nsteps = (mend - mbeg) / TK;                        // host guarantees whole 64-row steps
     // global -> VGPR -> LDS staging: a plain vector load does not hold the wave the way an LDS-DMA issue does, so the
     // MFMAs of the current step start at once and the next tile lands in registers underneath them
-    u32x4 stg[8];
-    auto gload = [&](int step) {
+    // two tiles are in flight in registers (the one written to LDS at the end of this step and the one after it): a
+    // first-touch row slab comes from HBM, and one step (~2 us) is not enough to cover that latency
+    u32x4 stg[2][8];
+    auto gload = [&](int step, u32x4 (&dst)[8]) {
+        step = step < nsteps ? step : nsteps - 1;                       // past the end: harmless reload
 #pragma unroll
-        for (int j = 0; j < 8; ++j) stg[j] = *(const u32x4*)(psrc[j] + (size_t)step * TK * ld);
+        for (int j = 0; j < 8; ++j) dst[j] = *(const u32x4*)(pbase + (size_t)(step * TK + 4 * j) * ld);
     };
-    auto lwrite = [&](int stage) {
+    auto lwrite = [&](int stage, const u32x4 (&src)[8]) {
         char* s = wsmem + stage * WSTAGE + blk * WBLK;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = 4 * (8 * (wid & 1) + j) + (lane >> 4), c = lane & 15;
-            *(u32x4*)(s + r * 256 + ((((c >> 1) ^ (r & 7)) << 5) | ((c & 1) << 4))) = stg[j];
+            *(u32x4*)(s + r * 256 + ((((c >> 1) ^ (r & 7)) << 5) | ((c & 1) << 4))) = src[j];
         }
     };
     f32x4 acc[4][6];
@@ -835,17 +833,12 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
     const int q4 = li >> 2, p4 = li & 3;
-    gload(0);
-    lwrite(0);
-    __syncthreads();
-    for (int st = 0; st < nsteps; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < nsteps) gload(st + 1);
+    auto compute = [&](int cur) {
         const char* sp = wsmem + cur * WSTAGE;
         const char* sq = sp + WBLK;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fp[4], fq[6];
+            bf16x8 fp[4], fq[3];
             const int row = ks * 32 + 4 * g + q4;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
@@ -853,23 +846,43 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
                 fp[tt] = cat4(lds_read_tr16(tr_addr(sp, row, cp)), lds_read_tr16(tr_addr(sp, row + 16, cp)));
             }
 #pragma unroll
-            for (int tt = 0; tt < 6; ++tt) {
-                const int c = wc * 96 + tt * 16;
-                const char* qb = sq + (c >> 7) * WBLK;
-                const int cq = (c & 127) + 4 * p4;
-                fq[tt] = cat4(lds_read_tr16(tr_addr(qb, row, cq)), lds_read_tr16(tr_addr(qb, row + 16, cq)));
+            for (int h = 0; h < 2; ++h) {                         // Q fragments in two halves: 12 live registers less
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) {
+                    const int c = wc * 96 + (3 * h + tt) * 16;
+                    const char* qb = sq + (c >> 7) * WBLK;
+                    const int cq = (c & 127) + 4 * p4;
+                    fq[tt] = cat4(lds_read_tr16(tr_addr(qb, row, cq)), lds_read_tr16(tr_addr(qb, row + 16, cq)));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][3 * h + j] = mfma16(fp[i], fq[j], acc[i][3 * h + j]);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[i][j] = mfma16(fp[i], fq[j], acc[i][j]);
             if (do_bias) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) accb[i] = mfma16(fp[i], ones, accb[i]);
             }
         }
-        if (st + 1 < nsteps) lwrite(cur ^ 1);          // stage cur^1 was last read in step st-1 (barrier since)
+    };
+    gload(0, stg[0]);
+    gload(1, stg[1]);
+    lwrite(0, stg[0]);
+    gload(2, stg[0]);
+    __syncthreads();
+    // step st: stage st&1 holds tile st; stg[(st+1)&1] holds tile st+1 (written to LDS at the end of the step) and tile
+    // st+2 is on its way into stg[st&1]; unrolled by two so that the register sets are static
+    for (int st = 0; st < nsteps; st += 2) {
+        compute(0);
+        lwrite(1, stg[1]);
+        gload(st + 3, stg[1]);
         __syncthreads();
+        if (st + 1 < nsteps) {
+            compute(1);
+            lwrite(0, stg[0]);
+            gload(st + 4, stg[0]);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
