@@ -230,6 +230,94 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     }
 }
 
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_a3_kernel(NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
+    const int ntn = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
+
+    // wave w issues pieces 4w..4w+3 of each operand tile; piece q = LDS rows 8q..8q+7
+    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
+    const bf16* asrc[4]; const bf16* bsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (4 * wid + j) + sub;
+        int m = m0 + r;
+        m = m < p.M ? m : p.M - 1;                                   // clamp: rows >= M are never stored
+        asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
+        bsrc[j] = p.B + (size_t)(n0 + perm_row(r)) * p.ldb + schunk * 8;
+    }
+    // A (activations / gradients: first-touch HBM data) runs TWO K-tiles ahead in a three-slot ring, W (L2-resident)
+    // one K-tile ahead in two slots; the end-of-step wait is counted so that the youngest A tile stays in flight
+    char* const sW = smem + 3 * TILE_BYTES;
+    auto issue_a = [&](int kt) {
+        char* s = smem + (kt % 3) * TILE_BYTES + (4 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(asrc[j] + kt * BK, s + j * 1024);
+    };
+    auto issue_w = [&](int kt) {
+        char* s = sW + (kt & 1) * TILE_BYTES + (4 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + kt * BK, s + j * 1024);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    const int nk = p.K / BK;
+    issue_a(0);
+    issue_w(0);
+    if (nk > 1) issue_a(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue_w(kt + 1);
+        if (kt + 2 < nk) issue_a(kt + 2);
+        const char* sa = smem + (kt % 3) * TILE_BYTES;
+        const char* sb = sW + (kt & 1) * TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = *(const bf16x8*)(sa + swz(wr * 64 + t * 16 + li, ks * 4 + g));
+                fb[t] = *(const bf16x8*)(sb + swz(wc * 64 + t * 16 + li, ks * 4 + g));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
+        }
+        // A(kt+1) and W(kt+1) must have landed; A(kt+2), the 4 youngest pieces, may still be in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*64 + 16 g + (4 nt + r)
+    float bias[16];
+    EpiAux aux;
+    epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int m = m0 + wr * 64 + mt * 16 + li;
+        if (m >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+        epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v, bias, aux, mt);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Register-stationary NT GEMM for K = 384 (every D-wide contraction of the ViT: qkv, proj, fc1, and the dX GEMMs
 // of fc2 and proj).  With K that small the 128x128 kernel above spends its time re-filling LDS: 196 KiB of A and W
@@ -900,7 +988,17 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
+        if (a3) {                                                                           \
+            static thread_local bool set = false;                                           \
+            if (!set) {                                                                     \
+                if (hipFuncSetAttribute((const void*)gemm_nt_a3_kernel<E>,                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES) != hipSuccess) \
+                    return SAIS_ERR_LAUNCH;                                                 \
+                set = true;                                                                 \
+            }                                                                               \
+            hipLaunchKernelGGL(gemm_nt_a3_kernel<E>, grid, dim3(256), 5 * TILE_BYTES, (hipStream_t)stream, p); \
+        } else                                                                              \
+            hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
         break;
 
 extern "C" int sais_gemm_nt_ws_(const SaisGemm* g, void* stream);       // gemm_ws.hip: wave-specialised, persistent
@@ -973,6 +1071,13 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
         return sais_gemm_nt(&rest, stream);            // M < 128 now: takes the 128x128 path
     }
     dim3 grid((g->N / BN) * ((g->M + BM - 1) / BM));
+    // Three-slot A ring (gemm_nt_a3_kernel, 80 KiB of LDS): measured per epilogue at M = 50 432 — it pays where the
+    // epilogue is heavy (fp32 residual: fc2 128 -> 114 us, proj 62 -> 60; GELU: 175 -> 169) and costs a little on the
+    // plain bf16 ones (dX fc1 77 -> 83 us), so it is selected by epilogue.  SAIS_NT_A3=0 / 1 forces it off / on.
+    static const int a3_env = [] { const char* e = getenv("SAIS_NT_A3"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool heavy = g->epilogue == SAIS_EPI_BIAS_RESID_F32 || g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 ||
+                       g->epilogue == SAIS_EPI_BIAS_GELU_BF16;
+    const bool a3 = g->M >= 8192 && (a3_env < 0 ? heavy : a3_env == 1);
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)
