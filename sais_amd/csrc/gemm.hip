@@ -192,11 +192,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     const int nk = p.K / BK;
     issue(0, 0);
     __syncthreads();
+    // the epilogue's own loads (bias, residual / pre-activation rows: first-touch HBM data) are issued before the MFMAs
+    // of the LAST K-step, so their latency runs under that step instead of in front of the stores
+    float bias[16];
+    EpiAux aux;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK);
         const char* sa = smem + cur * 2 * TILE_BYTES;
         const char* sb = sa + TILE_BYTES;
+        if (kt == nk - 1) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -214,9 +219,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     }
 
     // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*64 + 16 g + (4 nt + r)
-    float bias[16];
-    EpiAux aux;
-    epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         int m = m0 + wr * 64 + mt * 16 + li;
@@ -277,11 +279,16 @@ __global__ __launch_bounds__(256) void gemm_nt_a3_kernel(NtParams p) {
     if (nk > 1) issue_a(1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // the epilogue's own loads (bias, residual / pre-activation rows: first-touch HBM data) are issued before the MFMAs
+    // of the LAST K-step, so their latency runs under that step instead of in front of the stores
+    float bias[16];
+    EpiAux aux;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) issue_w(kt + 1);
         if (kt + 2 < nk) issue_a(kt + 2);
         const char* sa = smem + (kt % 3) * TILE_BYTES;
         const char* sb = sW + (kt & 1) * TILE_BYTES;
+        if (kt == nk - 1) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -302,9 +309,6 @@ __global__ __launch_bounds__(256) void gemm_nt_a3_kernel(NtParams p) {
     }
 
     // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*64 + 16 g + (4 nt + r)
-    float bias[16];
-    EpiAux aux;
-    epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         int m = m0 + wr * 64 + mt * 16 + li;
