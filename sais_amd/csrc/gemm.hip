@@ -1075,13 +1075,13 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
         return sais_gemm_nt(&rest, stream);            // M < 128 now: takes the 128x128 path
     }
     dim3 grid((g->N / BN) * ((g->M + BM - 1) / BM));
-    // Three-slot A ring (gemm_nt_a3_kernel, 80 KiB of LDS): measured per epilogue at M = 50 432 — it pays where the
-    // epilogue is heavy (fp32 residual: fc2 128 -> 114 us, proj 62 -> 60; GELU: 175 -> 169) and costs a little on the
-    // plain bf16 ones (dX fc1 77 -> 83 us), so it is selected by epilogue.  SAIS_NT_A3=0 / 1 forces it off / on.
-    static const int a3_env = [] { const char* e = getenv("SAIS_NT_A3"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool heavy = g->epilogue == SAIS_EPI_BIAS_RESID_F32 || g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 ||
-                       g->epilogue == SAIS_EPI_BIAS_GELU_BF16;
-    const bool a3 = g->M >= 8192 && (a3_env < 0 ? heavy : a3_env == 1);
+    // Three-slot A ring (gemm_nt_a3_kernel, 80 KiB of LDS, still two workgroups per CU) for the large-M GEMMs.  In the
+    // isolated microbenchmark (operands resident in the 256-MiB MALL between repetitions) it only pays on the heavy
+    // epilogues; inside the training step, where A was just written by the previous kernel and is a first touch for
+    // this one, it pays everywhere: 16.3 ms/step with it on all shapes, 16.7 on the heavy ones only, 17.0 without.
+    // SAIS_NT_A3=0 turns it off.
+    static const bool a3_on = [] { const char* e = getenv("SAIS_NT_A3"); return !(e && e[0] == '0'); }();
+    const bool a3 = g->M >= 8192 && a3_on;
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)
