@@ -429,3 +429,17 @@ def test_gemm_nt_wave_specialised_variant_matches(ops):
         assert lib.sais_gemm_nt_ws_(ctypes.byref(g), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
         torch.cuda.synchronize()
         assert_close(out, ref, atol=1e-2 if not f32 else 1e-3, rtol=1e-2, name=f"ws epi {epi}")
+
+
+def test_opt_in_gemm_variants_in_a_subprocess():
+    """The experimental NT paths that are selected by environment variable at library load (register-stationary
+    K = 384 kernel, no A ring) still produce the same results: run the epilogue test under each setting."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in ({"SAIS_NT_RS": "1"}, {"SAIS_NT_A3": "0"}, {"SAIS_TN_WIDE": "0"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-x", "-q",
+                            "-k", "epilogues or tn_grouped"], env=dict(os.environ, **env), cwd=root,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (env, r.stdout[-1500:])
