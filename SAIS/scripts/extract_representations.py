@@ -18,7 +18,7 @@ from SAIS.scripts._features_io import save_reps  # noqa: E402
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # :148
 
 
-def frame_batches(folder, dev, chunk=64):
+def frame_batches(folder, dev, chunk=256):
     """SurgDataset.__getitem__ (dino-main/main_dino.py:295-316) + the transform of :158-162, with the arithmetic on the
     GPU: JPEGs are decoded on the host (PIL), pushed as uint8 and turned into the float32 [n,3,224,224] ViT input by
     sais_amd.preprocess (CenterCrop(0.8 H, 0.8 W) -> Resize((224,224)) -> ToTensor -> Normalize, bit-identical to the
@@ -83,7 +83,7 @@ def main():
     flow = args.optical_flow_to_reps
     sub = 'flows' if flow else 'images'
     videos = [args.video] if args.video else sorted(os.listdir(os.path.join(args.data_path, sub)))
-    fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 64), use_graph=True)
+    fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 256), use_graph=True)
     reps = {}
     for v in videos:
         if args.synthetic_frames:
