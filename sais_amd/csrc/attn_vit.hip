@@ -34,6 +34,18 @@ DEVINL void stage_matrix(char* lds, const bf16* src, long ld, int tid) {
         *(u32x4*)(lds + r * ROWB + c * 16) = v;
     }
 }
+// the same for a 512-thread workgroup (the backward kernels run 8 waves per (frame, head))
+DEVINL void stage_matrix512(char* lds, const bf16* src, long ld, int tid) {
+    const int c = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = r0 + 64 * i;
+        if (r < TILE_ROWS) {
+            u32x4 v = r < NTOK ? *(const u32x4*)(src + (size_t)r * ld + c * 8) : u32x4{0, 0, 0, 0};
+            *(u32x4*)(lds + r * ROWB + c * 16) = v;
+        }
+    }
+}
 
 DEVINL bf16x8 row_frag(const char* lds, int row, int chunk) { return *(const bf16x8*)(lds + row * ROWB + chunk * 16); }
 
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
 // scored, turned into dS and fed to the dQ MFMAs, and nothing but the 16 dQ accumulators outlives a step.  The first
 // version kept the full 16 x 208 P and dP strips (104 fp32 registers + their copies out of the accumulator file):
 // 378 VGPRs, one wave per SIMD, 105 us per ViT block; this one fits two workgroups per CU.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
                                                              const bf16* out, long ldout, const float* lse,
                                                              float* delta, bf16* dqkv, long lddq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,22 +183,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* qkv, lo
     const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
     const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
     const bf16* ob = out + (size_t)f * NTOK * ldout + h * HD;
-    stage_matrix(sK, base + DM, ldq, tid);
-    stage_matrix(sV, base + 2 * DM, ldq, tid);
+    stage_matrix512(sK, base + DM, ldq, tid);
+    stage_matrix512(sV, base + 2 * DM, ldq, tid);
     __syncthreads();
     const float c = scale * LOG2E;
-    const int nmine = tiles_of_wave(wid, (f * NH + h) & 3);
+    const int nmine = wid + 8 < NKT ? 2 : 1;                 // 13 query tiles over 8 waves: tiles w and w + 8
     bf16x8 fq[2], fdo[2], fo[2], fq_next[2], fdo_next[2], fo_next[2];
-    load_q_frags(base, ldq, tile_id(wid, 0) * 16 + li, g, fq);
-    load_q_frags(dob, ldo, tile_id(wid, 0) * 16 + li, g, fdo);
-    load_q_frags(ob, ldout, tile_id(wid, 0) * 16 + li, g, fo);
+    load_q_frags(base, ldq, wid * 16 + li, g, fq);
+    load_q_frags(dob, ldo, wid * 16 + li, g, fdo);
+    load_q_frags(ob, ldout, wid * 16 + li, g, fo);
     for (int it = 0; it < nmine; ++it) {
-        const int qt = tile_id(wid, it);
+        const int qt = wid + 8 * it;
         const int q = qt * 16 + li, qc = q < NTOK ? q : NTOK - 1;
         if (it + 1 < nmine) {                                                   // prefetch the next tile's rows
-            load_q_frags(base, ldq, tile_id(wid, it + 1) * 16 + li, g, fq_next);
-            load_q_frags(dob, ldo, tile_id(wid, it + 1) * 16 + li, g, fdo_next);
-            load_q_frags(ob, ldout, tile_id(wid, it + 1) * 16 + li, g, fo_next);
+            load_q_frags(base, ldq, (wid + 8 * (it + 1)) * 16 + li, g, fq_next);
+            load_q_frags(dob, ldo, (wid + 8 * (it + 1)) * 16 + li, g, fdo_next);
+            load_q_frags(ob, ldout, (wid + 8 * (it + 1)) * 16 + li, g, fo_next);
         }
         const float nl2 = -lse[((size_t)f * NH + h) * NTOK + qc] * LOG2E;
         float dl = 0.f;
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* qkv, lo
 // Key on the lane: S = Q K^T and dP = dO V^T put P / dS in exactly the B-operand layout of
 // dV^T = dO^T P and dK^T = Q^T dS (sum over queries).  Each wave owns key tiles {w, w+4, ...} and
 // sweeps the 7 query k-steps; Q and dO of the head live in LDS (row + transposed reads).
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
                                                            const float* lse, const float* delta, bf16* dqkv,
                                                            long lddq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,8 +267,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* qkv, long
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
     const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
-    stage_matrix(sQ, base, ldq, tid);
-    stage_matrix(sO, dob, ldo, tid);
+    stage_matrix512(sQ, base, ldq, tid);
+    stage_matrix512(sO, dob, ldo, tid);
     if (tid < TILE_ROWS) {
         bool ok = tid < NTOK;
         size_t idx = ((size_t)f * NH + h) * NTOK + tid;
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* qkv, long
     }
     __syncthreads();
     const float c = scale * LOG2E;
-    for (int kt = wid; kt < NKT; kt += 4) {
+    for (int kt = wid; kt < NKT; kt += 8) {
         const int key = kt * 16 + li;
         bf16x8 fk[2], fv[2];
         load_q_frags(base + DM, ldq, key, g, fk);
@@ -351,10 +363,10 @@ extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, 
         (ldout & 7) || (lddqkv & 3))
         return SAIS_ERR_ARG;
     if (set_lds(attn_bwd_dq_kernel, FWD_LDS) || set_lds(attn_bwd_dkv_kernel, DKV_LDS)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(NH, frames), dim3(256), FWD_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(NH, frames), dim3(512), FWD_LDS, (hipStream_t)stream,
                        (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, delta_ws,
                        (bf16*)dqkv, lddqkv, 0.125f);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(NH, frames), dim3(256), DKV_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(NH, frames), dim3(512), DKV_LDS, (hipStream_t)stream,
                        (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, lse, delta_ws, (bf16*)dqkv, lddqkv, 0.125f);
     return sais_check_launch();
 }
