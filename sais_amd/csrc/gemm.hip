@@ -323,6 +323,182 @@ __global__ __launch_bounds__(256) void gemm_nt_a3_kernel(NtParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Eight-wave form of the A-ring kernel: the same 128x128x64 tile and LDS image, but 512 threads (2 x 4 waves of
+// 64 x 32), so that each wave issues 4 instead of 8 LDS-DMA instructions per K-step (an issue holds the wave for
+// 65-85 cycles) and four waves per SIMD (two workgroups per CU) cover each other's stalls.  Needs <= 128 VGPRs.
+// Weight rows are permuted inside each 32-row panel (LDS row 16 t + 4 a + b <- panel column 8 a + 4 t + b) so that a
+// lane owns 8 CONTIGUOUS output columns of a row: one 16-B bf16 store or two fp32 ones.
+DEVINL int perm_row32(int n) { return (n & ~31) | (((n >> 2) & 3) << 3) | (((n >> 4) & 1) << 2) | (n & 3); }
+
+struct EpiAux8 {
+    f32x4 r[4][2];        // f32 aux: 8 columns x 4 sub-tiles
+    bf16x8 u[4];          // bf16 aux
+};
+
+template <int EPI>
+DEVINL void epilogue_loads8(const NtParams& p, int mbase, int li, int n, float (&b)[8], EpiAux8& a) {
+    if (p.bias) {
+        const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { b[i] = t0[i]; b[4 + i] = t1[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = 0.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int m = mbase + mt * 16 + li;
+        m = m < p.M ? m : p.M - 1;
+        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
+            const float* r = (const float*)p.aux + (size_t)m * p.ldaux + n;
+            a.r[mt][0] = *(const f32x4*)r;
+            a.r[mt][1] = *(const f32x4*)(r + 4);
+        } else if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16 || EPI == SAIS_EPI_MUL_BF16) {
+            a.u[mt] = *(const bf16x8*)((const bf16*)p.aux + (size_t)m * p.ldaux + n);
+        }
+    }
+}
+
+template <int EPI>
+DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], const float (&b)[8], const EpiAux8& a, int mt) {
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = v[i] + b[i];
+    auto store_bf16 = [&](void* base, int ld, const float (&z)[8]) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16)z[i];
+        *(bf16x8*)((bf16*)base + (size_t)m * ld + n) = o;
+    };
+    auto store_f32 = [&](void* base, int ld, const float (&z)[8]) {
+        float* o = (float*)base + (size_t)m * ld + n;
+        *(f32x4*)o = f32x4{z[0], z[1], z[2], z[3]};
+        *(f32x4*)(o + 4) = f32x4{z[4], z[5], z[6], z[7]};
+    };
+    if constexpr (EPI == SAIS_EPI_BIAS_BF16) {
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_RELU_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = fmaxf(y[i], 0.f);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_F32) {
+        store_f32(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] += a.r[mt][i >> 2][i & 3];
+        store_f32(p.out, p.ldo, y);
+        if (p.out2) store_bf16(p.out2, p.ldo2, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
+        if (p.out2) store_bf16(p.out2, p.ldo2, y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = gelu_erf(y[i]);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) {
+        float d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gelu_and_grad(y[i], y[i], d[i]);
+        store_bf16(p.out2, p.ldo2, d);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] *= (float)a.u[mt][i];
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] *= dgelu_erf((float)a.u[mt][i]);
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_DRELU_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = (float)a.u[mt][i] > 0.f ? y[i] : 0.f;
+        store_bf16(p.out, p.ldo, y);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(NtParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
+    const int ntn = p.N / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
+
+    // wave w issues pieces 2w, 2w+1 of each operand tile; piece q = LDS rows 8q..8q+7
+    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
+    const bf16* asrc[2]; const bf16* bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 8 * (2 * wid + j) + sub;
+        int m = m0 + r;
+        m = m < p.M ? m : p.M - 1;                                   // clamp: rows >= M are never stored
+        asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
+        bsrc[j] = p.B + (size_t)(n0 + perm_row32(r)) * p.ldb + schunk * 8;
+    }
+    char* const sW = smem + 3 * TILE_BYTES;
+    auto issue_a = [&](int kt) {
+        char* s = smem + (kt % 3) * TILE_BYTES + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(asrc[j] + kt * BK, s + j * 1024);
+    };
+    auto issue_w = [&](int kt) {
+        char* s = sW + (kt & 1) * TILE_BYTES + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bsrc[j] + kt * BK, s + j * 1024);
+    };
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+    const int nk = p.K / BK;
+    float bias[8];
+    EpiAux8 aux;
+    issue_a(0);
+    issue_w(0);
+    if (nk > 1) issue_a(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue_w(kt + 1);
+        if (kt + 2 < nk) issue_a(kt + 2);
+        const char* sa = smem + (kt % 3) * TILE_BYTES;
+        const char* sb = sW + (kt & 1) * TILE_BYTES;
+        if (kt == nk - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fa[t] = *(const bf16x8*)(sa + swz(wr * 64 + t * 16 + li, ks * 4 + g));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fb[t] = *(const bf16x8*)(sb + swz(wc * 32 + t * 16 + li, ks * 4 + g));
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
+        }
+        // A(kt+1) and W(kt+1) must have landed; A(kt+2), the 2 youngest pieces, may still be in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*32 + 8 g + (4 nt + r)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wr * 64 + mt * 16 + li;
+        if (m >= p.M) continue;
+        float v[8];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+        epilogue8<EPI>(p, m, n0 + wc * 32 + 8 * g, v, bias, aux, mt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Register-stationary NT GEMM for K = 384 (every D-wide contraction of the ViT: qkv, proj, fc1, and the dX GEMMs
 // of fc2 and proj).  With K that small the 128x128 kernel above spends its time re-filling LDS: 196 KiB of A and W
 // per 12.6-MFLOP tile, a prologue and an epilogue for only six K-steps.  Here a workgroup owns a 128-row panel of A
@@ -992,7 +1168,16 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        if (a3) {                                                                           \
+        if (w8 && E != SAIS_EPI_PATCH_F32) {                                                \
+            static thread_local bool set8 = false;                                          \
+            if (!set8) {                                                                    \
+                if (hipFuncSetAttribute((const void*)gemm_nt_w8_kernel<E>,                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES) != hipSuccess) \
+                    return SAIS_ERR_LAUNCH;                                                 \
+                set8 = true;                                                                \
+            }                                                                               \
+            hipLaunchKernelGGL(gemm_nt_w8_kernel<E>, grid, dim3(512), 5 * TILE_BYTES, (hipStream_t)stream, p); \
+        } else if (a3) {                                                                    \
             static thread_local bool set = false;                                           \
             if (!set) {                                                                     \
                 if (hipFuncSetAttribute((const void*)gemm_nt_a3_kernel<E>,                  \
@@ -1082,6 +1267,9 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // SAIS_NT_A3=0 turns it off.
     static const bool a3_on = [] { const char* e = getenv("SAIS_NT_A3"); return !(e && e[0] == '0'); }();
     const bool a3 = g->M >= 8192 && a3_on;
+    // eight-wave form of the same kernel: 16.13 vs 16.28 ms/step inside the step (SAIS_NT_W8=0 falls back to four waves)
+    static const bool w8_on = [] { const char* e = getenv("SAIS_NT_W8"); return !(e && e[0] == '0'); }();
+    const bool w8 = g->M >= 8192 && w8_on;
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)
