@@ -60,6 +60,34 @@ __global__ void pos_bwd_kernel(const float* dtokens, int frames, int ntok, int d
     atomicAdd(dpos + (size_t)q * dim + c, s);
 }
 
+// The three kernels above and below fused: one pass over dtokens [F, ntok, dim].  Workgroup (token q, frame chunk):
+// every thread owns 4 columns, sums its chunk of frames (d pos_embed[q], and d cls for q = 0) and writes the bf16
+// patch-gradient row on the way; one atomicAdd per column and workgroup at the end.
+constexpr int EMB_CHUNKS = 4;
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const float* dtokens, int frames, int ntok, int dim, float* dcls,
+                                                        float* dpos, bf16* dpatch) {
+    const int q = blockIdx.x, c4 = threadIdx.x;
+    if (4 * c4 >= dim) return;
+    const int per = (frames + EMB_CHUNKS - 1) / EMB_CHUNKS;
+    const int f0 = blockIdx.y * per, f1 = min(frames, f0 + per);
+    f32x4 s = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int f = f0; f < f1; ++f) {
+        const f32x4 v = *(const f32x4*)(dtokens + ((size_t)f * ntok + q) * dim + 4 * c4);
+        s += v;
+        if (q > 0) {
+            bf16x4 o;
+            o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+            *(bf16x4*)(dpatch + ((size_t)f * (ntok - 1) + q - 1) * dim + 4 * c4) = o;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        atomicAdd(dpos + (size_t)q * dim + 4 * c4 + e, s[e]);
+        if (q == 0) atomicAdd(dcls + 4 * c4 + e, s[e]);
+    }
+}
+
 // gather the 196 patch-token rows of every frame into a dense bf16 [F*196, dim] matrix (dY of the patch GEMM)
 __global__ void gather_patch_rows_kernel(const float* dtokens, int frames, int ntok, int dim, bf16* out) {
     long total = (long)frames * (ntok - 1) * (dim / 4);
@@ -182,6 +210,11 @@ extern "C" int sais_vit_embed_bwd(const float* dtokens, int frames, int ntok, in
     SAIS_ENTER();
     if (!dtokens || !dcls || !dpos || !dpatch_bf16 || frames <= 0 || (dim & 3)) return SAIS_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
+    if (dim <= 512) {                 // fused single pass (the ViT case: dim 384)
+        hipLaunchKernelGGL(embed_bwd_kernel, dim3(ntok, EMB_CHUNKS), dim3(128), 0, s, dtokens, frames, ntok, dim, dcls, dpos,
+                           (bf16*)dpatch_bf16);
+        return sais_check_launch();
+    }
     hipLaunchKernelGGL(cls_rows_bwd_kernel, dim3((dim + 255) / 256), dim3(256), 0, s, dtokens, (long)ntok * dim, frames,
                        dim, dcls, dpos);
     hipLaunchKernelGGL(pos_bwd_kernel, dim3(((ntok - 1) * dim + 255) / 256), dim3(256), 0, s, dtokens, frames, ntok, dim, dpos);
