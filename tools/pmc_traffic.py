@@ -21,7 +21,7 @@ NT_NAMES = {0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_b
 
 
 def timer_name(kernel):
-    m = re.search(r"gemm_nt_kernel<(\d+)>|gemm_nt_kernelILi(\d+)E", kernel)
+    m = re.search(r"gemm_nt(?:_a3|_w8)?_kernel<(\d+)>|gemm_nt(?:_a3|_w8)?_kernelILi(\d+)E", kernel)
     if m:
         return "gemm_nt<%s>" % NT_NAMES[int(m.group(1) or m.group(2))]
     for key, name in (("gemm_tn_wide_kernel", "gemm_tn_grouped"), ("gemm_tn_grouped_kernel", "gemm_tn_grouped"),
