@@ -498,6 +498,121 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(NtParams p) {
     }
 }
 
+// Persistent form of the eight-wave kernel: a workgroup walks tiles b, b + G, ... and issues the first LDS-DMA loads of
+// its NEXT tile (A'(0), W'(0), A'(1)) before the epilogue of the current one, so the per-tile prologue (the first
+// K-tile's round trip, ~19 % of a K = 384 tile) runs under the epilogue's arithmetic and stores.  vmcnt is in-order
+// and counts stores: the wait that follows the epilogue allows exactly the stores it issued (+ the two A'(1) pieces)
+// to stay outstanding, which is only known for full tiles, so a ragged tile waits for everything.
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
+    const int ntn = p.N / BN;
+    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
+    const bf16* asrc[2]; const bf16* bsrc[2];
+    auto set_tile = [&](int v, int& m0, int& n0) {
+        const int tile = xcd_remap(v, ntiles);
+        n0 = (tile % ntn) * BN; m0 = (tile / ntn) * BM;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 8 * (2 * wid + j) + sub;
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;                               // clamp: rows >= M are never stored
+            asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
+            bsrc[j] = p.B + (size_t)(n0 + perm_row32(r)) * p.ldb + schunk * 8;
+        }
+    };
+    char* const sW = smem + 3 * TILE_BYTES;
+    auto issue_a = [&](int kt) {
+        char* s = smem + (kt % 3) * TILE_BYTES + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(asrc[j] + kt * BK, s + j * 1024);
+    };
+    auto issue_w = [&](int kt) {
+        char* s = sW + (kt & 1) * TILE_BYTES + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bsrc[j] + kt * BK, s + j * 1024);
+    };
+    const int nk = p.K / BK;
+    // store instructions one wave issues in a full tile's epilogue
+    constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2
+                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
+    const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
+
+    int v = blockIdx.x, m0, n0;
+    if (v >= ntiles) return;
+    set_tile(v, m0, n0);
+    issue_a(0);
+    issue_w(0);
+    if (nk > 1) issue_a(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (;;) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        float bias[8];
+        EpiAux8 aux;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue_w(kt + 1);
+            if (kt + 2 < nk) issue_a(kt + 2);
+            const char* sa = smem + (kt % 3) * TILE_BYTES;
+            const char* sb = sW + (kt & 1) * TILE_BYTES;
+            if (kt == nk - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[t] = *(const bf16x8*)(sa + swz(wr * 64 + t * 16 + li, ks * 4 + g));
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fb[t] = *(const bf16x8*)(sb + swz(wc * 32 + t * 16 + li, ks * 4 + g));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
+            }
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: only the epilogue's loads are out
+            __builtin_amdgcn_s_barrier();
+        }
+        // the next tile's first loads go out before this tile's epilogue
+        const int cm0 = m0, cn0 = n0;
+        const int nv = v + gridDim.x;
+        const bool more = nv < ntiles;
+        if (more) {
+            set_tile(nv, m0, n0);
+            issue_a(0);
+            issue_w(0);
+            if (nk > 1) issue_a(1);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = cm0 + wr * 64 + mt * 16 + li;
+            if (m >= p.M) continue;
+            float vv[8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[4 * nt + r] = acc[mt][nt][r];
+            epilogue8<EPI>(p, m, cn0 + wc * 32 + 8 * g, vv, bias, aux, mt);
+        }
+        if (!more) break;
+        v = nv;
+        // A'(0) and W'(0) must have landed; the two A'(1) pieces and this epilogue's stores may stay in flight
+        const int allow = (cm0 + BM <= p.M && nk > 1) ? nstores + 2 : 0;
+        if (allow == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (allow == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (allow == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Register-stationary NT GEMM for K = 384 (every D-wide contraction of the ViT: qkv, proj, fc1, and the dX GEMMs
 // of fc2 and proj).  With K that small the 128x128 kernel above spends its time re-filling LDS: 196 KiB of A and W
@@ -1168,7 +1283,18 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        if (w8 && E != SAIS_EPI_PATCH_F32) {                                                \
+        if (w8p && E != SAIS_EPI_PATCH_F32) {                                               \
+            static thread_local bool set8p = false;                                         \
+            if (!set8p) {                                                                   \
+                if (hipFuncSetAttribute((const void*)gemm_nt_w8p_kernel<E>,                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES) != hipSuccess) \
+                    return SAIS_ERR_LAUNCH;                                                 \
+                set8p = true;                                                               \
+            }                                                                               \
+            const int nt_ = (int)grid.x;                                                    \
+            hipLaunchKernelGGL(gemm_nt_w8p_kernel<E>, dim3(nt_ < 512 ? nt_ : 512), dim3(512), 5 * TILE_BYTES, \
+                               (hipStream_t)stream, p, nt_);                                \
+        } else if (w8 && E != SAIS_EPI_PATCH_F32) {                                         \
             static thread_local bool set8 = false;                                          \
             if (!set8) {                                                                    \
                 if (hipFuncSetAttribute((const void*)gemm_nt_w8_kernel<E>,                  \
@@ -1270,6 +1396,10 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // eight-wave form of the same kernel: 16.13 vs 16.28 ms/step inside the step (SAIS_NT_W8=0 falls back to four waves)
     static const bool w8_on = [] { const char* e = getenv("SAIS_NT_W8"); return !(e && e[0] == '0'); }();
     const bool w8 = g->M >= 8192 && w8_on;
+    // persistent form (next tile's first loads under the epilogue): 15.96 vs 16.06 ms/step inside the step;
+    // SAIS_NT_PERSIST=0 launches one workgroup per tile instead
+    static const bool w8p_on = [] { const char* e = getenv("SAIS_NT_PERSIST"); return !(e && e[0] == '0'); }();
+    const bool w8p = w8 && w8p_on;
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)

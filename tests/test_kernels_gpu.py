@@ -438,7 +438,7 @@ def test_opt_in_gemm_variants_in_a_subprocess():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"SAIS_NT_RS": "1"}, {"SAIS_NT_W8": "0"}, {"SAIS_NT_W8": "0", "SAIS_NT_A3": "0"}, {"SAIS_TN_WIDE": "0"}):
+    for env in ({"SAIS_NT_RS": "1"}, {"SAIS_NT_PERSIST": "0"}, {"SAIS_NT_W8": "0"}, {"SAIS_NT_W8": "0", "SAIS_NT_A3": "0"}, {"SAIS_TN_WIDE": "0"}):
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-x", "-q",
                             "-k", "epilogues or tn_grouped"], env=dict(os.environ, **env), cwd=root,
                            capture_output=True, text=True)
