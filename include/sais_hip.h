@@ -87,6 +87,9 @@ typedef struct SaisTnItem {
     float* db;                     /* f32 [N1] or NULL         */
 } SaisTnItem;
 int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream);
+/* the same with FP32 P and Q (rounded to bf16 while staging, like sais_gemm_tn_f32): one launch for the four weight
+ * gradients of a temporal-encoder layer                                                                        */
+int sais_gemm_tn_grouped_f32(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream);
 /* same as sais_gemm_tn with f32 P and Q (rounded to bf16 while staging; f32 accumulation) */
 int sais_gemm_tn_f32(const void* P, int ldp, const void* Q, int ldq, int M, int N1, int N2,
                      float* dW, int ldw, float* db, int nsplit, void* stream);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sais_gemm_tn_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_transpose_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_gemm_tn_grouped": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p],
+    "sais_gemm_tn_grouped_f32": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p],
     "sais_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_layernorm_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p,
                            c_long, c_void_p, c_void_p, c_void_p],

@@ -1145,6 +1145,23 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup gp) {
     else tn_tile<bf16>(p, (t / nt2) * 128, (t % nt2) * 128, mbeg, mend, smem);
 }
 
+// the same grouping for fp32 operands (rounded to bf16 while staging): the four dW of a temporal-encoder layer, M = a few
+// hundred rows, where the launch count rather than the arithmetic is what costs
+__global__ __launch_bounds__(256) void gemm_tn_grouped_f32_kernel(TnGroup gp) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TTILE];
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / gp.ntiles;
+    int t = wg - split * gp.ntiles, it = 0;
+    while (it + 1 < gp.nitems && t >= gp.tile_end[it]) ++it;
+    if (it > 0) t -= gp.tile_end[it - 1];
+    const TnParams& p = gp.item[it];
+    const int nt2 = p.N2 / 128;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    if (mbeg >= mend) return;
+    tn_tile<float>(p, (t / nt2) * 128, (t % nt2) * 128, mbeg, mend, smem);
+}
+
 // Wide variant of the grouped dW kernel: 128 (P columns) x 384 (Q columns) output tile per 512-thread workgroup
 // (8 waves as 2 x 4, 64 x 96 per wave), used when every item has N2 % 384 == 0 (all four dW of a ViT block do).
 // The 128x128 kernel above is paced by its global->LDS fill stream (ablation in DESIGN.md 4.1: 2.8 GB of fills per
@@ -1548,6 +1565,27 @@ extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, 
         return sais_check_launch();
     }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total * ns), dim3(256), 0, (hipStream_t)stream, gp);
+    return sais_check_launch();
+}
+
+extern "C" int sais_gemm_tn_grouped_f32(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream) {
+    SAIS_ENTER();
+    if (!items || nitems <= 0 || nitems > SAIS_TN_MAX_ITEMS || M <= 0 || nsplit <= 0) return SAIS_ERR_ARG;
+    int rows = (M + nsplit - 1) / nsplit;
+    rows = (rows + TK - 1) / TK * TK;
+    const int ns = (M + rows - 1) / rows;
+    TnGroup gp;
+    gp.nitems = nitems;
+    int total = 0;
+    for (int i = 0; i < nitems; ++i) {
+        const SaisTnItem& t = items[i];
+        if (!t.P || !t.Q || !t.dW || t.N1 % 128 || t.N2 % 128 || t.ldp % 4 || t.ldq % 4) return SAIS_ERR_ARG;
+        gp.item[i] = TnParams{t.P, t.Q, t.ldp, t.ldq, M, t.N1, t.N2, t.dW, t.ldw, t.db, rows};
+        total += (t.N1 / 128) * (t.N2 / 128);
+        gp.tile_end[i] = total;
+    }
+    gp.ntiles = total;
+    hipLaunchKernelGGL(gemm_tn_grouped_f32_kernel, dim3(total * ns), dim3(256), 0, (hipStream_t)stream, gp);
     return sais_check_launch();
 }
 

@@ -138,11 +138,13 @@ def gemm_tn(p, q, dW, db=None, nsplit=None):
 
 
 def gemm_tn_grouped(items, M, nsplit=None):
-    """items: list of (p bf16[M,N1], q bf16[M,N2], dW f32[N1,N2], db f32[N1] | None); all accumulate (+=)."""
+    """items: list of (p [M,N1], q [M,N2], dW f32[N1,N2], db f32[N1] | None), p and q all bf16 or all f32; all
+    accumulate (+=)."""
     arr = (L.SaisTnItem * len(items))()
     tiles, flops, nbytes = 0, 0.0, 0
+    f32 = items[0][0].dtype == F32
     for i, (p, q, dW, db) in enumerate(items):
-        _chk(p, BF16, "P"); _chk(q, BF16, "Q"); _chk(dW, F32, "dW"); _chk(db, F32, "db")
+        _chk(p, F32 if f32 else BF16, "P"); _chk(q, F32 if f32 else BF16, "Q"); _chk(dW, F32, "dW"); _chk(db, F32, "db")
         N1, N2 = p.shape[1], q.shape[1]
         arr[i] = L.SaisTnItem(_p(p), p.stride(0), _p(q), q.stride(0), N1, N2, _p(dW), dW.stride(0), _p(db))
         tiles += (N1 // 128) * (N2 // 128)
@@ -150,7 +152,8 @@ def gemm_tn_grouped(items, M, nsplit=None):
         nbytes += 2 * M * (N1 + N2) + 4 * N1 * N2
     if nsplit is None:
         nsplit = max(1, min((M + 255) // 256, (432 + tiles - 1) // tiles))
-    _timed("gemm_tn_grouped", flops, nbytes, lambda: L.call("sais_gemm_tn_grouped", arr, len(items), M, nsplit, _stream()))
+    _timed("gemm_tn_grouped_f32" if f32 else "gemm_tn_grouped", flops, nbytes,
+           lambda: L.call("sais_gemm_tn_grouped_f32" if f32 else "sais_gemm_tn_grouped", arr, len(items), M, nsplit, _stream()))
 
 
 def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None, rstd=None, ldy16=384, ldy32=384):

@@ -275,21 +275,23 @@ class fullModel(nn.Module):
                               dgamma=fl.g(p + "norm2.weight"), dbeta=fl.g(p + "norm2.bias"))
             dh = e32(M, FF)
             ops.gemm_nt_f32(dy2, fl.wt16[p + "linear2.weight"], L.EPI_DRELU_F32, dh, aux=a["h"])
-            ops.gemm_tn(dy2, a["h"], fl.g(p + "linear2.weight"), fl.g(p + "linear2.bias"))
             dz1 = e32(M, D)                                   # = dy2 (residual) + dh . W1
             ops.gemm_nt_f32(dh, fl.wt16[p + "linear1.weight"], L.EPI_BIAS_RESID_F32, dz1, aux=dy2)
-            ops.gemm_tn(dh, a["z1"], fl.g(p + "linear1.weight"), fl.g(p + "linear1.bias"))
             dy1 = e32(M, D)
             ops.layernorm_bwd(a["y1"], D, a["m1"], a["r1"], fl.w32(p + "norm1.weight"), M, dy32=dz1, dx32=dy1,
                               dgamma=fl.g(p + "norm1.weight"), dbeta=fl.g(p + "norm1.bias"))
             dctx = e32(M, D)
             ops.gemm_nt_f32(dy1, fl.wt16[p + "self_attn.out_proj.weight"], L.EPI_BIAS_F32, dctx)
-            ops.gemm_tn(dy1, a["ctx"], fl.g(p + "self_attn.out_proj.weight"), fl.g(p + "self_attn.out_proj.bias"))
             dqkv = e32(M, 3 * D)
             ops.temporal_attn_bwd(a["qkv"], s["pad"], B, S, dctx, dqkv)
             dz = e32(M, D)                                    # = dy1 (residual) + dqkv . Win
             ops.gemm_nt_f32(dqkv, fl.wt16[p + "self_attn.in_proj_weight"], L.EPI_BIAS_RESID_F32, dz, aux=dy1)
-            ops.gemm_tn(dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))
+            # the four weight / bias gradients of the layer in one launch (M is a few hundred rows: launch-bound)
+            ops.gemm_tn_grouped([
+                (dy2, a["h"], fl.g(p + "linear2.weight"), fl.g(p + "linear2.bias")),
+                (dh, a["z1"], fl.g(p + "linear1.weight"), fl.g(p + "linear1.bias")),
+                (dy1, a["ctx"], fl.g(p + "self_attn.out_proj.weight"), fl.g(p + "self_attn.out_proj.bias")),
+                (dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))], M, nsplit=2)
         x = s["x"]
         dx = torch.empty_like(x) if need_dx else None
         o = fl.offsets["frame_pos_embeddings.0"]
