@@ -61,9 +61,9 @@ __global__ void prepare_bwd_kernel(const float* dz32, const bf16* dz16, int B, i
 }
 
 // ---------------------------------------------------------------- masked multi-head attention, one WG per (clip, head)
-DEVINL void load_head(const float* qkv, int b, int h, int S, int which, float* dst, int tid) {
+DEVINL void load_head(const float* qkv, int b, int h, int S, int which, float* dst, int tid, int nt) {
     // dst[s][QS] <- qkv[(b*S+s), which*384 + h*96 + d]
-    for (int i = tid; i < S * (THD / 4); i += 256) {
+    for (int i = tid; i < S * (THD / 4); i += nt) {
         int s = i / (THD / 4), c4 = i % (THD / 4);
         f32x4 v = *(const f32x4*)(qkv + ((size_t)b * S + s) * (3 * D) + which * D + h * THD + 4 * c4);
 #pragma unroll
@@ -72,9 +72,10 @@ DEVINL void load_head(const float* qkv, int b, int h, int S, int which, float* d
 }
 
 // P[i][j] = softmax_j( (q_i * scale) . k_j  masked by key_pad[b][j] )  -> sP[S][S+1]
-DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad, int S, float scale, float* sP, int tid) {
+DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad, int S, float scale, float* sP, int tid,
+                      int nt) {
     const int SP = S + 1;
-    for (int idx = tid; idx < S * S; idx += 256) {
+    for (int idx = tid; idx < S * S; idx += nt) {
         int i = idx / S, j = idx % S;
         float a = 0.f;
 #pragma unroll 8
@@ -83,7 +84,7 @@ DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad
     }
     __syncthreads();
     const int lane = tid & 63, w = tid >> 6;
-    for (int i = w; i < S; i += 4) {
+    for (int i = w; i < S; i += nt >> 6) {
         float m = -INFINITY;
         for (int j = lane; j < S; j += 64) m = fmaxf(m, sP[i * SP + j]);
         m = wave_max(m);
@@ -96,23 +97,23 @@ DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void tattn_fwd_kernel(const float* qkv, const unsigned char* key_pad, int S, float* ctx,
+__global__ __launch_bounds__(1024) void tattn_fwd_kernel(const float* qkv, const unsigned char* key_pad, int S, float* ctx,
                                                         float* attn_avg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = (float*)smem;
     float* sK = sQ + S * QS;
     float* sV = sK + S * QS;
     float* sP = sV + S * QS;
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, SP = S + 1;
-    load_head(qkv, b, h, S, 0, sQ, tid);
-    load_head(qkv, b, h, S, 1, sK, tid);
-    load_head(qkv, b, h, S, 2, sV, tid);
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x, SP = S + 1;
+    load_head(qkv, b, h, S, 0, sQ, tid, nt);
+    load_head(qkv, b, h, S, 1, sK, tid, nt);
+    load_head(qkv, b, h, S, 2, sV, tid, nt);
     __syncthreads();
-    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, 0.10206207261596577f /* 96^-0.5 */, sP, tid);
+    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, 0.10206207261596577f /* 96^-0.5 */, sP, tid, nt);
     if (attn_avg)
-        for (int idx = tid; idx < S * S; idx += 256)
+        for (int idx = tid; idx < S * S; idx += nt)
             atomicAdd(attn_avg + (size_t)b * S * S + idx, sP[(idx / S) * SP + idx % S] * (1.0f / TH));
-    for (int idx = tid; idx < S * THD; idx += 256) {
+    for (int idx = tid; idx < S * THD; idx += nt) {
         int i = idx / THD, d = idx % THD;
         float a = 0.f;
         for (int j = 0; j < S; ++j) a += sP[i * SP + j] * sV[j * QS + d];
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const float* qkv, const 
     }
 }
 
-__global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const unsigned char* key_pad, int S,
+__global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const unsigned char* key_pad, int S,
                                                         const float* dctx, float* dqkv) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = (float*)smem;
@@ -129,28 +130,28 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
     float* sG = sV + S * QS;                 // dctx
     float* sP = sG + S * QS;
     float* sS = sP + S * (S + 1);            // dP then dS
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, SP = S + 1;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x, SP = S + 1;
     const float scale = 0.10206207261596577f;
-    load_head(qkv, b, h, S, 0, sQ, tid);
-    load_head(qkv, b, h, S, 1, sK, tid);
-    load_head(qkv, b, h, S, 2, sV, tid);
-    for (int i = tid; i < S * (THD / 4); i += 256) {
+    load_head(qkv, b, h, S, 0, sQ, tid, nt);
+    load_head(qkv, b, h, S, 1, sK, tid, nt);
+    load_head(qkv, b, h, S, 2, sV, tid, nt);
+    for (int i = tid; i < S * (THD / 4); i += nt) {
         int s = i / (THD / 4), c4 = i % (THD / 4);
         f32x4 v = *(const f32x4*)(dctx + ((size_t)b * S + s) * D + h * THD + 4 * c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sG[s * QS + 4 * c4 + e] = v[e];
     }
     __syncthreads();
-    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, scale, sP, tid);
+    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, scale, sP, tid, nt);
     // dV[j][d] = sum_i P[i][j] dctx[i][d]
-    for (int idx = tid; idx < S * THD; idx += 256) {
+    for (int idx = tid; idx < S * THD; idx += nt) {
         int j = idx / THD, d = idx % THD;
         float a = 0.f;
         for (int i = 0; i < S; ++i) a += sP[i * SP + j] * sG[i * QS + d];
         dqkv[((size_t)b * S + j) * (3 * D) + 2 * D + h * THD + d] = a;
     }
     // dP[i][j] = dctx_i . v_j
-    for (int idx = tid; idx < S * S; idx += 256) {
+    for (int idx = tid; idx < S * S; idx += nt) {
         int i = idx / S, j = idx % S;
         float a = 0.f;
 #pragma unroll 8
@@ -159,14 +160,14 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
     }
     __syncthreads();
     const int lane = tid & 63, w = tid >> 6;
-    for (int i = w; i < S; i += 4) {
+    for (int i = w; i < S; i += nt >> 6) {
         float dot = 0.f;
         for (int j = lane; j < S; j += 64) dot += sP[i * SP + j] * sS[i * SP + j];
         dot = wave_sum(dot);
         for (int j = lane; j < S; j += 64) sS[i * SP + j] = sP[i * SP + j] * (sS[i * SP + j] - dot) * scale;
     }
     __syncthreads();
-    for (int idx = tid; idx < S * THD; idx += 256) {
+    for (int idx = tid; idx < S * THD; idx += nt) {
         int i = idx / THD, d = idx % THD;
         float aq = 0.f, ak = 0.f;
         for (int j = 0; j < S; ++j) {
@@ -412,7 +413,7 @@ extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key
     if (set_lds(tattn_fwd_kernel, lds)) return SAIS_ERR_LAUNCH;
     hipStream_t s = (hipStream_t)stream;
     if (attn_avg && hipMemsetAsync(attn_avg, 0, (size_t)B * S * S * 4, s) != hipSuccess) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(256), lds, s, qkv, key_pad, S, ctx, attn_avg);
+    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(1024), lds, s, qkv, key_pad, S, ctx, attn_avg);
     return sais_check_launch();
 }
 
@@ -423,7 +424,7 @@ extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key
         return SAIS_ERR_ARG;
     int lds = (4 * S * QS + 2 * S * (S + 1)) * 4;
     if (set_lds(tattn_bwd_kernel, lds)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(256), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, dqkv);
+    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(1024), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, dqkv);
     return sais_check_launch();
 }
 
