@@ -543,6 +543,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 
     int v = blockIdx.x, m0, n0;
     if (v >= ntiles) return;
+#ifdef SAIS_W8P_STAMP        // per-wave phase timers for tools/w8p_stamp.py (build gemm.hip with -DSAIS_W8P_STAMP)
+    unsigned long long t_issue = 0, t_mma = 0, t_wait = 0, t_bar = 0, t_epi = 0, t_pro = 0, tt;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#define STAMP(acc_) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tt; tt = now_; }
+    tt = t_begin;
+#else
+#define STAMP(acc_)
+#endif
     set_tile(v, m0, n0);
     issue_a(0);
     issue_w(0);
@@ -557,9 +565,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
             for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
         float bias[8];
         EpiAux8 aux;
+        STAMP(t_pro)
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) issue_w(kt + 1);
             if (kt + 2 < nk) issue_a(kt + 2);
+            STAMP(t_issue)
             const char* sa = smem + (kt % 3) * TILE_BYTES;
             const char* sb = sW + (kt & 1) * TILE_BYTES;
             if (kt == nk - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
@@ -575,10 +585,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
             }
+            STAMP(t_mma)
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
             else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: only the epilogue's loads are out
+            STAMP(t_wait)
             __builtin_amdgcn_s_barrier();
+            STAMP(t_bar)
         }
         // the next tile's first loads go out before this tile's epilogue
         const int cm0 = m0, cn0 = n0;
@@ -601,6 +614,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
                 for (int r = 0; r < 4; ++r) vv[4 * nt + r] = acc[mt][nt][r];
             epilogue8<EPI>(p, m, cn0 + wc * 32 + 8 * g, vv, bias, aux, mt);
         }
+        STAMP(t_epi)
         if (!more) break;
         v = nv;
         // A'(0) and W'(0) must have landed; the two A'(1) pieces and this epilogue's stores may stay in flight
@@ -611,6 +625,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+#ifdef SAIS_W8P_STAMP
+    if (lane == 0 && p.grp_out == 777) {      // p.aux doubles as the [workgroups][8 waves][8] u64 output (EPI without aux)
+        unsigned long long* d = (unsigned long long*)p.aux + ((size_t)blockIdx.x * 8 + wid) * 8;
+        d[0] = t_issue; d[1] = t_mma; d[2] = t_wait; d[3] = t_bar; d[4] = t_epi; d[5] = t_pro;
+        d[6] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+#endif
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Where a wave of the persistent NT kernel spends its time (s_memtime stamps per phase).  Needs an instrumented build:
+    make -C sais_amd/csrc clean && make -C sais_amd/csrc EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -DSAIS_W8P_STAMP"
+(then rebuild normally)."""
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from sais_amd import _lib as L, ops
