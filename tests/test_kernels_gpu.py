@@ -61,7 +61,8 @@ def test_gemm_tn_exact_integers(ops):
 # the last two shapes exercise the opt-in register-stationary kernel when SAIS_NT_RS=1 (M >= 8192, K = 384: whole
 # 128-row panels, the 57 ragged rows go to the 128x128 kernel; 256 full panels + a split tail in the last case)
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (50432 // 8, 1152, 384), (264, 2048, 384), (128, 384, 1536),
-                                   (8192 + 3 * 128 + 57, 384, 384), (50432 - 128 * 90, 1152, 384)])
+                                   (8192 + 3 * 128 + 57, 384, 384), (50432 - 128 * 90, 1152, 384),
+                                   (8192 + 128 + 5, 512, 384)])
 def test_gemm_nt_epilogues(ops, M, N, K):
     from sais_amd import _lib as L
     a = rnd(M, K, seed=3, dtype=torch.bfloat16)
