@@ -50,6 +50,7 @@ def main():
     t0 = time.time()
     from sais_amd.inference import run_windows, save_inference_outputs, tta_probs
     from sais_amd.model_io import loadModel
+    from sais_amd.postprocess import read_frame_counts
     rgb = load_reps(a.path, '%s_RepsAndLabels' % a.encoder_params)
     flow = load_reps(a.path, 'ViT_SelfSupervised_ImageNet_FlowRepsAndLabels')
     for domain in a.domains:
@@ -61,17 +62,25 @@ def main():
                                      freeze_encoder_params=a.freeze_encoder, self_attention=a.self_attention,
                                      importance_loss=a.importance_loss, inference=True)
             for phase in a.phases:
-                all_reps, all_attn = {"reps": ([], [], []), "labels": [], "videonames": [], "logits": []}, []
-                for video in sorted(rgb.keys()):
+                all_reps, all_attn, all_imp = {"reps": ([], [], []), "labels": [], "videonames": [], "logits": []}, [], []
+                # videos and their frame counts come from paths/Custom_Paths.csv, as in the reference
+                # (prepare_dataset.py:1705-1727) — NOT from whatever the reps file holds
+                counts = read_frame_counts(os.path.join(a.path, 'paths', 'Custom_Paths.csv'))
+                for video, total_frames in counts.items():
+                    if video not in rgb or video not in flow:
+                        raise SystemExit('no features for video %r in the reps files: run extract_representations.py '
+                                         'for it first' % video)
                     x = torch.from_numpy(rgb[video]).float().to(dev)
                     f = torch.from_numpy(flow[video]).float().to(dev)
-                    r, attn = run_windows(md['model'], x, f, videoname=video, batch_size=a.batch_size)
+                    r, attn, imp = run_windows(md['model'], x, f, videoname=video, batch_size=a.batch_size,
+                                               total_frames=total_frames)
                     for v in range(3):
                         all_reps["reps"][v].extend(r["reps"][v])
                     all_reps["labels"] += r["labels"]
                     all_reps["videonames"] += r["videonames"]
                     all_attn += attn
-                save_inference_outputs(savepath, phase, all_reps, all_attn)
+                    all_imp += imp
+                save_inference_outputs(savepath, phase, all_reps, all_attn, all_imp)
                 probs = tta_probs(all_reps, md['prototypes'])
                 print('[%s] %i windows; mean class probabilities %s' % (phase, probs.shape[0], probs.mean(0).tolist()))
     print('Time taken (s): %.3f' % (time.time() - t0))

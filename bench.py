@@ -8,32 +8,68 @@ clips — one "step" = one full training step of the SAIS hot path on one batch 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no torchrun environment: this process touches no GPU, starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (one rank per GPU over RCCL)
+and exits with its code; fewer than N visible GPUs, or a torchrun WORLD_SIZE that differs from --gpus, is an
+error (non-zero exit), never a silent 1-rank run.
+
 Prints ONE JSON line on rank 0.  `value` = frames/s over all ranks with inputs resident in HBM;
-`roofline` = the dominant MFMA kernel's algorithmic FLOP/s (HIP events on the launch stream, measured in a
-separate instrumented pass after the timed region) against the dense bf16 MFMA peak;
-`cpu_baseline` = the CPU oracle (oracle/, the validated restatement of the reference) timed on this
-host's cores on a bounded sample (rank 0, N=1 only).
+`roofline` = the MFMA kernel with the largest total time: algorithmic FLOP/s from HIP events on the launch
+stream (raw event intervals, measured in a separate instrumented pass after the timed region) against the
+dense bf16 MFMA peak; `cpu_baseline` = the CPU oracle (oracle/, the validated restatement of the reference)
+timed on this host's cores on a bounded sample (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md (2:1-sparse figure NOT used)
+HBM_PEAK_GBPS = 8000.0           # HBM3E spec (same guide; ~6.3 TB/s achievable)
 FLOP_PER_FRAME_FWD_BWD = 27.475e9   # SURVEY §8d: 3 x 9.197 GF - 0.1156 GF (no dX for pixels)
 FLOP_TEMPORAL_PER_CLIP = 3 * 0.57764e9
+HBM_BYTES_PER_FRAME = 133e6      # SURVEY §8d / BASELINE.md §4: fused bf16 plan, fwd+bwd
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="issue the launches of a step eagerly instead of "
+                                                              "replaying the captured hipGraph (N=1 only)")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 outside torchrun: launch N ranks as CHILD processes (this process never initialises the GPU)."""
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise HIP on this image
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; "
+                         "refusing to run fewer ranks than asked\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def build(dev, B, T, C, lr):
-    import synth
+    import torch
     from sais_amd.optim import SGD
     from sais_amd.temporal import fullModel
     from sais_amd.vit import vit_small
@@ -46,7 +82,8 @@ def build(dev, B, T, C, lr):
     return vit, model, protos, opt
 
 
-def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on=False):
+def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on=False, comm_events=None):
+    import torch
     from sais_amd.loss import calcNCELoss
     from sais_amd.loss import label_columns
     names = [f"v_{i}" for i in range(B)]
@@ -61,78 +98,116 @@ def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, d
         loss.backward()
         if dist_on:
             sync.reduce_params(protos.values())
-            sync.wait()
+            if comm_events is not None:       # how long the compute stream stalls for the collectives = exposed comm time
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                nbytes = sync.wait()
+                e1.record()
+                comm_events.append((e0, e1, nbytes))
+            else:
+                sync.wait()
         opt.step(grad_scale=1.0 / world)
         return loss
     return step
 
 
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(T, C, threads):
-    """CPU oracle (fp32 torch restatement of the reference, pinned to its golden vectors) on a bounded sample:
-    one 32-frame clip, fwd + bwd + SGD, same model."""
+    """CPU oracle (fp32 torch restatement of the reference, pinned to its golden vectors) on bounded samples of the
+    configurations BASELINE.md §3 lists.  `value` = config 2's model on one 32-frame clip, fwd+bwd+SGD (the same
+    figure as round 1); `variants` holds config 1 and the B=8 / forward-only legs."""
+    import torch
     import synth
     from oracle import sais_oracle as O
     torch.set_num_threads(threads)
-    vsd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0).items()}
-    tsd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
-    pr = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(2, C).items()}
-    clips = synth.clips(seed=0, B=1, T=T)
-    pad = synth.padding_mask([T])
-    lab = synth.labels(seed=0, B=1, nclasses=C)
 
-    def step():
-        _, emb, _ = O.e2e_forward(vsd, tsd, clips, None, pad, "RGB")
-        loss = O.nce_loss(emb, lab, pr)
-        loss.backward()
-        with torch.no_grad():
-            for d in (vsd, tsd, pr):
-                for p in d.values():
-                    if p.grad is not None:
-                        p -= 0.1 * p.grad
-                        p.grad = None
-    t0 = time.time()
-    step()                                                   # warm-up (also sizes the sample)
-    warm = time.time() - t0
-    budget = 20.0                                            # seconds of timed CPU work
-    nmax = max(1, min(10, int(budget / max(warm, 1e-3))))
-    n, t0 = 0, time.time()
-    while n < nmax:
-        step()
-        n += 1
-    dt = (time.time() - t0) / n
-    return dict(value=round(T / dt, 2), unit="frames/s", cores=threads, kind="port",
-                sample=f"1 clip x {T} frames (B=1), fwd+bwd+SGD, fp32, {n} timed steps after 1 warm-up, "
-                       f"torch {torch.__version__} CPU oracle")
+    def leg(B, Tn, nlayers, train, budget_s, max_steps):
+        vsd = {k: v.clone().requires_grad_(train) for k, v in synth.vit_state_dict(seed=0).items()}
+        tsd = {k: v.clone().requires_grad_(train) for k, v in synth.temporal_state_dict(seed=1, nlayers=nlayers).items()}
+        pr = {k: v.clone().requires_grad_(train) for k, v in synth.prototypes(2, C).items()}
+        clips = synth.clips(seed=0, B=B, T=Tn)
+        pad = synth.padding_mask([Tn] * B)
+        lab = synth.labels(seed=0, B=B, nclasses=C)
+
+        def step():
+            if not train:
+                with torch.no_grad():
+                    _, emb, _ = O.e2e_forward(vsd, tsd, clips, None, pad, "RGB", nlayers=nlayers)
+                    O.cosine_logits(emb, pr)
+                return
+            _, emb, _ = O.e2e_forward(vsd, tsd, clips, None, pad, "RGB", nlayers=nlayers)
+            loss = O.nce_loss(emb, lab, pr)
+            loss.backward()
+            with torch.no_grad():
+                for d in (vsd, tsd, pr):
+                    for p in d.values():
+                        if p.grad is not None:
+                            p -= 0.1 * p.grad
+                            p.grad = None
+        t0 = time.time()
+        step()                                               # warm-up (also sizes the sample)
+        warm = time.time() - t0
+        n_max = max(1, min(max_steps, int(budget_s / max(warm, 1e-3))))
+        n, t0 = 0, time.time()
+        while n < n_max:
+            step()
+            n += 1
+        dt = (time.time() - t0) / n
+        return round(B * Tn / dt, 2), n
+
+    main, n_main = leg(1, T, 4, True, 12.0, 10)
+    variants = {}
+    for name, (B, Tn, nl, train, budget, mx) in {
+            "config1_B1_T16_1layer_fwd": (1, 16, 1, False, 2.0, 5),
+            "config1_B1_T16_1layer_fwd_bwd": (1, 16, 1, True, 3.0, 5),
+            f"config2_B1_T{T}_fwd": (1, T, 4, False, 3.0, 5),
+            f"config2_B8_T{T}_fwd_bwd_sgd": (8, T, 4, True, 1.0, 1)}.items():
+        v, n = leg(B, Tn, nl, train, budget, mx)
+        variants[name] = {"frames_per_s": v, "timed_steps": n}
+    return dict(value=main, unit="frames/s", cores=threads, kind="port", cpu=cpu_model_name(),
+                sample=f"1 clip x {T} frames (B=1), 4-layer temporal encoder, fwd+bwd+SGD, fp32, {n_main} timed steps "
+                       f"after 1 warm-up, torch {torch.__version__} CPU oracle",
+                variants=variants)
 
 
-def load_pmc_traffic(kernel):
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def load_pmc(name):
+    path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         try:
-            return json.load(open(path)).get(kernel)
+            return json.load(open(path))
         except Exception:
             return None
     return None
 
 
+# ------------------------------------------------------------------------------------------ main
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
-    ap.add_argument("--frames", type=int, default=32)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="issue the ~700 launches of a step eagerly instead of "
-                                                              "replaying the captured hipGraph (N=1 only)")
-    args = ap.parse_args()
+    args = parse_args()
+    force_dist = os.environ.get("SAIS_BENCH_FORCE_DIST") == "1"
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(spawn_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus and not force_dist:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # SAIS_BENCH_FORCE_DIST=1 (with torchrun --nproc-per-node 1) takes the distributed code path on a 1-GPU box:
     # RCCL init, gradient all-reduce from the backward hooks, barriers, max-over-ranks timing
-    dist_on = world > 1 or (os.environ.get("SAIS_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    dist_on = world > 1 or (force_dist and "RANK" in os.environ)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -142,6 +217,7 @@ def main():
     dev = torch.device("cuda", local)
     if dist_on:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        world = dist.get_world_size()                    # what RCCL actually formed
 
     import synth
     from sais_amd import ops
@@ -152,7 +228,8 @@ def main():
     labels = synth.labels(seed=rank, B=B, nclasses=C)
     from sais_amd.parallel import GradSync
     sync = GradSync(world, active=dist_on)
-    step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on)
+    comm_events = [] if dist_on else None
+    step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on, comm_events)
     vit(frames[:2])                                          # builds the flat buffers
     model._engine(dev)
     vit.grad_ready_hook = sync.vit_hook(vit)
@@ -173,6 +250,8 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    if comm_events is not None:
+        comm_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -182,27 +261,70 @@ def main():
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
+    comm = None
+    if comm_events:
+        comm = dict(allreduce_bytes_per_step=int(comm_events[-1][2]),
+                    exposed_comm_ms_per_step=round(sum(a.elapsed_time(b) for a, b, _ in comm_events) / len(comm_events), 3),
+                    payload="fp32 flat gradient slices, one all-reduce per ViT block issued from the backward hooks")
+    timed_loss = float(loss.detach())
+
+    # parity of the measured code path: one hipGraph replay and one eager step from the SAME weights must give the
+    # same loss (the forward has no atomics, so this is exact up to nothing)
+    graph_check = None
+    if use_graph and rank == 0:
+        snap = [vit.flat.flat.clone(), model.flat.flat.clone()] + [p.detach().clone() for p in protos.values()]
+
+        def restore():
+            with torch.no_grad():
+                vit.flat.flat.copy_(snap[0])
+                model.flat.flat.copy_(snap[1])
+                for p, s in zip(protos.values(), snap[2:]):
+                    p.copy_(s)
+            vit.flat.refresh_shadows(vit._t_names)
+            model.flat.refresh_shadows(model._t_names())
+        lg = float(step().detach())
+        restore()
+        le = float(eager_step().detach())
+        restore()
+        graph_check = dict(loss_graph_replay=lg, loss_eager=le, abs_diff=abs(lg - le))
+        if not abs(lg - le) <= 1e-6 * max(1.0, abs(le)):
+            raise SystemExit(f"bench.py: hipGraph replay loss {lg!r} != eager loss {le!r} from the same weights")
 
     # instrumented pass (outside the timed region): HIP events around every MFMA kernel launch
     roof = None
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
-        for _ in range(2):
+        NPASS = 3
+        for _ in range(NPASS):
             eager_step()
         torch.cuda.synchronize()
         summ = ops.TIMER.summary()
         ops.TIMER = None
-        kern = max(summ, key=lambda k: summ[k]["total_ms"])
-        k = summ[kern]
-        ach = k["flops"] / (k["avg_ms"] * 1e-3) / 1e12
-        pmc = load_pmc_traffic(kern)
+        fam = {}
+        for tag, v in summ.items():                          # tag = "<kernel>[shape]"; a kernel = all its shapes
+            f = fam.setdefault(tag.split("[")[0], dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            f["total_ms"] += v["total_ms"]
+            f["launches"] += v["launches"]
+            f["flops"] += v["flops"] * v["launches"]
+            f["bytes"] += v["bytes"] * v["launches"]
+        kern = max(fam, key=lambda k: fam[k]["total_ms"])
+        k = fam[kern]
+        avg_ms = k["total_ms"] / k["launches"]
+        flops, nbytes = k["flops"] / k["launches"], k["bytes"] / k["launches"]
+        ach = flops / (avg_ms * 1e-3) / 1e12
+        pmc = (load_pmc("pmc_traffic.json") or {}).get(kern)
         roof = dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4),
-                    traffic=(pmc or {}).get("hbm_bytes_per_launch"),      # PMC (profiles/pmc_traffic.json), bytes/launch
-                    algorithmic_bytes=int(k["bytes"]),
-                    hbm_gbps_algorithmic=round(k["bytes"] / (k["avg_ms"] * 1e-3) / 1e9, 1),
-                    avg_launch_us=round(k["avg_ms"] * 1e3, 1), launches_per_step=k["launches"] // 2,
-                    all_kernels={n: dict(ms_per_step=round(v["total_ms"] / 2, 3),
+                    traffic=(pmc or {}).get("hbm_bytes_per_launch"),
+                    traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, collected "
+                                   "offline; NOT a live counter)",
+                    algorithmic_bytes=int(nbytes),
+                    hbm_gbps_algorithmic=round(nbytes / (avg_ms * 1e-3) / 1e9, 1),
+                    avg_launch_us=round(avg_ms * 1e3, 1), launches_per_step=k["launches"] // NPASS,
+                    timing="raw HIP-event interval per launch (includes ~4 us of event overhead; rocprofv3's kernel "
+                           "durations in profiles/ are shorter by that much)",
+                    all_kernels={n: dict(ms_per_step=round(v["total_ms"] / NPASS, 3), launches_per_step=v["launches"] // NPASS,
+                                         avg_us=round(v["avg_ms"] * 1e3, 1),
                                          tflops=round(v["flops"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
                                          gbps=round(v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9, 1)) for n, v in summ.items()})
     if dist_on:
@@ -211,6 +333,9 @@ def main():
     if rank == 0:
         fps = world * B * T * args.steps / dt
         step_flops = B * T * FLOP_PER_FRAME_FWD_BWD + B * FLOP_TEMPORAL_PER_CLIP
+        if roof is not None:
+            roof["hbm_frac"] = round(B * T * HBM_BYTES_PER_FRAME * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)
+            roof["hbm_frac_note"] = "whole step: 133 MB/frame fused-plan algorithmic bytes / step time / 8 TB/s"
         out = {
             "metric": "frames/sec ViT-S/16 fwd+bwd, 224x224 32-frame clips",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,7 +347,9 @@ def main():
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager"},
             "step_tflops": round(step_flops * world * args.steps / dt / 1e12, 1),
             "frac_of_mfma_roofline": round(step_flops * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
-            "loss": round(float(loss.detach()), 6),
+            "loss": round(timed_loss, 6),
+            "graph_vs_eager": graph_check,
+            "comm": comm,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -232,96 +232,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_a3_kernel(NtParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
-    const int ntn = p.N / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
-
-    // wave w issues pieces 4w..4w+3 of each operand tile; piece q = LDS rows 8q..8q+7
-    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
-    const bf16* asrc[4]; const bf16* bsrc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (4 * wid + j) + sub;
-        int m = m0 + r;
-        m = m < p.M ? m : p.M - 1;                                   // clamp: rows >= M are never stored
-        asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
-        bsrc[j] = p.B + (size_t)(n0 + perm_row(r)) * p.ldb + schunk * 8;
-    }
-    // A (activations / gradients: first-touch HBM data) runs TWO K-tiles ahead in a three-slot ring, W (L2-resident)
-    // one K-tile ahead in two slots; the end-of-step wait is counted so that the youngest A tile stays in flight
-    char* const sW = smem + 3 * TILE_BYTES;
-    auto issue_a = [&](int kt) {
-        char* s = smem + (kt % 3) * TILE_BYTES + (4 * wid) * 1024;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(asrc[j] + kt * BK, s + j * 1024);
-    };
-    auto issue_w = [&](int kt) {
-        char* s = sW + (kt & 1) * TILE_BYTES + (4 * wid) * 1024;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(bsrc[j] + kt * BK, s + j * 1024);
-    };
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-
-    const int nk = p.K / BK;
-    issue_a(0);
-    issue_w(0);
-    if (nk > 1) issue_a(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // the epilogue's own loads (bias, residual / pre-activation rows: first-touch HBM data) are issued before the MFMAs
-    // of the LAST K-step, so their latency runs under that step instead of in front of the stores
-    float bias[16];
-    EpiAux aux;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) issue_w(kt + 1);
-        if (kt + 2 < nk) issue_a(kt + 2);
-        const char* sa = smem + (kt % 3) * TILE_BYTES;
-        const char* sb = sW + (kt & 1) * TILE_BYTES;
-        if (kt == nk - 1) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                fa[t] = *(const bf16x8*)(sa + swz(wr * 64 + t * 16 + li, ks * 4 + g));
-                fb[t] = *(const bf16x8*)(sb + swz(wc * 64 + t * 16 + li, ks * 4 + g));
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
-        }
-        // A(kt+1) and W(kt+1) must have landed; A(kt+2), the 4 youngest pieces, may still be in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*64 + 16 g + (4 nt + r)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        int m = m0 + wr * 64 + mt * 16 + li;
-        if (m >= p.M) continue;
-        float v[16];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-        epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v, bias, aux, mt);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Eight-wave form of the A-ring kernel: the same 128x128x64 tile and LDS image, but 512 threads (2 x 4 waves of
 // 64 x 32), so that each wave issues 4 instead of 8 LDS-DMA instructions per K-step (an issue holds the wave for
@@ -414,90 +324,6 @@ DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], cons
     }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_nt_w8_kernel(NtParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
-    const int ntn = p.N / BN;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (tile % ntn) * BN, m0 = (tile / ntn) * BM;
-
-    // wave w issues pieces 2w, 2w+1 of each operand tile; piece q = LDS rows 8q..8q+7
-    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
-    const bf16* asrc[2]; const bf16* bsrc[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 8 * (2 * wid + j) + sub;
-        int m = m0 + r;
-        m = m < p.M ? m : p.M - 1;                                   // clamp: rows >= M are never stored
-        asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
-        bsrc[j] = p.B + (size_t)(n0 + perm_row32(r)) * p.ldb + schunk * 8;
-    }
-    char* const sW = smem + 3 * TILE_BYTES;
-    auto issue_a = [&](int kt) {
-        char* s = smem + (kt % 3) * TILE_BYTES + (2 * wid) * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(asrc[j] + kt * BK, s + j * 1024);
-    };
-    auto issue_w = [&](int kt) {
-        char* s = sW + (kt & 1) * TILE_BYTES + (2 * wid) * 1024;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds16(bsrc[j] + kt * BK, s + j * 1024);
-    };
-
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-
-    const int nk = p.K / BK;
-    float bias[8];
-    EpiAux8 aux;
-    issue_a(0);
-    issue_w(0);
-    if (nk > 1) issue_a(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) issue_w(kt + 1);
-        if (kt + 2 < nk) issue_a(kt + 2);
-        const char* sa = smem + (kt % 3) * TILE_BYTES;
-        const char* sb = sW + (kt & 1) * TILE_BYTES;
-        if (kt == nk - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fb[2];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fa[t] = *(const bf16x8*)(sa + swz(wr * 64 + t * 16 + li, ks * 4 + g));
-#pragma unroll
-            for (int t = 0; t < 2; ++t) fb[t] = *(const bf16x8*)(sb + swz(wc * 32 + t * 16 + li, ks * 4 + g));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
-        }
-        // A(kt+1) and W(kt+1) must have landed; A(kt+2), the 2 youngest pieces, may still be in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-    // lane holds, for row m = m0 + wr*64 + mt*16 + li, columns n0 + wc*32 + 8 g + (4 nt + r)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wr * 64 + mt * 16 + li;
-        if (m >= p.M) continue;
-        float v[8];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-        epilogue8<EPI>(p, m, n0 + wc * 32 + 8 * g, v, bias, aux, mt);
-    }
-}
-
 // Persistent form of the eight-wave kernel: a workgroup walks tiles b, b + G, ... and issues the first LDS-DMA loads of
 // its NEXT tile (A'(0), W'(0), A'(1)) before the epilogue of the current one, so the per-tile prologue (the first
 // K-tile's round trip, ~19 % of a K = 384 tile) runs under the epilogue's arithmetic and stores.  vmcnt is in-order
@@ -543,14 +369,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 
     int v = blockIdx.x, m0, n0;
     if (v >= ntiles) return;
-#ifdef SAIS_W8P_STAMP        // per-wave phase timers for tools/w8p_stamp.py (build gemm.hip with -DSAIS_W8P_STAMP)
-    unsigned long long t_issue = 0, t_mma = 0, t_wait = 0, t_bar = 0, t_epi = 0, t_pro = 0, tt;
-    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-#define STAMP(acc_) { unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_ += now_ - tt; tt = now_; }
-    tt = t_begin;
-#else
-#define STAMP(acc_)
-#endif
     set_tile(v, m0, n0);
     issue_a(0);
     issue_w(0);
@@ -565,11 +383,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
             for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
         float bias[8];
         EpiAux8 aux;
-        STAMP(t_pro)
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) issue_w(kt + 1);
             if (kt + 2 < nk) issue_a(kt + 2);
-            STAMP(t_issue)
             const char* sa = smem + (kt % 3) * TILE_BYTES;
             const char* sb = sW + (kt & 1) * TILE_BYTES;
             if (kt == nk - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
@@ -585,13 +401,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
             }
-            STAMP(t_mma)
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
             else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: only the epilogue's loads are out
-            STAMP(t_wait)
             __builtin_amdgcn_s_barrier();
-            STAMP(t_bar)
         }
         // the next tile's first loads go out before this tile's epilogue
         const int cm0 = m0, cn0 = n0;
@@ -614,7 +427,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
                 for (int r = 0; r < 4; ++r) vv[4 * nt + r] = acc[mt][nt][r];
             epilogue8<EPI>(p, m, cn0 + wc * 32 + 8 * g, vv, bias, aux, mt);
         }
-        STAMP(t_epi)
         if (!more) break;
         v = nv;
         // A'(0) and W'(0) must have landed; the two A'(1) pieces and this epilogue's stores may stay in flight
@@ -624,176 +436,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
         else if (allow == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-    }
-#ifdef SAIS_W8P_STAMP
-    if (lane == 0 && p.grp_out == 777) {      // p.aux doubles as the [workgroups][8 waves][8] u64 output (EPI without aux)
-        unsigned long long* d = (unsigned long long*)p.aux + ((size_t)blockIdx.x * 8 + wid) * 8;
-        d[0] = t_issue; d[1] = t_mma; d[2] = t_wait; d[3] = t_bar; d[4] = t_epi; d[5] = t_pro;
-        d[6] = __builtin_amdgcn_s_memtime() - t_begin;
-    }
-#endif
-#undef STAMP
-}
-
-// ---------------------------------------------------------------------------------------------
-// Register-stationary NT GEMM for K = 384 (every D-wide contraction of the ViT: qkv, proj, fc1, and the dX GEMMs
-// of fc2 and proj).  With K that small the 128x128 kernel above spends its time re-filling LDS: 196 KiB of A and W
-// per 12.6-MFLOP tile, a prologue and an epilogue for only six K-steps.  Here a workgroup owns a 128-row panel of A
-// and KEEPS IT IN REGISTERS (each wave: its 64 rows x 384 k as 48 MFMA fragments = 192 VGPRs, loaded straight from
-// global memory in fragment layout, never through LDS) while it walks the panel's 128-column tiles; only the weight
-// tiles stream through LDS, as one continuous sequence of 16-KiB chunks (128 weight rows x 64 k) in a four-slot
-// ring that keeps running across tile boundaries, so the next tile's first chunks land during the epilogue.
-// One wave per SIMD (the registers do not allow more): global->VGPR->LDS staging, whose issue does not stall the
-// wave the way LDS-DMA does.  Per chunk and wave: 4 ds_write_b128 (chunk q+2), 4 global loads (chunk q+3),
-// 8 ds_read_b128, 32 MFMAs, one s_barrier.
-// Work units: one per panel for the first multiple-of-256 panels, the remaining panels split into column pieces so
-// that the last round of workgroups is short (host picks the split).
-struct RsSched {
-    int full_panels;      // units [0, full_panels): whole panel, all N tiles
-    int pieces;           // later units: panel = full_panels + v / pieces, tiles [ (v % pieces) * tpp, ... )
-    int tpp;              // tiles per piece
-};
-
-constexpr int RS_KSTEPS = 12;           // 384 / 32
-constexpr int RS_CHUNK = 128 * 128;     // bytes: 128 weight rows x 64 k x bf16
-
-template <int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_nt_rs_kernel(NtParams p, RsSched sc) {
-    __shared__ __attribute__((aligned(16))) char ring[4 * RS_CHUNK];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
-    const int ntn = p.N / BN;
-    int panel, t0, t1;
-    if ((int)blockIdx.x < sc.full_panels) { panel = blockIdx.x; t0 = 0; t1 = ntn; }
-    else {
-        const int v = blockIdx.x - sc.full_panels;
-        panel = sc.full_panels + v / sc.pieces;
-        t0 = (v % sc.pieces) * sc.tpp;
-        t1 = min(ntn, t0 + sc.tpp);
-    }
-    const int m0 = panel * BM;
-
-    // weight chunk q of this unit = tile t0 + q/6, k range (q%6)*64: this wave stages LDS rows 32w .. 32w+31.
-    // Three staging register sets (chunk index mod 3; six chunks per tile keep that static): a chunk is loaded five
-    // iterations before it is consumed and written to LDS two iterations before, so neither the L2 latency (~2k cycles
-    // under load, i.e. more than two chunk times) nor the ds_write sits on the MFMA path.
-    const int srow = lane >> 3, schunk = lane & 7;
-    u32x4 st[3][4];
-    const int nq = (t1 - t0) * 6;
-    // buffer loads: address = descriptor base + SGPR offset (tile, k) + a per-lane byte offset fixed for the whole
-    // kernel, so a chunk load costs no vector arithmetic (one wave per SIMD: every VALU cycle is taken from the MFMAs)
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.N * p.ldb * 2, 0x00020000);      // raw buffer over W
-    unsigned loff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) loff[i] = (unsigned)(perm_row(32 * wid + 8 * i + srow) * p.ldb + schunk * 8) * 2u;
-    auto gload = [&](int q, u32x4 (&dst)[4]) {
-        q = q < nq ? q : nq - 1;                       // past the end: re-load the last chunk (never consumed); keeps
-        const int tile = t0 + q / 6, c = q - (q / 6) * 6;   // the loop free of branches around memory instructions
-        const int soff = __builtin_amdgcn_readfirstlane((tile * BN * p.ldb + c * 64) * 2);      // wave-uniform
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, loff[i], soff, 0);
-    };
-    auto lwrite = [&](int q, const u32x4 (&src)[4]) {
-        char* slot = ring + (q & 3) * RS_CHUNK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *(u32x4*)(slot + swz(32 * wid + 8 * i + srow, schunk)) = src[i];
-    };
-    gload(0, st[0]);
-    gload(1, st[1]);
-    gload(2, st[2]);
-
-    // the panel: fa[ks][mt] = rows m0 + wr*64 + mt*16 + li, k = 32 ks + 8 g .. +7
-    bf16x8 fa[RS_KSTEPS][4];
-#pragma unroll
-    for (int ks = 0; ks < RS_KSTEPS; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            int m = m0 + wr * 64 + mt * 16 + li;
-            m = m < p.M ? m : p.M - 1;                                   // clamp: rows >= M are never stored
-            fa[ks][mt] = *(const bf16x8*)(p.A + (size_t)m * p.lda + ks * 32 + g * 8);
-        }
-    lwrite(0, st[0]);
-    lwrite(1, st[1]);
-    gload(3, st[0]);
-    gload(4, st[1]);
-    // no blanket vmcnt(0) here: the compiler puts a counted wait at the first use of every A fragment, so the first
-    // tile starts as soon as its first two k-steps have arrived and the rest of the panel lands under its MFMAs
-    __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): chunks 0 and 1 are in LDS
-    __builtin_amdgcn_s_barrier();
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-
-    // fragments are read one half-chunk ahead: fb0 always holds (chunk q, k 0..31) on entry; chunk q+1 has been
-    // visible since the barrier that ended iteration q-1, so its first fragments are fetched under the second MFMA
-    // block of chunk q and no LDS latency is left between the barrier and the first MFMA
-    bf16x8 fb0[4], fb1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) fb0[t] = *(const bf16x8*)(ring + swz(wc * 64 + t * 16 + li, g));
-    int q = 0;
-    for (int tile = t0; tile < t1; ++tile) {
-        const int n0 = tile * BN;
-        float bias[16];
-        EpiAux aux;
-#pragma unroll
-        for (int c = 0; c < 6; ++c, ++q) {
-            // the epilogue's own loads (bias, residual / multiplier rows) go out two chunks early
-            if (c == 4) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
-            const char* sb = ring + (q & 3) * RS_CHUNK;
-            const char* sn = ring + ((q + 1) & 3) * RS_CHUNK;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fb1[t] = *(const bf16x8*)(sb + swz(wc * 64 + t * 16 + li, 4 + g));
-            lwrite(q + 2, st[(c + 2) % 3]);           // past the end it lands in a slot nobody reads any more
-            gload(q + 5, st[(c + 2) % 3]);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb0[nt], fa[2 * c][mt], acc[mt][nt]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ds_read (fb1)
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // ds_write (chunk q+2)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // global load (chunk q+4)
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fb0[t] = *(const bf16x8*)(sn + swz(wc * 64 + t * 16 + li, g));
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb1[nt], fa[2 * c + 1][mt], acc[mt][nt]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // ds_read (fb0 of chunk q+1)
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave's ds_writes are in LDS (vmcnt/expcnt untouched)
-            __builtin_amdgcn_s_barrier();
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + wr * 64 + mt * 16 + li;
-            float v[16];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[4 * nt + r] = acc[mt][nt][r]; acc[mt][nt][r] = 0.f; }
-            epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v, bias, aux, mt);       // whole panels only: no row guard
-        }
     }
 }
 
@@ -1322,7 +964,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        if (w8p && E != SAIS_EPI_PATCH_F32) {                                               \
+        if (big && E != SAIS_EPI_PATCH_F32) {                                               \
             static thread_local bool set8p = false;                                         \
             if (!set8p) {                                                                   \
                 if (hipFuncSetAttribute((const void*)gemm_nt_w8p_kernel<E>,                 \
@@ -1333,112 +975,26 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
             const int nt_ = (int)grid.x;                                                    \
             hipLaunchKernelGGL(gemm_nt_w8p_kernel<E>, dim3(nt_ < 512 ? nt_ : 512), dim3(512), 5 * TILE_BYTES, \
                                (hipStream_t)stream, p, nt_);                                \
-        } else if (w8 && E != SAIS_EPI_PATCH_F32) {                                         \
-            static thread_local bool set8 = false;                                          \
-            if (!set8) {                                                                    \
-                if (hipFuncSetAttribute((const void*)gemm_nt_w8_kernel<E>,                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES) != hipSuccess) \
-                    return SAIS_ERR_LAUNCH;                                                 \
-                set8 = true;                                                                \
-            }                                                                               \
-            hipLaunchKernelGGL(gemm_nt_w8_kernel<E>, grid, dim3(512), 5 * TILE_BYTES, (hipStream_t)stream, p); \
-        } else if (a3) {                                                                    \
-            static thread_local bool set = false;                                           \
-            if (!set) {                                                                     \
-                if (hipFuncSetAttribute((const void*)gemm_nt_a3_kernel<E>,                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES) != hipSuccess) \
-                    return SAIS_ERR_LAUNCH;                                                 \
-                set = true;                                                                 \
-            }                                                                               \
-            hipLaunchKernelGGL(gemm_nt_a3_kernel<E>, grid, dim3(256), 5 * TILE_BYTES, (hipStream_t)stream, p); \
         } else                                                                              \
             hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
         break;
-
-extern "C" int sais_gemm_nt_ws_(const SaisGemm* g, void* stream);       // gemm_ws.hip: wave-specialised, persistent
 
 extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     SAIS_ENTER();
     if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
     if (g->M <= 0 || g->N % BN || g->K % BK || g->lda % 8 || g->ldb % 8 || g->ldo % 8) return SAIS_ERR_ARG;
-    // The wave-specialised persistent kernel (gemm_ws.hip) is correct but, as measured in round 1, not yet faster
-    // than the 128x128 kernel below (its consumers stall ~7.8k cycles per tile issuing the epilogue stores): it is
-    // opt-in (SAIS_GEMM_WS=1) until the store hand-off to the idle loader waves lands.
-    static const bool use_ws = [] { const char* e = getenv("SAIS_GEMM_WS"); return e && e[0] == '1'; }();
     if (g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 && !g->out2) return SAIS_ERR_ARG;
     if ((g->epilogue == SAIS_EPI_MUL_BF16 || g->epilogue == SAIS_EPI_DGELU_BF16 || g->epilogue == SAIS_EPI_DRELU_BF16 ||
          g->epilogue == SAIS_EPI_BIAS_RESID_F32) && !g->aux)
         return SAIS_ERR_ARG;
-    if (use_ws && g->M >= 8192 && g->epilogue != SAIS_EPI_BIAS_GELU_GRAD_BF16 && g->epilogue != SAIS_EPI_MUL_BF16) {
-        int rc = sais_gemm_nt_ws_(g, stream);
-        return rc ? rc : sais_check_launch();
-    }
     NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
                g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off};
-    // Opt-in (SAIS_NT_RS=1).  Measured on MI355X (round 1, M = 50 432): at parity or slightly ahead of the 128x128
-    // kernel on the N = 1536 shapes (dX fc2 133 vs 142 us, fc1+gelu 182 vs 181 us), behind on qkv (90 vs 74 us) and on
-    // the N = 384 shapes whose units are only three tiles long (77 vs 62, 53 vs 36 us).  s_memtime stamps per
-    // workgroup: 15k cycles until the panel is in registers, then ~900 cycles per chunk for 512 cycles of MFMA and
-    // 2.4k cycles of epilogue per tile, all serial because the registers allow one wave per SIMD; ablations: LDS
-    // fragment reads cost nothing, weight staging 19 %, barriers 8 %.  See DESIGN.md §4.1.
-    static const bool use_rs = [] { const char* e = getenv("SAIS_NT_RS"); return e && e[0] == '1'; }();
-    if (use_rs && g->K == 384 && g->M >= 8192 && g->epilogue != SAIS_EPI_PATCH_F32) {
-        // unit schedule: whole panels for the first multiple of 256, the rest split into column pieces; pick the
-        // split that minimises (rounds x tiles per piece) + an A-panel load (~0.7 tile) per round
-        const int ntn = g->N / BN, P = g->M / BM, CUS = 256;          // whole panels; a ragged tail goes to the kernel below
-        RsSched sc{(P / CUS) * CUS, 1, ntn};
-        const int tail = P - sc.full_panels;
-        if (tail > 0) {
-            double best = 1e30;
-            for (int pp = 1; pp <= ntn; ++pp) {
-                const int tpp = (ntn + pp - 1) / pp, pieces = (ntn + tpp - 1) / tpp;
-                const int rounds = (tail * pieces + CUS - 1) / CUS;
-                const double cost = rounds * (tpp + 0.7);
-                if (cost < best) { best = cost; sc.pieces = pieces; sc.tpp = tpp; }
-            }
-        }
-        dim3 rgrid(sc.full_panels + tail * sc.pieces);
-        switch (g->epilogue) {
-#define LAUNCH_RS(E) case E: hipLaunchKernelGGL(gemm_nt_rs_kernel<E>, rgrid, dim3(256), 0, (hipStream_t)stream, p, sc); break;
-            LAUNCH_RS(SAIS_EPI_BIAS_BF16)
-            LAUNCH_RS(SAIS_EPI_BIAS_RELU_BF16)
-            LAUNCH_RS(SAIS_EPI_BIAS_F32)
-            LAUNCH_RS(SAIS_EPI_BIAS_RESID_F32)
-            LAUNCH_RS(SAIS_EPI_BIAS_GELU_BF16)
-            LAUNCH_RS(SAIS_EPI_DGELU_BF16)
-            LAUNCH_RS(SAIS_EPI_DRELU_BF16)
-            LAUNCH_RS(SAIS_EPI_BIAS_GELU_GRAD_BF16)
-            LAUNCH_RS(SAIS_EPI_MUL_BF16)
-#undef LAUNCH_RS
-            default: return SAIS_ERR_ARG;
-        }
-        const int done = P * BM;
-        if (done == g->M) return sais_check_launch();
-        if (sais_check_launch() != SAIS_OK) return SAIS_ERR_LAUNCH;
-        SaisGemm rest = *g;
-        rest.A = (const char*)g->A + (size_t)done * g->lda * 2;
-        rest.M = g->M - done;
-        const size_t osz = (g->epilogue == SAIS_EPI_BIAS_F32 || g->epilogue == SAIS_EPI_BIAS_RESID_F32) ? 4 : 2;
-        rest.out = (char*)g->out + (size_t)done * g->ldo * osz;
-        if (g->out2) rest.out2 = (char*)g->out2 + (size_t)done * g->ldo2 * 2;
-        if (g->aux) rest.aux = (const char*)g->aux + (size_t)done * g->ldaux * (g->epilogue == SAIS_EPI_BIAS_RESID_F32 ? 4 : 2);
-        return sais_gemm_nt(&rest, stream);            // M < 128 now: takes the 128x128 path
-    }
     dim3 grid((g->N / BN) * ((g->M + BM - 1) / BM));
-    // Three-slot A ring (gemm_nt_a3_kernel, 80 KiB of LDS, still two workgroups per CU) for the large-M GEMMs.  In the
-    // isolated microbenchmark (operands resident in the 256-MiB MALL between repetitions) it only pays on the heavy
-    // epilogues; inside the training step, where A was just written by the previous kernel and is a first touch for
-    // this one, it pays everywhere: 16.3 ms/step with it on all shapes, 16.7 on the heavy ones only, 17.0 without.
-    // SAIS_NT_A3=0 turns it off.
-    static const bool a3_on = [] { const char* e = getenv("SAIS_NT_A3"); return !(e && e[0] == '0'); }();
-    const bool a3 = g->M >= 8192 && a3_on;
-    // eight-wave form of the same kernel: 16.13 vs 16.28 ms/step inside the step (SAIS_NT_W8=0 falls back to four waves)
-    static const bool w8_on = [] { const char* e = getenv("SAIS_NT_W8"); return !(e && e[0] == '0'); }();
-    const bool w8 = g->M >= 8192 && w8_on;
-    // persistent form (next tile's first loads under the epilogue): 15.96 vs 16.06 ms/step inside the step;
-    // SAIS_NT_PERSIST=0 launches one workgroup per tile instead
-    static const bool w8p_on = [] { const char* e = getenv("SAIS_NT_PERSIST"); return !(e && e[0] == '0'); }();
-    const bool w8p = w8 && w8p_on;
+    // Two kernels, chosen by M alone: the four-wave 128x128 kernel for small M (inference batches, tests, the
+    // patch-embed epilogue) and the persistent eight-wave A-ring kernel for the ViT GEMMs of a training step
+    // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
+    // four-wave A-ring) were measured slower inside the step and are gone from the library.
+    const bool big = g->M >= 8192;
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)
@@ -1559,8 +1115,7 @@ extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, 
     }
     gp.ntiles = total;
     // wide tiles (128 x 384) when every item allows them and M is a whole number of 64-row steps
-    static const bool allow_wide = [] { const char* e = getenv("SAIS_TN_WIDE"); return !(e && e[0] == '0'); }();
-    bool wide = allow_wide && M % TK == 0 && M >= 8192;
+    bool wide = M % TK == 0 && M >= 8192;
     for (int i = 0; i < nitems && wide; ++i) wide = items[i].N2 % WQ == 0;
     if (wide) {
         TnWideGroup wg;

@@ -127,34 +127,42 @@ class FeatureExtractor:
 
 # --------------------------------------------------------------------------- windowed temporal inference
 @torch.no_grad()
-def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2):
+def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, total_frames=None):
     """The `Custom_inference` phase of single_epoch (perform_training.py:71-185) over one video.
-    Returns the dict train.py:116 saves as reps_and_labels_<phase> plus the attention list (:117)."""
+    Returns the dict train.py:116 saves as reps_and_labels_<phase>, the attention list (:117) and the importance list
+    (:118; per-batch [B,1,T+1,1] tensors with `-il`, else empty).  `total_frames` = the video's row count in
+    paths/Custom_Paths.csv, which is what sizes the windows in the reference (prepare_dataset.py:1705-1727); default:
+    the number of feature rows."""
     model.eval()
-    wins = gesture_windows(rgb_reps.shape[0])
+    wins = gesture_windows(rgb_reps.shape[0] if total_frames is None else total_frames)
     reps = ([], [], [])
-    attention, labels, names = [], [], []
+    attention, labels, names, importance = [], [], [], []
     for i in range(0, len(wins), batch_size):
         items = [sample_window(rgb_reps, flow_reps, s, e) for s, e in wins[i:i + batch_size]]
         c = pad_collate_tta(items)
         use_f = model.modalities in ("Flow", "RGB-Flow")
-        embs, attn = model(c["x"], c["f"] if use_f else None, c["xlens"], c["flens"], 'Prototypes', c["xpad"],
-                           c["fpad"] if use_f else None, None)
+        out = model(c["x"], c["f"] if use_f else None, c["xlens"], c["flens"], 'Prototypes', c["xpad"],
+                    c["fpad"] if use_f else None, None)
+        if model.importance_loss:                                    # (importances, embs, attn), prepare_model.py:445-446
+            imp, embs, attn = out
+            importance.append(imp.detach().cpu())                    # perform_training.py:139-141
+        else:
+            embs, attn = out
         for v in range(3):
             for b in range(len(items)):
                 reps[v].append(embs[v][b].detach().cpu())
         attention.append(attn.detach().cpu())
         labels += [torch.tensor(0, dtype=torch.long)] * len(items)          # placeholder label (:2637)
         names += [videoname] * len(items)
-    return {"reps": reps, "labels": labels, "videonames": names, "logits": []}, attention
+    return {"reps": reps, "labels": labels, "videonames": names, "logits": []}, attention, importance
 
 
-def save_inference_outputs(savepath, phase, reps_and_labels, attention):
+def save_inference_outputs(savepath, phase, reps_and_labels, attention, importance=()):
     """train.py:113-119 — rank 0 writes reps_and_labels_<ph>, attention_<ph>, importance_<ph> with torch.save."""
     os.makedirs(savepath, exist_ok=True)
     torch.save(reps_and_labels, os.path.join(savepath, f"reps_and_labels_{phase}"))
     torch.save(attention, os.path.join(savepath, f"attention_{phase}"))
-    torch.save([], os.path.join(savepath, f"importance_{phase}"))
+    torch.save(list(importance), os.path.join(savepath, f"importance_{phase}"))
 
 
 def tta_probs(reps_and_labels, prototypes):

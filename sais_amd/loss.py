@@ -9,6 +9,12 @@ from . import _lib as L
 from . import ops
 
 
+def nce_max_rows(C):
+    """Largest batch one `sais_nce` launch takes: it is a single-workgroup kernel that keeps (2B + C + 2BC) floats in
+    64 KiB of LDS (sais_amd/csrc/temporal.hip).  C = 2 -> 2730 rows."""
+    return (16384 - C) // (2 + 2 * C)
+
+
 def _stack(prototypes):
     keys = list(prototypes.keys())
     return torch.cat([prototypes[k].reshape(1, -1) for k in keys], dim=0).float().contiguous(), keys
@@ -32,6 +38,10 @@ class _NCEFn(torch.autograd.Function):
         p = torch.cat([q.reshape(1, -1) for q in protos], dim=0).float().contiguous()
         emb = emb.float().contiguous()
         B, C = emb.shape[0], p.shape[0]
+        if B > nce_max_rows(C):
+            raise L.SaisHipError(f"calcNCELoss: batch of {B} rows with {C} prototypes exceeds the single-workgroup loss "
+                                 f"kernel's limit of {nce_max_rows(C)} rows (the loss is a mean over the batch and its "
+                                 "gradient couples every row with the prototypes); use a smaller batch")
         loss = torch.empty(1, dtype=torch.float32, device=emb.device)
         demb = torch.empty_like(emb)
         dpro = torch.zeros_like(p)
@@ -65,7 +75,10 @@ def cosine_logits_and_probs(snip_sequence, gesture_prototypes):
     B, C = emb.shape[0], p.shape[0]
     sim = torch.empty(B, C, dtype=torch.float32, device=emb.device)
     probs = torch.empty_like(sim)
-    ops.nce(emb, p.detach(), None, sim, probs, None, None, None, 1.0)
+    # the forward is row-independent: long videos (thousands of windows) go through in chunks of the kernel's row limit
+    step = nce_max_rows(C)
+    for i in range(0, B, step):
+        ops.nce(emb[i:i + step], p.detach(), None, sim[i:i + step], probs[i:i + step], None, None, None, 1.0)
     return sim, probs
 
 

@@ -32,29 +32,12 @@ class KernelTimer:
         e.record()
         self.recs.setdefault(tag, []).append((s, e, flops, nbytes))
 
-    @staticmethod
-    def bracket_overhead_ms(n=64):
-        """What an empty event bracket measures on this stream (the two event packets themselves): a few us, which
-        matters for 30-60 us kernels; subtracted from every interval so that the averages agree with rocprofv3's
-        kernel durations."""
-        pairs = []
-        for _ in range(n):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            e.record()
-            pairs.append((s, e))
-        torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in pairs)
-        return ts[len(ts) // 2]
-
     def summary(self):
+        """Raw HIP-event intervals (an event bracket adds ~4 us to a 30-60 us kernel; rocprofv3's kernel durations in
+        profiles/ are the un-bracketed figure).  Tags are "<kernel>[shape]"."""
         out = {}
-        # an empty bracket shows the latency of both event packets; around a kernel one of them overlaps the kernel's
-        # own dispatch, so half of it is the bracket's contribution (checked against rocprofv3: 63.3 us raw, 58.6 us
-        # in the trace, 8.8 us empty bracket)
-        ovh = 0.5 * self.bracket_overhead_ms()
         for tag, lst in self.recs.items():
-            ms = [max(a.elapsed_time(b) - ovh, 1e-4) for a, b, _, _ in lst]
+            ms = [a.elapsed_time(b) for a, b, _, _ in lst]
             out[tag] = dict(launches=len(lst), total_ms=sum(ms), avg_ms=sum(ms) / len(ms),
                             flops=sum(f for _, _, f, _ in lst) / len(lst), bytes=sum(b for _, _, _, b in lst) / len(lst))
         return out
@@ -94,7 +77,7 @@ def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0,
                    _p(out), out.stride(-2), _p(out2), 0 if out2 is None else out2.stride(-2),
                    _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2])
     nbytes = 2 * (M * K + N * K) + out.element_size() * M * N
-    _timed(f"gemm_nt<{_NT_NAMES[epilogue]}>", 2.0 * M * N * K, nbytes,
+    _timed(f"gemm_nt<{_NT_NAMES[epilogue]}>[N{N},K{K}]", 2.0 * M * N * K, nbytes,
            lambda: L.call("sais_gemm_nt", ctypes.byref(g), _stream()))
     return out
 

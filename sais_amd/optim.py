@@ -4,6 +4,7 @@ pass.  Parameters that do not belong to a sais_amd engine (the prototypes) get t
 import torch
 
 from . import ops
+from ._lib import SaisHipError
 
 
 class SGD(torch.optim.Optimizer):
@@ -27,11 +28,11 @@ class SGD(torch.optim.Optimizer):
             for p in group["params"]:
                 if id(p) in owned or p.grad is None:
                     continue
-                if p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous() \
-                        and p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0:
-                    ops.sgd_step(p, p.grad, None, lr, grad_scale)
-                else:
-                    p.add_(p.grad, alpha=-lr * grad_scale)
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                        and p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0):
+                    raise SaisHipError("SGD.step: parameters must be contiguous, 16-B aligned fp32 device tensors "
+                                       "(the HIP path has no torch / CPU fallback)")
+                ops.sgd_step(p, p.grad, None, lr, grad_scale)
         lr = self.param_groups[0]["lr"]
         for e in self.engines:
             if e.flat is not None:

@@ -17,7 +17,8 @@ class GradSync:
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.active = self.world > 1 if active is None else active     # active with world 1: exercises the path
         self.pending = []
-        self.bytes = 0
+        self.bytes = 0                      # bytes handed to all_reduce since the last wait()
+        self._temporal = None               # fullModel whose touched slices still have to be exchanged this step
 
     def _reduce(self, t):
         if self.active and t.numel() > 0:
@@ -25,27 +26,46 @@ class GradSync:
             self.bytes += t.numel() * t.element_size()
 
     def vit_hook(self, vit):
-        """hook for VisionTransformer.grad_ready_hook"""
+        """hook for VisionTransformer.grad_ready_hook: called per block, last block first."""
         def fn(lo, hi):
+            self.flush_temporal()           # the temporal backward is complete once the ViT backward starts
             self._reduce(vit.flat.grad[lo:hi])
         return fn
 
     @staticmethod
     def temporal_ranges(model, T):
-        """Touched slices of fullModel's flat gradient buffer on the Prototypes path with T frames:
-        frame_cls, linear.{weight,bias}, position rows 0..T-1, the 4 frame-encoder layers."""
+        """Touched slices of fullModel's flat gradient buffer on the Prototypes path with at most T frames per stream:
+        linear (+ importance_function with -il), frame_cls, position rows 0..T-1, the frame-encoder layers.  Everything
+        else (clip_*, transEncoderClip, MIL heads, linear2, position rows >= T) never receives a gradient
+        (the reference's disabled DDP needed find_unused_parameters=True for them, prepare_model.py:549)."""
         f = model.flat
         first_clip = "transEncoderClip.layers.0.self_attn.in_proj_weight"
-        return [(f.offsets["frame_cls"], f.offsets["frame_cls"] + 384),
-                (f.offsets["linear.weight"], f.offsets["linear.bias"] + 256),
-                (f.offsets["frame_pos_embeddings.0"], f.offsets["frame_pos_embeddings.0"] + T * 384),
-                (f.offsets["transEncoderFrame.layers.0.self_attn.in_proj_weight"], f.offsets[first_clip])]
+        r = [(f.offsets["linear.weight"], f.offsets["linear.bias"] + 256),
+             (f.offsets["frame_cls"], f.offsets["frame_cls"] + 384),
+             (f.offsets["frame_pos_embeddings.0"], f.offsets["frame_pos_embeddings.0"] + T * 384),
+             (f.offsets["transEncoderFrame.layers.0.self_attn.in_proj_weight"], f.offsets[first_clip])]
+        if getattr(model, "importance_loss", False):
+            r.append((f.offsets["importance_function.weight"], f.offsets["importance_function.bias"] + 4))
+        return r
 
-    def temporal_hook(self, model, T):
+    def temporal_hook(self, model, T=None):
+        """hook for fullModel.grad_ready_hook.  It fires once per backward CALL (several per step with TTA list inputs
+        or gradient accumulation), so it only marks the model: the exchange itself is issued ONCE per step, when the
+        ViT backward starts (vit_hook) or at wait(), over the slices touched by the longest stream seen (RGB and flow
+        lengths may differ)."""
         def fn(lo, hi):
-            for a, b in self.temporal_ranges(model, T):
-                self._reduce(model.flat.grad[a:b])
+            self._temporal = (model, T)
         return fn
+
+    def flush_temporal(self):
+        if self._temporal is None:
+            return
+        model, T = self._temporal
+        self._temporal = None
+        Tmax = max(T or 0, getattr(model, "_touched_T", 0))
+        model._touched_T = 0
+        for a, b in self.temporal_ranges(model, Tmax):
+            self._reduce(model.flat.grad[a:b])
 
     def reduce_params(self, params):
         for p in params:
@@ -53,6 +73,9 @@ class GradSync:
                 self._reduce(p.grad)
 
     def wait(self):
+        self.flush_temporal()
         for w in self.pending:
             w.wait()
         self.pending = []
+        n, self.bytes = self.bytes, 0
+        return n

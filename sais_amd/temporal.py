@@ -98,6 +98,7 @@ class fullModel(nn.Module):
         self._sig = None
         self._anchor = None
         self.grad_ready_hook = None
+        self._touched_T = 0            # longest stream whose position rows received a gradient since the last exchange
 
     # ------------------------------------------------------------------ engine plumbing
     @property
@@ -143,6 +144,11 @@ class fullModel(nn.Module):
     def forward(self, x, f, xlens, flens, task, xpad, fpad, domains=None):
         if task != 'Prototypes':
             raise NotImplementedError(f"task {task!r}: only 'Prototypes' is on the MI355X hot path")
+        if '+' in self.domain:
+            # the reference sends samples whose domain is not 'NH_02' through linearB (prepare_model.py:405-414);
+            # linearB is registered (state_dict contract) but the per-sample head selection is not built
+            raise NotImplementedError("multi-domain training ('+' in the domain name: per-sample linear / linearB "
+                                      "selection, prepare_model.py:405-414) is not on the MI355X hot path")
         if isinstance(x, (list, tuple)) or isinstance(f, (list, tuple)):          # TTA versions, :331-346
             n = len(x) if x is not None else len(f)
             embs, attn0, imp0 = [], None, None
@@ -294,6 +300,7 @@ class fullModel(nn.Module):
                 (dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))], M, nsplit=2)
         x = s["x"]
         dx = torch.empty_like(x) if need_dx else None
+        self._touched_T = max(self._touched_T, T)
         o = fl.offsets["frame_pos_embeddings.0"]
         ops.temporal_prepare_bwd(dz, None, B, T, dx, 0 if dx is None else dx.stride(0), 0 if dx is None else dx.stride(2),
                                  False, fl.grad[o:o + T * D], fl.g("frame_cls"))

@@ -15,9 +15,6 @@ Deliberate differences from the reference (documented in DESIGN.md): only the Vi
 geometry is supported; DropPath (stochastic, train() only, never used by SAIS which runs the ViT in
 eval(): extract_representations.py:362) is the identity.
 """
-import math
-import os
-
 import torch
 import torch.nn as nn
 
@@ -111,8 +108,6 @@ class VisionTransformer(nn.Module):
         self._sig = None
         self._anchor = None
         self.grad_ready_hook = None                  # callable(lo, hi): flat-grad slice [lo,hi) is final
-        self.overlap_dw = os.environ.get("SAIS_DW_OVERLAP", "0") == "1"
-        self._side = None
         self._t_names = []
         for i in range(depth):
             p = f"blocks.{i}."
@@ -131,11 +126,6 @@ class VisionTransformer(nn.Module):
             self.flat.refresh_shadows(self._t_names)
             self._sig = self.flat.signature(self._sentinels)
         return self.flat
-
-    def _side_stream(self, device):
-        if self._side is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device)
-        return self._side
 
     def shadows_dirty(self):
         self._sig = None
@@ -246,44 +236,17 @@ class VisionTransformer(nn.Module):
         M = Fr * NTOK
         e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
-        dx16 = e16(M, D)
+        dxa, dxb = e16(M, D), e16(M, D)            # bf16 copies of the residual-stream gradient (block input / mid)
         ops.layernorm_bwd(saved["x_final"], NTOK * D, saved["meanN"], saved["rstdN"], f.w32("norm.weight"), Fr,
                           dy32=dreps, dx32=dx, lddx32=NTOK * D, dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
-        ops.cast_bf16(dx, dx16)
-        dxn, dao = e16(M, D), e16(M, D)
+        ops.cast_bf16(dx, dxa)
+        dxn, dao, du, dqkv = e16(M, D), e16(M, D), e16(M, HID), e16(M, 3 * D)
         delta = torch.empty(Fr, HEADS, NTOK, dtype=torch.float32, device=dev)
-        # The weight-gradient GEMMs of a block (one grouped launch) are off the critical chain, so they go to a side
-        # stream and run under the next blocks' dX GEMMs / LayerNorm / attention backward (HBM-bound kernels next to an
-        # MFMA-bound one).  Their operands must then outlive the block: three rotating sets of the bf16 gradient
-        # streams (A: block input grad, B: grad at the attention stage, U: fc1 pre-activation grad, Q: dqkv), i.e.
-        # 3 x 350 MB at config 2; the main stream waits for the dW launch of block i+2 before block i overwrites set
-        # (i-1) % 3.  Opt-in (SAIS_DW_OVERLAP=1): measured on MI355X it does not pay — 20.4 ms/step against 19.6 ms on
-        # one stream (both kernels fill the chip; co-residency costs each more than the overlap returns).
-        overlap = self.overlap_dw
-        nset = 3 if overlap else 1
-        A = [dx16] + [e16(M, D) for _ in range(2)]
-        B, U, Q = ([e16(M, n) for _ in range(nset)] for n in (D, HID, 3 * D))
-        main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev) if overlap else main
-        done, keep, hooked = {}, [], self.depth
         if self.grad_ready_hook:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
-
-        def retire(upto):                 # main waits for the dW launches of blocks >= upto; their slices are final
-            nonlocal hooked
-            for j in reversed(range(upto, hooked)):
-                if overlap:
-                    main.wait_event(done.pop(j))
-                if self.grad_ready_hook:
-                    self.grad_ready_hook(*self.block_grad_range(j))
-            hooked = min(hooked, upto)
-
         for i in reversed(range(self.depth)):
             p = f"blocks.{i}."
             s = saved["blocks"][i]
-            k = (self.depth - 1 - i) % 3
-            dxa, dxc = A[k], A[(k + 1) % 3]
-            dxb, du, dqkv = B[k % nset], U[k % nset], Q[k % nset]
             # MLP branch
             ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
             ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
@@ -292,30 +255,19 @@ class VisionTransformer(nn.Module):
             # attention branch
             ops.gemm_nt(dxb, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
             ops.vit_attn_bwd(s["qkv"], dao, s["ao"], s["lse"], delta, Fr, dqkv)
-            # all four weight / bias gradients of the block in one launch (108 output tiles)
-            if overlap:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-            with torch.cuda.stream(side):
-                ops.gemm_tn_grouped([
-                    (dxa, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
-                    (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
-                    (dxb, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias")),
-                    (dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
-                if overlap:
-                    done[i] = torch.cuda.Event()
-                    done[i].record(side)
-                    keep.append(s)            # the side stream still reads the saved activations
+            # all four weight / bias gradients of the block in one launch.  (A side stream for this launch was measured
+            # in round 1: 20.4 vs 19.6 ms/step — both kernels fill the chip — and removed.)
+            ops.gemm_tn_grouped([
+                (dxa, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
+                (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
+                (dxb, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias")),
+                (dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
             ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn)
-            retire(i + 2 if overlap else i + 1)       # dxc (set k+1) was an operand of block i+2's dW launch
             ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,
-                              dx32=dx, dx16=dxc, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
+                              dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
             saved["blocks"][i] = None
-            if not overlap:
-                retire(i)
-        retire(0)
-        keep.clear()
+            if self.grad_ready_hook:                  # the block's gradient slice is final: DP all-reduce may start
+                self.grad_ready_hook(*self.block_grad_range(i))
         dpatch = e16(Fr * 196, D)
         ops.vit_embed_bwd(dx, Fr, f.g("cls_token"), f.g("pos_embed"), dpatch)
         ops.gemm_tn(dpatch, saved["patches"], f.g("patch_embed.proj.weight").view(D, PATCH_K),

@@ -1,5 +1,6 @@
 """One tiny fwd+bwd+SGD step of the whole hot path on cuda:0, checked against the CPU oracle.
-Called by __graft_entry__.smoke() (the oracle is imported HERE as the checker only)."""
+Called by __graft_entry__.smoke().  Test infrastructure: the oracle is imported HERE as the checker only; nothing under
+sais_amd/ imports oracle/."""
 import os
 import sys
 

@@ -124,13 +124,18 @@ def _dp_worker(rank, world, port, out):
     m.flat.grad.copy_(torch.randn(m.flat.numel, generator=g))
     local_v, local_m = vit.flat.grad.clone(), m.flat.grad.clone()
     # backward order: temporal first, then final norm, blocks last..first, embedding
-    sync.temporal_hook(m, T)(0, m.flat.numel)
+    # (the temporal hook fires once per backward CALL — three times with TTA list inputs — but the slices must be
+    # exchanged ONCE, over the longest stream seen: a second all-reduce would double-count the remote gradients)
+    m._touched_T = T
+    th = sync.temporal_hook(m)
+    th(0, m.flat.numel)
+    th(0, m.flat.numel)
     hook = sync.vit_hook(vit)
     hook(vit.flat.offsets["norm.weight"], vit.flat.numel)
     for i in reversed(range(2)):
         hook(*vit.block_grad_range(i))
     hook(0, vit.flat.offsets["blocks.0.norm1.weight"])
-    sync.wait()
+    nbytes = sync.wait()
     others_v = [torch.zeros_like(local_v) for _ in range(world)]
     others_m = [torch.zeros_like(local_m) for _ in range(world)]
     dist.all_gather(others_v, local_v)
@@ -147,7 +152,7 @@ def _dp_worker(rank, world, port, out):
     cover = all(touched[m.flat.offsets[n]] for n in names_touched) and not touched[m.flat.offsets["frame_pos_embeddings.5"]] \
         and not touched[m.flat.offsets["transEncoderClip.layers.0.linear1.weight"]]
     if rank == 0:
-        open(out, "w").write(f"{ok_v} {ok_m} {cover} {sync.bytes}")
+        open(out, "w").write(f"{ok_v} {ok_m} {cover} {nbytes}")
     dist.destroy_process_group()
 
 

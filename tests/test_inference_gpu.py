@@ -53,7 +53,7 @@ def test_long_video_512_frames_graph_extraction_and_windows(gpu):
     cos = lambda a: (a / a.norm(dim=1, keepdim=True)) @ (p / p.norm(dim=1, keepdim=True)).t()
     assert (cos(reps[idx].cpu()) - cos(ref)).abs().max().item() <= 1e-3
 
-    out, attention = run_windows(m, reps, flow_reps, videoname="synthetic", batch_size=2)
+    out, attention, _imp = run_windows(m, reps, flow_reps, videoname="synthetic", batch_size=2)
     wins = gesture_windows(N)
     assert len(wins) == 34 and len(out["reps"][0]) == 34 and len(out["videonames"]) == 34
     attn = torch.cat(attention)
@@ -112,17 +112,25 @@ def test_cli_main_sh_equivalent_on_synthetic_frames(gpu, tmp_path):
     model_io.save_params_file(m, fold / "params.zip")
     model_io.save_prototypes_file(synth.prototypes(2, 2), fold / "prototypes.zip")
     env = dict(os.environ, PYTHONPATH=ROOT)
-    ex = [sys.executable, os.path.join(ROOT, "SAIS/scripts/extract_representations.py"), "--arch", "vit_small",
-          "--patch_size", "16", "--model_type", "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "1024",
-          "--data_path", str(root) + "/", "--data_list", "Custom", "--save_type", "h5", "--video", "vid_01",
-          "--synthetic_frames", "64"]
-    subprocess.run(ex, check=True, env=env, cwd=ROOT)
-    subprocess.run(ex + ["--optical_flow_to_reps"], check=True, env=env, cwd=ROOT)
-    run = [sys.executable, os.path.join(ROOT, "SAIS/scripts/run_experiments.py"), "-p", str(root) + "/", "-data",
-           "Custom_Gestures", "-d", "Custom", "-m", "ViT", "-enc", "ViT_SelfSupervised_ImageNet", "-t", "Prototypes",
-           "-mod", "RGB-Flow", "-dim", "384", "-bs", "2", "-lr", "1e-1", "-nc", "2", "-bc", "-sa", "-domains",
-           "in_vs_out", "-ph", "Custom_inference", "-dt", "reps", "-e", "1", "-f", "1", "--inference"]
-    subprocess.run(run, check=True, env=env, cwd=ROOT)
+    sc = lambda name: os.path.join(ROOT, "SAIS/scripts", name)
+
+    def main_sh(video, nframes):
+        """the stages of SAIS/main.sh -f <video> -s <nframes> up to inference"""
+        subprocess.run([sys.executable, sc("generate_paths.py"), "-f", video, "-p", str(root) + "/", "--synthetic_frames",
+                        str(nframes)], check=True, env=env, cwd=ROOT)
+        ex = [sys.executable, sc("extract_representations.py"), "--arch", "vit_small",
+              "--patch_size", "16", "--model_type", "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "1024",
+              "--data_path", str(root) + "/", "--data_list", "Custom", "--save_type", "h5", "--video", video,
+              "--synthetic_frames", str(nframes)]
+        subprocess.run(ex, check=True, env=env, cwd=ROOT)
+        subprocess.run(ex + ["--optical_flow_to_reps"], check=True, env=env, cwd=ROOT)
+        run = [sys.executable, sc("run_experiments.py"), "-p", str(root) + "/", "-data",
+               "Custom_Gestures", "-d", "Custom", "-m", "ViT", "-enc", "ViT_SelfSupervised_ImageNet", "-t", "Prototypes",
+               "-mod", "RGB-Flow", "-dim", "384", "-bs", "2", "-lr", "1e-1", "-nc", "2", "-bc", "-sa", "-domains",
+               "in_vs_out", "-ph", "Custom_inference", "-dt", "reps", "-e", "1", "-f", "1", "--inference"]
+        subprocess.run(run, check=True, env=env, cwd=ROOT)
+
+    main_sh("vid_01", 64)
     r = torch.load(fold / "reps_and_labels_Custom_inference", weights_only=False)
     attn = torch.load(fold / "attention_Custom_inference", weights_only=False)
     imp = torch.load(fold / "importance_Custom_inference", weights_only=False)
@@ -132,6 +140,20 @@ def test_cli_main_sh_equivalent_on_synthetic_frames(gpu, tmp_path):
     assert r["labels"][0].dtype == torch.int64 and r["labels"][0].dim() == 0
     assert sum(a.shape[0] for a in attn) == nwin and tuple(attn[0].shape[1:]) == (16, 16)
     assert imp == []
+    # the features are a real HDF5 file with one dataset per video label (extract_representations.py:389-407)
+    from sais_amd.hdf5_min import read_h5
+    h5 = read_h5(str(root / "results" / "ViT_SelfSupervised_ImageNet_RepsAndLabels.h5"))
+    assert list(h5.keys()) == ["vid_01"] and h5["vid_01"].shape == (64, 384) and h5["vid_01"].dtype.name == "float32"
+    # a second, different video through the same project directory: the reps files are truncated (mode 'w') and the
+    # windows come from the regenerated Custom_Paths.csv, so the outputs describe the new video only and the
+    # post-processing stage lines up with them
+    main_sh("vid_02", 48)
+    r2 = torch.load(fold / "reps_and_labels_Custom_inference", weights_only=False)
+    nwin2 = (48 - 15) // 15 + 1
+    assert r2["videonames"] == ["vid_02"] * nwin2 and len(r2["reps"][0]) == nwin2
+    assert list(read_h5(str(root / "results" / "ViT_SelfSupervised_ImageNet_RepsAndLabels.h5")).keys()) == ["vid_02"]
+    subprocess.run([sys.executable, sc("process_inference_results.py"), "-p", str(root) + "/"], check=True, env=env, cwd=ROOT)
+    assert (root / "results" / "Custom_inference_gestures.csv").exists()
 
 
 def test_main_sh_on_jpeg_frames_end_to_end(gpu, tmp_path):

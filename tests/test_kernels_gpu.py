@@ -58,8 +58,8 @@ def test_gemm_tn_exact_integers(ops):
     assert torch.equal(db.cpu(), p.sum(0))
 
 
-# the last two shapes exercise the opt-in register-stationary kernel when SAIS_NT_RS=1 (M >= 8192, K = 384: whole
-# 128-row panels, the 57 ragged rows go to the 128x128 kernel; 256 full panels + a split tail in the last case)
+# M >= 8192 takes the persistent eight-wave kernel (ragged last tile, 512-workgroup persistent grid with and without a
+# second round); the last-but-one shape is 304 tiles x 9 column tiles = more tiles than persistent workgroups
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (50432 // 8, 1152, 384), (264, 2048, 384), (128, 384, 1536),
                                    (8192 + 3 * 128 + 57, 384, 384), (50432 - 128 * 90, 1152, 384),
                                    (8192 + 128 + 5, 512, 384)])
@@ -407,40 +407,3 @@ def test_gemm_tn_grouped_matches_individual(ops, M):
         assert_close(dW, rw, atol=2e-3 * math.sqrt(M), rtol=1e-4)
         if db is not None:
             assert_close(db, rb, atol=1e-3 * math.sqrt(M))
-
-
-def test_gemm_nt_wave_specialised_variant_matches(ops):
-    """The opt-in persistent loader/consumer GEMM (SAIS_GEMM_WS=1, gemm_ws.hip) against the default kernel."""
-    import ctypes
-    from sais_amd import _lib as L
-    lib = L.load()
-    lib.sais_gemm_nt_ws_.argtypes = [ctypes.POINTER(L.SaisGemm), ctypes.c_void_p]
-    lib.sais_gemm_nt_ws_.restype = ctypes.c_int
-    M, N, K = 197 * 64, 384, 1152
-    a = rnd(M, K, seed=120, dtype=torch.bfloat16)
-    w = rnd(N, K, seed=121, scale=0.05, dtype=torch.bfloat16)
-    bias, res = rnd(N, seed=122), rnd(M, N, seed=123)
-    for epi, f32 in ((L.EPI_BIAS_BF16, False), (L.EPI_BIAS_RESID_F32, True), (L.EPI_BIAS_GELU_BF16, False)):
-        dt = torch.float32 if f32 else torch.bfloat16
-        ref, out = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=dt, device=DEV)
-        aux = res if f32 else None
-        ops.gemm_nt(a, w, epi, ref, bias=bias, aux=aux)
-        g = L.SaisGemm(a.data_ptr(), K, w.data_ptr(), K, M, N, K, epi, bias.data_ptr(), out.data_ptr(), N, None, 0,
-                       None if aux is None else aux.data_ptr(), N if aux is not None else 0, 0, 0, 0)
-        assert lib.sais_gemm_nt_ws_(ctypes.byref(g), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
-        torch.cuda.synchronize()
-        assert_close(out, ref, atol=1e-2 if not f32 else 1e-3, rtol=1e-2, name=f"ws epi {epi}")
-
-
-def test_opt_in_gemm_variants_in_a_subprocess():
-    """The experimental NT paths that are selected by environment variable at library load (register-stationary
-    K = 384 kernel, no A ring) still produce the same results: run the epilogue test under each setting."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"SAIS_NT_RS": "1"}, {"SAIS_NT_PERSIST": "0"}, {"SAIS_NT_W8": "0"}, {"SAIS_NT_W8": "0", "SAIS_NT_A3": "0"}, {"SAIS_TN_WIDE": "0"}):
-        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-x", "-q",
-                            "-k", "epilogues or tn_grouped"], env=dict(os.environ, **env), cwd=root,
-                           capture_output=True, text=True)
-        assert r.returncode == 0, (env, r.stdout[-1500:])
