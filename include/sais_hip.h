@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 1
+#define SAIS_ABI_VERSION 2
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -93,6 +93,33 @@ int sais_gemm_tn_grouped_f32(const SaisTnItem* items, int nitems, int M, int nsp
 /* same as sais_gemm_tn with f32 P and Q (rounded to bf16 while staging; f32 accumulation) */
 int sais_gemm_tn_f32(const void* P, int ldp, const void* Q, int ldq, int M, int N1, int N2,
                      float* dW, int ldw, float* db, int nsplit, void* stream);
+
+/* ---------------------------------------------------------------- GEMM with LayerNorm in the epilogue (N = 384)
+ * The ViT block's residual stream is D = 384 wide, so a workgroup that owns a 128-row x 384-column output tile owns
+ * whole rows and can normalise them before they leave the registers (SURVEY §7 steps 4-5, §8b `proj_residual`,
+ * `fc2_residual`, `ln_qkv`, `ln_fc1_gelu`):
+ *   sais_gemm_ln_fwd:  x_out = A . W^T + bias + resid ;  out16 = LayerNorm(x_out; gamma, beta, eps) ; mean/rstd saved.
+ *       = `x = x + attn.proj(...)` / `x = x + mlp.fc2(...)` followed by the NEXT `norm2` / `norm1`
+ *         (Block.forward, dino-main/vision_transformer.py:107-113; nn.LayerNorm(eps=1e-6) via vit_small :243-247).
+ *   sais_gemm_ln_bwd:  dy = A . W^T (the dX of fc1 / qkv: autograd of F.linear, :59-65 / :80-92) followed by autograd
+ *       of that LayerNorm:  dx = dres + rstd (dy g - mean(dy g) - xhat mean(dy g xhat)),  dgamma += sum_m dy xhat,
+ *       dbeta += sum_m dy.  `resid` is the LayerNorm INPUT x saved by the forward, `mean`/`rstd` its statistics.
+ * W is bf16 [384,K] (K % 64 == 0), A bf16 [M,K]; out32 / dres may alias (in-place residual-gradient update).       */
+typedef struct SaisGemmLn {
+    const void* A; int lda;        /* bf16 [M,K]                                              */
+    const void* W; int ldw;        /* bf16 [384,K]                                            */
+    int M, K;
+    const float* bias;             /* fwd: f32 [384] or NULL; bwd: unused                     */
+    const float* resid; int ldr;   /* fwd: residual f32 [M,384]; bwd: LayerNorm input x f32   */
+    float* out32; int ldo32;       /* fwd: x_out; bwd: dx (f32, optional)                     */
+    void* out16; int ldo16;        /* fwd: LayerNorm(x_out) bf16; bwd: dx bf16 (optional)     */
+    const float* gamma; const float* beta; float eps;
+    float* mean; float* rstd;      /* fwd: outputs [M] (optional); bwd: inputs                */
+    const float* dres; int lddres; /* bwd: residual-stream gradient added to dx (optional)    */
+    float* dgamma; float* dbeta;   /* bwd: f32 [384], accumulated (both or neither)           */
+} SaisGemmLn;
+int sais_gemm_ln_fwd(const SaisGemmLn* g, void* stream);
+int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm over dim = 384
  * nn.LayerNorm in Block / final norm (vision_transformer.py:99,103,107-113,212; eps 1e-6 from

@@ -28,6 +28,14 @@ class SaisTnItem(ctypes.Structure):
                 ("dW", c_void_p), ("ldw", c_int), ("db", c_void_p)]
 
 
+class SaisGemmLn(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int), ("W", c_void_p), ("ldw", c_int), ("M", c_int), ("K", c_int),
+                ("bias", c_void_p), ("resid", c_void_p), ("ldr", c_int), ("out32", c_void_p), ("ldo32", c_int),
+                ("out16", c_void_p), ("ldo16", c_int), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
+                ("mean", c_void_p), ("rstd", c_void_p), ("dres", c_void_p), ("lddres", c_int),
+                ("dgamma", c_void_p), ("dbeta", c_void_p)]
+
+
 EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
 EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
@@ -38,6 +46,8 @@ SIGNATURES = {
     "sais_abi_version": [],
     "sais_gemm_nt": [ctypes.POINTER(SaisGemm), c_void_p],
     "sais_gemm_nt_f32": [ctypes.POINTER(SaisGemm), c_void_p],
+    "sais_gemm_ln_fwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
+    "sais_gemm_ln_bwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
     "sais_gemm_tn_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_transpose_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_gemm_tn_grouped": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p],

@@ -86,6 +86,40 @@ DEVINL void gelu_and_grad(float u, float& y, float& dy) {      // both from one 
     dy = fmaf(u * 0.3989422804014327f, e, cdf);
 }
 
+// ---- shared by the GEMM kernels (gemm.hip, gemm_row.hip) --------------------------------------------------------
+// LDS tile image: 128-B rows (64 bf16), 16-B chunk index XOR (row & 7) -> conflict-free ds_read_b128 fragment reads.
+DEVINL int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// weight-row permutation inside a 64-row wave panel: n_local = 16a + 4t + b  ->  LDS row 16t + 4a + b, so that with
+// the operands swapped in the MFMA a lane ends up with 16 CONTIGUOUS output columns of one output row
+DEVINL int perm_row(int n) { return (n & 64) | ((n & 0x0c) << 2) | ((n & 0x30) >> 2) | (n & 3); }
+
+// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the
+// 8 XCDs, so hand each XCD a CONTIGUOUS run of logical tiles.
+DEVINL int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at a wave-uniform base
+DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15); every lane of the row gets the total
+template <int CTRL>
+DEVINL float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+DEVINL float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);      // row_half_mirror
+    v += dpp_mov<0x140>(v);      // row_mirror
+    return v;
+}
+
 // hipGetLastError is sticky across the whole process (torch included): clear it on entry so that
 // sais_check_launch() reports only this call's own launch status.
 #define SAIS_ENTER() (void)hipGetLastError()

@@ -31,11 +31,6 @@ struct NtParams {
     int grp_in, grp_out, grp_off;
 };
 
-DEVINL int swz(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
-
-// weight-row permutation inside a 64-row wave panel: n_local = 16a + 4t + b  ->  LDS row 16t + 4a + b
-DEVINL int perm_row(int n) { return (n & 64) | ((n & 0x0c) << 2) | ((n & 0x30) >> 2) | (n & 3); }
-
 // Epilogue in two phases.  vmcnt is in-order and counts stores on CDNA4, so a load issued after a store cannot be
 // consumed before that store has been acknowledged: phase A issues EVERY load a lane needs (bias once, the
 // residual / pre-activation rows of all four 16-row sub-tiles), phase B only does arithmetic and stores.
@@ -135,19 +130,6 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16], cons
         for (int i = 0; i < 16; ++i) y[i] = (float)a.u[mt][i >> 3][i & 7] > 0.f ? y[i] : 0.f;
         store_bf16(p.out, p.ldo, y);
     }
-}
-
-// XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the
-// 8 XCDs, so hand each XCD a CONTIGUOUS run of logical tiles; tiles are numbered n-fastest, hence the
-// workgroups that share an A row-panel (and walk the small weight matrix) hit the same private L2.
-DEVINL int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-
-DEVINL void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // Staging is LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write): one wave-instruction fills
@@ -979,6 +961,8 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
             hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
         break;
 
+extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream);      // gemm_row.hip: 128 x 384 row-owning tiles
+
 extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     SAIS_ENTER();
     if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
@@ -995,6 +979,13 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
     // four-wave A-ring) were measured slower inside the step and are gone from the library.
     const bool big = g->M >= 8192;
+#ifndef SAIS_NO_ROW_PLAIN
+    // the ViT GEMMs of a training step (N = 384 / 1152 / 1536): 128 x 384 tiles of gemm_row.hip
+    if (big && g->N % 384 == 0 && (g->epilogue == SAIS_EPI_BIAS_BF16 || g->epilogue == SAIS_EPI_MUL_BF16 ||
+                                   g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 ||
+                                   (g->epilogue == SAIS_EPI_BIAS_RESID_F32 && !g->out2)))
+        return sais_gemm_nt_row_(g, stream);
+#endif
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)

@@ -82,6 +82,45 @@ def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0,
     return out
 
 
+ROW_GEMM_MIN_M = 8192        # from this M on, the ViT GEMMs run on the 128 x 384 row-owning kernel (gemm_row.hip)
+
+
+def _ld(t):
+    return 0 if t is None else t.stride(-2)
+
+
+def gemm_ln_fwd(a, w, bias, resid, x_out, xn_out, gamma, beta, eps, mean=None, rstd=None):
+    """x_out f32[M,384] = a[M,K] . w[384,K]^T + bias + resid ;  xn_out bf16 = LayerNorm(x_out) ; mean/rstd saved.
+    One launch (LayerNorm in the GEMM epilogue); resid and x_out may be the same tensor."""
+    _chk(a, BF16, "A"); _chk(w, BF16, "W"); _chk(bias, F32, "bias"); _chk(resid, F32, "resid")
+    _chk(x_out, F32, "x_out"); _chk(xn_out, BF16, "xn_out"); _chk(gamma, F32, "gamma"); _chk(beta, F32, "beta")
+    M, K = a.shape
+    if tuple(w.shape) != (384, K):
+        raise L.SaisHipError(f"gemm_ln_fwd: W must be [384,{K}], got {tuple(w.shape)}")
+    g = L.SaisGemmLn(_p(a), a.stride(0), _p(w), w.stride(0), M, K, _p(bias), _p(resid), _ld(resid), _p(x_out),
+                     _ld(x_out), _p(xn_out), _ld(xn_out), _p(gamma), _p(beta), eps, _p(mean), _p(rstd), None, 0,
+                     None, None)
+    nbytes = 2 * (M * K + 384 * K) + M * 384 * (4 + 4 + 2)
+    _timed(f"gemm_ln_fwd[N384,K{K}]", 2.0 * M * 384 * K, nbytes,
+           lambda: L.call("sais_gemm_ln_fwd", ctypes.byref(g), _stream()))
+
+
+def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dgamma=None, dbeta=None):
+    """dy = a[M,K] . w[384,K]^T, then LayerNorm backward at the saved input x / mean / rstd:
+    dx = dres + dLN(dy) -> dx32 (f32) and/or dx16 (bf16); dgamma / dbeta accumulated.  dres may alias dx32."""
+    _chk(a, BF16, "A"); _chk(w, BF16, "W"); _chk(x, F32, "x"); _chk(dres, F32, "dres"); _chk(dx32, F32, "dx32")
+    _chk(dx16, BF16, "dx16"); _chk(gamma, F32, "gamma")
+    M, K = a.shape
+    if tuple(w.shape) != (384, K):
+        raise L.SaisHipError(f"gemm_ln_bwd: W must be [384,{K}], got {tuple(w.shape)}")
+    g = L.SaisGemmLn(_p(a), a.stride(0), _p(w), w.stride(0), M, K, None, _p(x), _ld(x), _p(dx32), _ld(dx32),
+                     _p(dx16), _ld(dx16), _p(gamma), None, 0.0, _p(mean), _p(rstd), _p(dres), _ld(dres),
+                     _p(dgamma), _p(dbeta))
+    nbytes = 2 * (M * K + 384 * K) + M * 384 * (4 + 4 + 4 + 2)
+    _timed(f"gemm_ln_bwd[N384,K{K}]", 2.0 * M * 384 * K, nbytes,
+           lambda: L.call("sais_gemm_ln_bwd", ctypes.byref(g), _stream()))
+
+
 def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None):
     """fp32-operand variant (bf16x3 split on the matrix cores): out f32[M,N] = a f32[M,K] . w f32[N,K]^T."""
     _chk(a, F32, "A"); _chk(w, F32, "B"); _chk(bias, F32, "bias"); _chk(out, F32, "out"); _chk(aux, F32, "aux")

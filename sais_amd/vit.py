@@ -184,16 +184,23 @@ class VisionTransformer(nn.Module):
         ops.vit_cls_rows(f.w32("cls_token"), f.w32("pos_embed"), x, Fr)
         x = x.view(M, D)
         saved = {"patches": patches, "blocks": [], "Fr": Fr} if save else None
+        # Large M (training step, big extraction batches): the N = 384 GEMMs run on the row-owning kernel with the
+        # FOLLOWING LayerNorm in their epilogue (sais_gemm_ln_fwd): proj -> norm2, fc2 -> the next block's norm1.
+        # Only block 0's norm1 and the final norm remain stand-alone launches.
+        fused = M >= ops.ROW_GEMM_MIN_M
         xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
+        xn2 = e16(M, D)
+        mean1 = rstd1 = None
         for i in range(self.depth):
             p = f"blocks.{i}."
             last_attn = want_last_attn and i == self.depth - 1
             if save:
-                xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
-            mean1 = e32(M) if save else None
-            rstd1 = e32(M) if save else None
-            ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
-                              rstd=rstd1)
+                qkv, ao, h = e16(M, 3 * D), e16(M, D), e16(M, HID)
+            if i == 0 or not fused:                      # otherwise xn / mean1 / rstd1 came out of the previous fc2
+                if save:
+                    xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
+                ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
+                                  rstd=rstd1)
             ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
             lse = e32(Fr, HEADS, NTOK) if save else None
             probs = e32(Fr, HEADS, NTOK, NTOK) if last_attn else None
@@ -201,22 +208,35 @@ class VisionTransformer(nn.Module):
             if last_attn:
                 return probs, None
             x_mid = e32(M, D) if save else x
-            ops.gemm_nt(ao, f.w(p + "attn.proj.weight"), L.EPI_BIAS_RESID_F32, x_mid, bias=f.w32(p + "attn.proj.bias"),
-                        aux=x)
-            xn2 = e16(M, D) if save else xn
+            if save:
+                xn2 = e16(M, D)
             mean2 = e32(M) if save else None
             rstd2 = e32(M) if save else None
-            ops.layernorm_fwd(x_mid, M, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2,
-                              mean=mean2, rstd=rstd2)
+            if fused:
+                ops.gemm_ln_fwd(ao, f.w(p + "attn.proj.weight"), f.w32(p + "attn.proj.bias"), x, x_mid, xn2,
+                                f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, mean2, rstd2)
+            else:
+                ops.gemm_nt(ao, f.w(p + "attn.proj.weight"), L.EPI_BIAS_RESID_F32, x_mid,
+                            bias=f.w32(p + "attn.proj.bias"), aux=x)
+                ops.layernorm_fwd(x_mid, M, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2,
+                                  mean=mean2, rstd=rstd2)
             u = e16(M, HID) if save else None
             ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
                         bias=f.w32(p + "mlp.fc1.bias"), out2=u)
             x_out = e32(M, D) if save else x
-            ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"),
-                        aux=x_mid)
+            blk = dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, mean2=mean2,
+                       rstd2=rstd2, xn2=xn2, dgelu=u, h=h) if save else None
+            if fused and i + 1 < self.depth:
+                q = f"blocks.{i + 1}."
+                if save:
+                    xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
+                ops.gemm_ln_fwd(h, f.w(p + "mlp.fc2.weight"), f.w32(p + "mlp.fc2.bias"), x_mid, x_out, xn,
+                                f.w32(q + "norm1.weight"), f.w32(q + "norm1.bias"), 1e-6, mean1, rstd1)
+            else:
+                ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"),
+                            aux=x_mid)
             if save:
-                saved["blocks"].append(dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=lse,
-                                            x_mid=x_mid, mean2=mean2, rstd2=rstd2, xn2=xn2, dgelu=u, h=h))
+                saved["blocks"].append(blk)
             x = x_out
         reps = e32(Fr, D)
         meanN = e32(Fr) if save else None
@@ -240,7 +260,8 @@ class VisionTransformer(nn.Module):
         ops.layernorm_bwd(saved["x_final"], NTOK * D, saved["meanN"], saved["rstdN"], f.w32("norm.weight"), Fr,
                           dy32=dreps, dx32=dx, lddx32=NTOK * D, dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
         ops.cast_bf16(dx, dxa)
-        dxn, dao, du, dqkv = e16(M, D), e16(M, D), e16(M, HID), e16(M, 3 * D)
+        fused = M >= ops.ROW_GEMM_MIN_M
+        dxn, dao, du, dqkv = (None if fused else e16(M, D)), e16(M, D), e16(M, HID), e16(M, 3 * D)
         delta = torch.empty(Fr, HEADS, NTOK, dtype=torch.float32, device=dev)
         if self.grad_ready_hook:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
@@ -249,9 +270,14 @@ class VisionTransformer(nn.Module):
             s = saved["blocks"][i]
             # MLP branch
             ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
-            ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
-            ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
-                              dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))
+            if fused:         # dX of fc1 with norm2's backward (+ residual gradient) in its epilogue
+                ops.gemm_ln_bwd(du, f.wt16[p + "mlp.fc1.weight"], s["x_mid"], s["mean2"], s["rstd2"],
+                                f.w32(p + "norm2.weight"), dres=dx, dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"),
+                                dbeta=f.g(p + "norm2.bias"))
+            else:
+                ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
+                ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
+                                  dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))
             # attention branch
             ops.gemm_nt(dxb, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
             ops.vit_attn_bwd(s["qkv"], dao, s["ao"], s["lse"], delta, Fr, dqkv)
@@ -262,9 +288,14 @@ class VisionTransformer(nn.Module):
                 (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
                 (dxb, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias")),
                 (dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
-            ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn)
-            ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,
-                              dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
+            if fused:         # dX of qkv with norm1's backward in its epilogue
+                ops.gemm_ln_bwd(dqkv, f.wt16[p + "attn.qkv.weight"], s["x_in"], s["mean1"], s["rstd1"],
+                                f.w32(p + "norm1.weight"), dres=dx, dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"),
+                                dbeta=f.g(p + "norm1.bias"))
+            else:
+                ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn)
+                ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,
+                                  dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
             saved["blocks"][i] = None
             if self.grad_ready_hook:                  # the block's gradient slice is final: DP all-reduce may start
                 self.grad_ready_hook(*self.block_grad_range(i))

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib.sais_abi_version.restype = ctypes.c_int
-    assert lib.sais_abi_version() == 1
+    assert lib.sais_abi_version() == 2
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -29,6 +29,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_gemm_nt(None, None) == -1
     g = _lib.SaisGemm()
     assert lib.sais_gemm_nt(ctypes.byref(g), None) == -1
+    assert lib.sais_gemm_ln_fwd(None, None) == -1 and lib.sais_gemm_ln_bwd(ctypes.byref(_lib.SaisGemmLn()), None) == -1
     assert lib.sais_layernorm_fwd(None, 384, 4, 384, None, None, 1e-6, None, 384, None, 384, None, None, None) == -1
     assert lib.sais_vit_attn_fwd(None, 1152, 1, None, 384, None, None, None) == -1
     assert lib.sais_temporal_attn_fwd(None, None, 1, 1000, None, None, None) == -1

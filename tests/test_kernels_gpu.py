@@ -407,3 +407,62 @@ def test_gemm_tn_grouped_matches_individual(ops, M):
         assert_close(dW, rw, atol=2e-3 * math.sqrt(M), rtol=1e-4)
         if db is not None:
             assert_close(db, rb, atol=1e-3 * math.sqrt(M))
+
+
+# ------------------------------------------------------------------ row-owning GEMM with LayerNorm in the epilogue
+def _ln_ref(x, gamma, beta, eps):
+    return F.layer_norm(x, (384,), gamma, beta, eps)
+
+
+@pytest.mark.parametrize("M,K", [(300, 384), (8192 + 128 + 57, 1536), (12608, 384)])
+def test_gemm_ln_fwd(ops, M, K):
+    """x_out = A.W^T + b + resid ; xn = LayerNorm(x_out) in ONE launch vs fp32 torch (ragged last tile included)."""
+    a = rnd(M, K, seed=200, dtype=torch.bfloat16)
+    w = rnd(384, K, seed=201, scale=0.05, dtype=torch.bfloat16)
+    bias, resid = rnd(384, seed=202, scale=0.1), rnd(M, 384, seed=203, scale=2.0)
+    resid[:, 7] += 30.0                                   # an outlier channel: mean/variance must not lose it
+    gamma, beta = 1 + 0.1 * rnd(384, seed=204), 0.05 * rnd(384, seed=205)
+    x_out = torch.empty(M, 384, device=DEV)
+    xn = torch.empty(M, 384, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    ops.gemm_ln_fwd(a, w, bias, resid, x_out, xn, gamma, beta, 1e-6, mean, rstd)
+    ref_x = a.float() @ w.float().t() + bias + resid
+    assert_close(x_out, ref_x, atol=2e-3, rtol=1e-5, name="x_out")
+    assert_close(mean, ref_x.mean(1), atol=1e-4, name="mean")
+    assert_close(rstd, 1.0 / torch.sqrt(ref_x.var(1, unbiased=False) + 1e-6), atol=0, rtol=1e-4, name="rstd")
+    assert_close(xn, _ln_ref(x_out, gamma, beta, 1e-6), atol=2e-2, rtol=1e-2, name="xn")      # bf16 rounding of the output
+    # in place on the residual stream (the inference path)
+    r2 = resid.clone()
+    ops.gemm_ln_fwd(a, w, bias, r2, r2, xn, gamma, beta, 1e-6)
+    assert torch.equal(r2, x_out)
+
+
+@pytest.mark.parametrize("M,K", [(300, 1152), (8192 + 57, 1536), (12608, 1152)])
+def test_gemm_ln_bwd(ops, M, K):
+    """dy = A.W^T ; dx = dres + dLN(dy) ; dgamma, dbeta — vs torch autograd of layer_norm on the fp32 dy."""
+    a = rnd(M, K, seed=210, scale=0.5, dtype=torch.bfloat16)
+    w = rnd(384, K, seed=211, scale=0.05, dtype=torch.bfloat16)
+    x = rnd(M, 384, seed=212, scale=1.5)
+    x[:, 11] -= 20.0
+    gamma = 1 + 0.1 * rnd(384, seed=213)
+    dres = rnd(M, 384, seed=214)
+    mean = x.mean(1)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+    dgamma, dbeta = torch.zeros(384, device=DEV), torch.zeros(384, device=DEV)
+    dx32 = dres.clone()                                    # in place, as the ViT backward uses it
+    dx16 = torch.empty(M, 384, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=dx32, dx32=dx32, dx16=dx16, dgamma=dgamma, dbeta=dbeta)
+    dy = a.float() @ w.float().t()
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = torch.zeros(384, device=DEV, requires_grad=True)
+    F.layer_norm(xr, (384,), gr, br, 1e-6).backward(dy)
+    scale = dy.abs().max().item()
+    assert_close(dx32, xr.grad + dres, atol=2e-4 * scale, rtol=1e-4, name="dx32")
+    assert_close(dx16, xr.grad + dres, atol=2e-2, rtol=1e-2, name="dx16")
+    assert_close(dgamma, gr.grad, atol=2e-4 * scale * math.sqrt(M), rtol=1e-4, name="dgamma")
+    assert_close(dbeta, br.grad, atol=2e-4 * scale * math.sqrt(M), rtol=1e-4, name="dbeta")
+    # without the residual gradient / without the column sums
+    dx_only = torch.empty(M, 384, device=DEV)
+    ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dx32=dx_only)
+    assert_close(dx_only, xr.grad, atol=2e-4 * scale, rtol=1e-4, name="dx (no dres)")
