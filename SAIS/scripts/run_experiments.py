@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Drop-in for the inference surface of the reference's SAIS/scripts/run_experiments.py (:19-121) on MI355X:
-same flags, same params/Fold_<k>/ layout ((params.zip, prototypes.zip) in, reps_and_labels_<ph> / attention_<ph> /
-importance_<ph> out, train.py:113-119).  Only what main.sh:27 exercises is implemented:
--data Custom_Gestures -m ViT -t Prototypes -dt reps, phases ending in `inference`."""
+"""Drop-in for the reference's SAIS/scripts/run_experiments.py (:19-121) on MI355X: same flags, same
+params/Fold_<k>/ layout.
+  --inference (what main.sh:27 runs): (params.zip, prototypes.zip) in, reps_and_labels_<ph> / attention_<ph> /
+      importance_<ph> out (train.py:113-119), windows from paths/Custom_Paths.csv.
+  without --inference: sais_amd.train.trainModel (train.py:18-121) on the feature files under results/ and the
+      annotated windows of paths/<dataset>_Annotations.csv; writes params / prototypes / metrics / reps_and_labels.
+Only -m ViT -t Prototypes -dt reps is on this build's path."""
 import argparse
 import os
 import sys
@@ -44,10 +47,24 @@ def main():
     a = p.parse_args()
     print('Modalities: %s' % a.modalities)
     print('Self Attention: %s' % str(a.self_attention))
-    if not a.inference or a.dataset_name != 'Custom_Gestures':
-        raise SystemExit('this build covers the inference surface of main.sh:27 (Custom_Gestures, --inference); '
-                         'training on the private datasets needs prepare_dataset.py, which is out of scope')
     t0 = time.time()
+    if a.model != 'ViT' or a.task != 'Prototypes' or a.data_type != 'reps':
+        raise SystemExit('this build covers -m ViT -t Prototypes -dt reps only (SURVEY.md §8)')
+    if not a.inference:
+        from sais_amd.train import trainModel
+        for domain in a.domains:
+            for fold in range(a.nfolds):
+                savepath = os.path.join(a.path, 'params/Fold_%i' % fold)             # getSavepath :82-83
+                print('***** \n Savepath: %s \n *****' % savepath)
+                trainModel(a.local_rank, 1, a.path, savepath, a.dataset_name, a.data_type, a.batch_size, a.nclasses,
+                           domain, a.phases, a.learning_rate, a.modalities, a.freeze_encoder, False, a.task,
+                           a.balance_classes, a.balance_groups, a.single_group, 'None', a.self_attention,
+                           a.importance_loss, a.model, a.encoder_params, 5, 1, 0, a.rep_dim, a.nepochs, fold,
+                           a.training_fraction)
+        print('Time taken (s): %.3f' % (time.time() - t0))
+        return
+    if a.dataset_name != 'Custom_Gestures':
+        raise SystemExit('--inference is built for -data Custom_Gestures (main.sh:27)')
     from sais_amd.inference import run_windows, save_inference_outputs, tta_probs
     from sais_amd.model_io import loadModel
     from sais_amd.postprocess import read_frame_counts

@@ -1,0 +1,336 @@
+"""Training harness of the SAIS hot path on MI355X — drop-in for the reference's
+SAIS/scripts/train.py:18-121 (`trainModel`), perform_training.py:49-227 (`single_epoch`),
+prepare_dataset.py:2798-2899 (`createPaddingMask`, `pad_collate`, Prototypes branch) and
+prepare_miscellaneous.py:111-185 (`calcNCEMetrics`), for `-t Prototypes -m ViT -dt reps`.
+
+What runs where: the arithmetic of a step (temporal encoder forward / backward, prototype loss, SGD) is the HIP
+path (sais_amd.temporal / loss / optim); everything in this file is the reference's HOST logic restated — batching,
+padding, the epoch / phase loop, early stopping on the validation loss (patience 5), the best-validation snapshot and
+the files rank 0 writes: `params` (module.-prefixed state_dict), `prototypes` (pickled nn.ParameterDict), `metrics`,
+`reps_and_labels` — which `loadModel(..., inference=True)` reads back once renamed *.zip (README.md:64-75).
+
+Dataset.  The reference trains on private surgical datasets through prepare_dataset.VideoDataset; what a Prototypes /
+reps item IS there (prepare_dataset.py:2631-2700) is restated by `GestureWindows`: annotated windows
+(Video, Gesture, StartFrame, EndFrame) over the per-video feature files, `arange(start-1, end-1, (end-start)//10)` frame
+indices (+3 / +6 offsets for the two extra test-time-augmentation versions in val / test / inference), flow rows
+`unique(idx // 15)`.  The annotation table is this build's own CSV (paths/<dataset>_Annotations.csv: Video, Gesture,
+StartFrame, EndFrame, phase) since the reference's tables are not public.
+
+Data parallel: with torch.distributed initialised, every rank takes a strided shard of the training windows, the
+gradients are exchanged by sais_amd.parallel.GradSync (touched slices only) and 1/world is folded into SGD.
+"""
+import copy
+import csv
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+from . import _lib as L
+from .loss import calcImportanceLoss, calcNCELoss, cosine_logits_and_probs
+from .model_io import loadModel, save_prototypes_file
+
+FLOW_JUMP = 15
+TTA_OFFSETS = (0, 3, 6)
+
+
+# ------------------------------------------------------------------------------------------ collate (host)
+def createPaddingMask(x, lens):
+    """prepare_dataset.py:2798-2806.  x: list of [nframes, nsnippets, dim]; True = masked key; slot 0 is the CLS token."""
+    nsnippets = max(el.shape[1] for el in x)
+    key_padding_mask = torch.zeros(len(x), nsnippets, max(lens) + 1).type(torch.bool)
+    for row, xlen in zip(range(key_padding_mask.shape[0]), lens):
+        key_padding_mask[row, :, xlen + 1:] = True
+    return key_padding_mask
+
+
+def pad_collate(batch):
+    """pad_collate, Prototypes branch (:2839-2899).  batch items: (videoname, snippets, flows, label, frames_importance,
+    domain) with snippets / flows either tensors [nsnippets, nframes, dim] (training) or tuples of 3 such tensors (TTA).
+    Returns the reference's 11-tuple: videoname, snippets_padded, flows_padded, frames_importance_padded, label,
+    snippets_lens, flows_lens, snippets_mask, flows_mask, frames_importance_mask, domains (dicts keyed 0/1/2 under TTA)."""
+    videoname, snippets, flows, label, frames_importance, domains = zip(*batch)
+    if isinstance(snippets[0], tuple):
+        snippets_lens, snippets_padded, snippets_mask = {}, {}, {}
+        flows_lens, flows_padded, flows_mask = {}, {}, {}
+        nbatch, nversions = len(snippets), len(snippets[0])
+        for i in range(nversions):
+            for src, lens_d, pad_d, mask_d in ((snippets, snippets_lens, snippets_padded, snippets_mask),
+                                               (flows, flows_lens, flows_padded, flows_mask)):
+                seq = [src[n][i] for n in range(nbatch)]
+                lens = [s.shape[1] for s in seq]
+                seq = [s.permute(1, 0, 2) for s in seq]                  # nframes x nsnippets x dim
+                mask_d[i] = createPaddingMask(seq, lens)
+                pad_d[i] = pad_sequence(seq, batch_first=True, padding_value=0).permute(0, 2, 1, 3)
+                lens_d[i] = lens
+        frames_importance_padded = torch.zeros(1, 1)                     # placeholders (:2873-2874)
+        frames_importance_mask = torch.zeros(1, 1)
+    else:
+        snippets_lens = [s.shape[1] for s in snippets]
+        flows_lens = [f.shape[1] for f in flows]
+        frames_importance = [i.permute(1, 0) for i in frames_importance]        # nframes x 1
+        snippets = [s.permute(1, 0, 2) for s in snippets]
+        flows = [f.permute(1, 0, 2) for f in flows]
+        snippets_mask = createPaddingMask(snippets, snippets_lens)
+        flows_mask = createPaddingMask(flows, flows_lens)
+        frames_importance_mask = createPaddingMask(frames_importance, snippets_lens)
+        snippets_padded = pad_sequence(snippets, batch_first=True, padding_value=0).permute(0, 2, 1, 3)
+        flows_padded = pad_sequence(flows, batch_first=True, padding_value=0).permute(0, 2, 1, 3)
+        frames_importance_padded = pad_sequence(frames_importance, batch_first=True, padding_value=0).permute(0, 2, 1)
+    videoname = [v for v in videoname]
+    label = torch.stack([l for l in label])
+    return (videoname, snippets_padded, flows_padded, frames_importance_padded, label, snippets_lens, flows_lens,
+            snippets_mask, flows_mask, frames_importance_mask, domains)
+
+
+# ------------------------------------------------------------------------------------------ dataset (host)
+class GestureWindows(torch.utils.data.Dataset):
+    """Prototypes / reps items as prepare_dataset.VideoDataset.__getitem__ builds them (:2631-2700)."""
+
+    def __init__(self, rows, rgb_reps, flow_reps, classes, phase, domain):
+        self.rows, self.rgb, self.flow = rows, rgb_reps, flow_reps
+        self.classes = sorted(classes)                         # LabelEncoder order
+        self.phase, self.domain = phase, domain
+
+    def __len__(self):
+        return len(self.rows)
+
+    def _version(self, video_reps, flow_reps, start, end, off, jump):
+        idx = list(np.arange(start + off, end, jump))
+        x = torch.tensor(video_reps[idx, :], dtype=torch.float).unsqueeze(0)
+        rows = [r for r in np.unique([i // FLOW_JUMP for i in idx]) if r < len(flow_reps)]
+        f = torch.tensor(flow_reps[rows, :], dtype=torch.float).unsqueeze(0)
+        return x, f
+
+    def __getitem__(self, i):
+        r = self.rows[i]
+        video = r["Video"]
+        label = torch.tensor(self.classes.index(r["Gesture"]), dtype=torch.long)
+        start, end = int(r["StartFrame"]) - 1, int(r["EndFrame"]) - 1
+        jump = max((end - start) // 10, 1)
+        video_reps, flow_reps = self.rgb[video], self.flow[video]
+        if self.phase in ("train", "train+val"):
+            x, f = self._version(video_reps, flow_reps, start, end, 0, jump)
+            return video, x, f, label, torch.zeros(1, x.shape[1], dtype=torch.float), self.domain
+        vs = [self._version(video_reps, flow_reps, start, end, off, jump) for off in TTA_OFFSETS]
+        xs, fs = tuple(v[0] for v in vs), tuple(v[1] for v in vs)
+        return video, xs, fs, label, torch.zeros(1, xs[0].shape[1], dtype=torch.float), self.domain
+
+
+def read_annotations(path):
+    """paths/<dataset>_Annotations.csv -> {phase: [row dict]} and the sorted class list."""
+    by_phase, classes = defaultdict(list), set()
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            by_phase[row["phase"]].append(row)
+            classes.add(row["Gesture"])
+    return by_phase, sorted(classes)
+
+
+def load_dataloaders(root_path, dataset_name, batch_size, phases, domain, encoder_params, rank=0, world_size=1, seed=0):
+    """loadDataloader(...).load() (:2790-2796): shuffle only the training phases, drop_last=False, pad_collate."""
+    from .hdf5_min import read_h5
+    rgb = read_h5(os.path.join(root_path, "results", "%s_RepsAndLabels.h5" % encoder_params))
+    flow = read_h5(os.path.join(root_path, "results", "ViT_SelfSupervised_ImageNet_FlowRepsAndLabels.h5"))
+    by_phase, classes = read_annotations(os.path.join(root_path, "paths", "%s_Annotations.csv" % dataset_name))
+    loaders = {}
+    for phase in phases:
+        rows = by_phase[phase]
+        train = phase in ("train", "train+val")
+        if train and world_size > 1:
+            rows = rows[rank::world_size]                      # data parallel: a strided shard of the windows per rank
+        ds = GestureWindows(rows, rgb, flow, classes, phase, domain)
+        g = torch.Generator().manual_seed(seed)
+        loaders[phase] = torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=train, drop_last=False,
+                                                     collate_fn=pad_collate, generator=g)
+    return loaders, classes
+
+
+# ------------------------------------------------------------------------------------------ metrics (host)
+def calcNCEMetrics(rank, snip_sequence_list, labels_list, videoname_list, gesture_prototypes):
+    """prepare_miscellaneous.py:111-171: probabilities (mean over the TTA versions), accuracy, macro precision / recall,
+    AUC.  The probabilities come from the HIP head kernel; the scores are sklearn on the host, as in the reference."""
+    from sklearn.metrics import precision_score, recall_score, roc_auc_score
+    keys = list(gesture_prototypes.keys())
+    labels = torch.stack([l.detach().cpu() for l in labels_list])
+    cols = torch.tensor([keys.index(str(int(l))) for l in labels])
+    versions = snip_sequence_list if isinstance(snip_sequence_list, tuple) else (snip_sequence_list,)
+    probs = None
+    for v in versions:
+        p = cosine_logits_and_probs(torch.stack(list(v)), gesture_prototypes)[1].cpu()
+        probs = p if probs is None else probs + p
+    probs = probs / len(versions)
+    preds = torch.argmax(probs, 1)
+    acc = (torch.sum(preds == cols) / preds.shape[0]).item()
+    y, yhat, pr = cols.numpy(), preds.numpy(), probs.numpy()
+    prec = precision_score(y, yhat, average="macro", zero_division=0)
+    rec = recall_score(y, yhat, average="macro", zero_division=0)
+    if len(keys) == 2:
+        pr = pr[:, -1]
+    try:
+        auc = roc_auc_score(y, pr, multi_class="ovr")
+    except Exception:
+        auc = float("nan")
+    return acc, auc, prec, rec
+
+
+def trackMetrics(metrics, metrics_dict):
+    for name, value in metrics.items():
+        metrics_dict[name].append(value)
+    return metrics_dict
+
+
+def printMetrics(phase, metrics):
+    names = [phase + "_" + n for n in metrics]
+    print("  ".join(names))
+    print("  ".join("%.3f" % v for v in metrics.values()))
+
+
+# ------------------------------------------------------------------------------------------ one epoch
+def single_epoch(rank, world_size, dataloader, model_dict, optimizer, device, phase, nclasses, task, importance_loss,
+                 sync=None):
+    """perform_training.single_epoch (:49-227), Prototypes task.  Returns (metrics, snip_sequence_list, labels_list,
+    videoname_list, attention_list, importance_list, output_logits_list) with the reference's structure."""
+    if task != "Prototypes":
+        raise NotImplementedError("only task 'Prototypes' is on the MI355X hot path")
+    model = model_dict["model"]
+    lists = ([], [], [])
+    attention_list, importance_list, labels_list, videoname_list = [], [], [], []
+    running_loss, nitems, is_list = 0.0, 0, False
+    for (videoname, snippets, flows, importances, labels, xlens, flens, xpad, fpad, ipad, domains) in dataloader[phase]:
+        if isinstance(snippets, dict):                                         # TTA versions (:92-100)
+            snippets = [s.to(device) for s in snippets.values()]
+            xpad = [m.to(device) for m in xpad.values()]
+            xlens = [l for l in xlens.values()]
+            flows = [f.to(device) for f in flows.values()]
+            fpad = [m.to(device) for m in fpad.values()]
+            flens = [l for l in flens.values()]
+        else:
+            snippets, xpad, fpad, flows = snippets.to(device), xpad.to(device), fpad.to(device), flows.to(device)
+        with torch.set_grad_enabled(phase == "train"):
+            if importance_loss:
+                output_importances, snip_sequence, snip_attn = model(snippets, flows, xlens, flens, task, xpad, fpad, domains)
+            else:
+                snip_sequence, snip_attn = model(snippets, flows, xlens, flens, task, xpad, fpad, domains)
+            is_list = isinstance(snip_sequence, list)
+            if "inference" in phase:
+                loss = torch.tensor(0)                                         # :121-122
+            elif is_list:
+                loss = torch.mean(torch.stack([calcNCELoss(rank, s, labels, videoname, model_dict["prototypes"], domains).detach()
+                                               for s in snip_sequence]))
+            else:
+                loss = calcNCELoss(rank, snip_sequence, labels, videoname, model_dict["prototypes"], domains)
+                if phase == "train" and importance_loss:
+                    loss = loss + calcImportanceLoss(output_importances, importances, ipad, labels)
+        if phase == "train":
+            optimizer.zero_grad()
+            loss.backward()
+            if sync is not None:
+                sync.reduce_params(model_dict["prototypes"].values())
+                sync.wait()
+            optimizer.step(grad_scale=1.0 / world_size)
+        if is_list:
+            for v in range(3):
+                lists[v].extend(s.detach() for s in snip_sequence[v])
+        else:
+            lists[0].extend(s.detach() for s in snip_sequence)
+        attention_list.append(snip_attn.detach())
+        labels_list.extend(labels)
+        videoname_list.extend(videoname)
+        if importance_loss:
+            xl = xlens[0] if is_list else xlens
+            importance_list.append([imp[:, 1:n + 1, :].squeeze() for imp, n in zip(output_importances.detach(), xl)])
+        bsz = snippets[0].shape[0] if is_list else snippets.shape[0]
+        running_loss += float(loss) * bsz
+        nitems += bsz
+    ave_loss = running_loss / max(len(dataloader[phase].dataset), 1)
+    snip_sequence_list = lists if is_list else lists[0]
+    if phase == "inference" or nitems == 0:
+        acc, auc, prec, rec = 0, 0, 0, 0
+    else:
+        acc, auc, prec, rec = calcNCEMetrics(rank, snip_sequence_list, labels_list, videoname_list, model_dict["prototypes"])
+    metrics = {"loss": ave_loss, "acc": acc, "auc": auc, "precision": prec, "recall": rec}
+    return metrics, snip_sequence_list, labels_list, videoname_list, attention_list, importance_list, []
+
+
+# ------------------------------------------------------------------------------------------ training loop
+def trainModel(rank, world_size, root_path, savepath, dataset_name, data_type, batch_size, nclasses, domain, phases, lr,
+               modalities, freeze_encoder_params, inference, task, balance, balance_groups, single_group, group_info,
+               self_attention, importance_loss, encoder_type, encoder_params, snippetLength, frameSkip, overlap, rep_dim,
+               nepochs, fold, training_fraction, dataloader=None):
+    """train.py:18-121 with the reference's positional signature.  `dataloader` ({phase: DataLoader}) overrides the
+    files under root_path.  Returns the metrics history {name: [per validation epoch]}."""
+    if not torch.cuda.is_available():
+        raise L.SaisHipError("trainModel needs an MI355X: the HIP path has no CPU fallback")
+    import torch.distributed as dist
+    from .parallel import GradSync
+    model, optimizer, device = loadModel(rank, world_size, savepath, data_type, nclasses, domain, rep_dim, encoder_type,
+                                         task, fold, lr=lr, modalities=modalities,
+                                         freeze_encoder_params=freeze_encoder_params, self_attention=self_attention,
+                                         importance_loss=importance_loss, inference=inference)
+    if dataloader is None:
+        dataloader, _ = load_dataloaders(root_path, dataset_name, batch_size, phases, domain, encoder_params, rank,
+                                         world_size, seed=fold)
+    sync = None
+    if world_size > 1 and dist.is_initialized():
+        sync = GradSync(world_size)
+        model["model"]._engine(device)
+        model["model"].grad_ready_hook = sync.temporal_hook(model["model"])
+    best_params_dict, best_prototypes_dict, reps_and_labels_dict = {}, {}, {}
+    attention_dict, importance_dict = [], []
+    metrics_dict = defaultdict(list)
+    min_loss, epoch_count, max_patience, patience_count = float("inf"), 1, 5, 1
+    while epoch_count <= nepochs and patience_count <= max_patience:
+        print("\n **** Epoch %i ****" % epoch_count)
+        for phase in phases:
+            print(phase)
+            if phase == "train" and not inference:
+                model["model"].train()
+            else:
+                model["model"].eval()
+            metrics, snippets, labels, videonames, attention, importance, logits = single_epoch(
+                rank, world_size, dataloader, model, optimizer, device, phase, nclasses, task, importance_loss, sync)
+            printMetrics(phase, metrics)
+            if not inference:
+                if phase == "val":
+                    loss = metrics["loss"]
+                    metrics_dict = trackMetrics(metrics, metrics_dict)
+                    if loss < min_loss:
+                        min_loss, patience_count = loss, 1
+                        best_params_dict = {k: v.detach().cpu().clone() for k, v in model["model"].state_dict().items()}
+                        reps_and_labels_dict = {"reps": _to_cpu(snippets), "labels": [l.cpu() for l in labels],
+                                                "videonames": videonames, "logits": logits}
+                        best_prototypes_dict = copy.deepcopy({k: v.detach().cpu() for k, v in model["prototypes"].items()})
+                    else:
+                        patience_count += 1
+            else:
+                reps_and_labels_dict = {"reps": _to_cpu(snippets), "labels": [l.cpu() for l in labels],
+                                        "videonames": videonames, "logits": logits}
+                attention_dict = [a.cpu() for a in attention]
+                importance_dict = importance
+        epoch_count += 1
+    if rank == 0:                                                          # :98-121
+        os.makedirs(savepath, exist_ok=True)
+        if not inference:
+            if not best_params_dict:                                       # no 'val' phase: keep the final weights
+                best_params_dict = {k: v.detach().cpu().clone() for k, v in model["model"].state_dict().items()}
+                best_prototypes_dict = {k: v.detach().cpu() for k, v in model["prototypes"].items()}
+            # keys carry the `module.` prefix loadModel(inference=True) strips (prepare_model.py:525-527)
+            torch.save({"module." + k: v for k, v in best_params_dict.items()}, os.path.join(savepath, "params"))
+            torch.save(dict(metrics_dict), os.path.join(savepath, "metrics"))
+            save_prototypes_file(best_prototypes_dict, os.path.join(savepath, "prototypes"))
+            torch.save(reps_and_labels_dict, os.path.join(savepath, "reps_and_labels"))
+            print("All Info Saved!")
+        else:
+            torch.save(reps_and_labels_dict, os.path.join(savepath, "reps_and_labels_%s" % phases[0]))
+            torch.save(attention_dict, os.path.join(savepath, "attention_%s" % phases[0]))
+            torch.save(importance_dict, os.path.join(savepath, "importance_%s" % phases[0]))
+    return dict(metrics_dict)
+
+
+def _to_cpu(snippets):
+    if isinstance(snippets, tuple):
+        return tuple([s.cpu() for s in v] for v in snippets)
+    return [s.cpu() for s in snippets]

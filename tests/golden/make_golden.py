@@ -299,10 +299,8 @@ def golden_importance(prepare_model, misc, out):
     print("importance.npz keys", len(g))
 
 
-def golden_collate(out):
-    import prepare_dataset
-    dl = prepare_dataset.loadDataloader.__new__(prepare_dataset.loadDataloader)
-    dl.task = 'Prototypes'
+def collate_batches():
+    """Seeded inputs of the two pad_collate branches (shared with tests/test_train_host.py)."""
     lens = [5, 3, 7, 1]
     gen = torch.Generator().manual_seed(5)
     batch = []
@@ -311,12 +309,42 @@ def golden_collate(out):
         fl = torch.randn(1, n, 384, generator=gen)
         imp = torch.zeros(1, n)
         batch.append((f"v{i}", s, fl, torch.tensor(i % 2), imp, 'dom'))
+    # test-time-augmentation form (val / test / inference items): tuples of 3 versions with different lengths
+    tta_lens = [(15, 12, 9), (10, 8, 6), (15, 12, 9)]
+    tta_flens = [(2, 2, 1), (1, 1, 1), (2, 1, 1)]
+    tta = []
+    for i, (ls, fls) in enumerate(zip(tta_lens, tta_flens)):
+        xs = tuple(torch.randn(1, n, 384, generator=gen) for n in ls)
+        fs = tuple(torch.randn(1, n, 384, generator=gen) for n in fls)
+        tta.append((f"w{i}", xs, fs, torch.tensor(0), torch.zeros(1, ls[0]), 'dom'))
+    return lens, batch, tta
+
+
+def golden_collate(out):
+    import prepare_dataset
+    dl = prepare_dataset.loadDataloader.__new__(prepare_dataset.loadDataloader)
+    dl.task = 'Prototypes'
+    lens, batch, tta = collate_batches()
     outp = dl.pad_collate(batch)
     names, sp, fp, ip, lab, sl, fl_, sm, fm, im, dom = outp
     g = {"lens": np.array(lens), "snippets_padded": sp.numpy(), "snippets_mask": sm.numpy(),
-         "flows_mask": fm.numpy(), "labels": lab.numpy(), "snippets_lens": np.array(sl)}
+         "flows_mask": fm.numpy(), "labels": lab.numpy(), "snippets_lens": np.array(sl),
+         "flows_padded": fp.numpy(), "flows_lens": np.array(fl_), "importance_padded": ip.numpy(),
+         "importance_mask": im.numpy()}
+    names, sp, fp, ip, lab, sl, fl_, sm, fm, im, dom = dl.pad_collate(tta)
+    assert isinstance(sp, dict) and list(sp.keys()) == [0, 1, 2]
+    for v in range(3):
+        g[f"tta/snippets_padded_{v}"] = sp[v].numpy()
+        g[f"tta/snippets_mask_{v}"] = sm[v].numpy()
+        g[f"tta/snippets_lens_{v}"] = np.array(sl[v])
+        g[f"tta/flows_padded_{v}"] = fp[v].numpy()
+        g[f"tta/flows_mask_{v}"] = fm[v].numpy()
+        g[f"tta/flows_lens_{v}"] = np.array(fl_[v])
+    g["tta/labels"] = lab.numpy()
+    g["tta/importance_padded"] = ip.numpy()
+    g["tta/importance_mask"] = im.numpy()
     np.savez_compressed(os.path.join(out, "collate.npz"), **g)
-    print("collate.npz", sp.shape, sm.shape)
+    print("collate.npz", sp[0].shape, sm[0].shape, len(g), "arrays")
 
 
 def golden_e2e(vits, prepare_model, misc, out):
