@@ -8,7 +8,8 @@
 //   LN_BWD  (dX of fc1 / qkv followed by autograd of norm2 / norm1):
 //           dy = A.W^T ; dx = dres + rstd (dy g - mean(dy g) - xhat mean(dy g xhat)) ; dgamma += sum dy xhat ;
 //           dbeta += sum dy.  Replaces gemm_nt<bias_bf16> + ln_bwd_kernel (the bf16 dy round trip disappears).
-//   BIAS_BF16 / RESID_F32: the two plain N = 384 GEMMs of a block (dX of proj; the last block's fc2).
+//   BIAS_BF16 / RESID_F32 / MUL_BF16 / GELU_GRAD_BF16: the other ViT GEMMs (N = 384 g: qkv, fc1 + GELU, dX of fc2 and
+//           proj, the last block's fc2) as column groups of 384 with the same tile and the same streaming epilogue.
 //
 // Tile.  M = 50 432 rows over 256 CUs x 2 workgroups is 98.5 rows per workgroup: the host picks rows_per_tile =
 // ceil(M / 512) (99 -> 510 equal tiles, one round, two workgroups on every CU) and the kernel computes 7 MFMA row
@@ -39,15 +40,15 @@ constexpr int RBN = 384, RBK = 64, RMT = 7;         // 7 row tiles of 16 = 112 r
 constexpr int RTILE = 128 * 64 * 2;                 // 16 KiB: 128 rows x 64 k bf16
 constexpr int ROW_LDS = 5 * RTILE;                  // A x 2, W x 3
 
-enum { ROW_BIAS_BF16 = 0, ROW_RESID_F32, ROW_LN_FWD, ROW_LN_BWD };
+enum { ROW_BIAS_BF16 = 0, ROW_RESID_F32, ROW_LN_FWD, ROW_LN_BWD, ROW_MUL_BF16, ROW_GELU_GRAD_BF16 };
 
 struct RowParams {
     const bf16* A; const bf16* W;
-    int lda, ldw, M, K, rows_per_tile;
-    const float* bias;              // [384] or null
-    void* out; int ldo;             // bf16 out (BIAS) | f32 x_out (RESID, LN_FWD) | f32 dx (LN_BWD)
-    void* out2; int ldo2;           // bf16: xn (LN_FWD) | dx (LN_BWD)
-    const void* aux; int ldaux;     // f32 residual (RESID, LN_FWD) | f32 LN input x (LN_BWD)
+    int lda, ldw, M, N, K, rows_per_tile;
+    const float* bias;              // [N] or null
+    void* out; int ldo;             // bf16 out (BIAS, MUL, GELU) | f32 x_out (RESID, LN_FWD) | f32 dx (LN_BWD)
+    void* out2; int ldo2;           // bf16: gelu' (GELU_GRAD) | xn (LN_FWD) | dx (LN_BWD)
+    const void* aux; int ldaux;     // bf16 multiplier (MUL) | f32 residual (RESID, LN_FWD) | f32 LN input x (LN_BWD)
     const float* gamma; const float* beta; float eps;
     float* mean; float* rstd;       // LN_FWD: out (nullable) | LN_BWD: in
     const float* dres; int lddres;  // LN_BWD: residual-stream gradient added to dx (may alias out)
@@ -64,7 +65,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int m0 = xcd_remap(blockIdx.x, gridDim.x) * p.rows_per_tile;
+    // tiles are numbered column-group fastest, so the N/384 workgroups that share an A row panel run side by side on
+    // one XCD (xcd_remap hands every XCD a contiguous run of tiles) and the panel is fetched from HBM once
+    const int ngrp = p.N / RBN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (tile % ngrp) * RBN;
+    const int m0 = (tile / ngrp) * p.rows_per_tile;
     const int mend = min(p.M, m0 + p.rows_per_tile);                 // rows [m0, mend) are this workgroup's
 
     // staging: wave w issues pieces 4w..4w+3 (8 LDS rows each) of every 128-row slot.  A: tile rows; W chunk c: LDS rows
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
         int m = m0 + r;
         m = m < p.M ? m : p.M - 1;                                   // clamp: rows outside the tile are never stored
         aoff[j] = ((unsigned)m * (unsigned)p.lda + schunk * 8) * 2u;
-        woff[j] = ((unsigned)(96 * (r >> 5) + perm32(r & 31)) * (unsigned)p.ldw + schunk * 8) * 2u;
+        woff[j] = ((unsigned)(n0 + 96 * (r >> 5) + perm32(r & 31)) * (unsigned)p.ldw + schunk * 8) * 2u;
     }
     char* const sA = smem;
     char* const sW = smem + 2 * RTILE;
@@ -151,33 +157,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
     // ------------------------------------------------------------------------------------------- epilogues
     // lane: rows m0 + 16 mt + li (mt = 0..6); per chunk c the 8 columns 96 wid + 32 c + 8 g + (4 t + e)
     const int cbase = 96 * wid + 8 * g;                              // + 32 c
-    if constexpr (EPI == ROW_BIAS_BF16 || EPI == ROW_RESID_F32) {
-#pragma unroll
-        for (int mt = 0; mt < RMT; ++mt) {
-            const int m = m0 + 16 * mt + li;
-            if (m >= mend) continue;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int n = cbase + 32 * c;
-                f32x4 y0 = acc[mt][2 * c], y1 = acc[mt][2 * c + 1];
-                if (p.bias) { y0 += *(const f32x4*)(p.bias + n); y1 += *(const f32x4*)(p.bias + n + 4); }
-                if constexpr (EPI == ROW_BIAS_BF16) {
-                    bf16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { o[e] = (bf16)y0[e]; o[4 + e] = (bf16)y1[e]; }
-                    *(bf16x8*)((bf16*)p.out + (size_t)m * p.ldo + n) = o;
-                } else {
-                    const float* r = (const float*)p.aux + (size_t)m * p.ldaux + n;
-                    float* o = (float*)p.out + (size_t)m * p.ldo + n;
-                    y0 += *(const f32x4*)r;
-                    y1 += *(const f32x4*)(r + 4);
-                    *(f32x4*)o = y0;
-                    *(f32x4*)(o + 4) = y1;
-                }
-            }
-        }
-    } else {
-        // ---- LayerNorm epilogues: 32-row fp32 slabs through LDS, then a row-streaming phase ------------------------
+    {
+        // ---- every epilogue: 32-row fp32 slabs through LDS, then a row-streaming phase ----------------------------
         constexpr int SLD = 388;                                     // floats per slab row (1552 B: conflict-free dumps)
         float* const slab = (float*)smem;                            // [32][SLD]; the operand slots are free now
         float* const scr = slab + 32 * SLD;                          // LN_BWD: [8][2][384] column sums + gamma
@@ -193,6 +174,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
         auto st12 = [&](float* q, const float (&v)[12]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) *(f32x4*)(q + 128 * i + 4 * l32) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        };
+        auto ld12_bf16 = [&](const bf16* q, float (&v)[12]) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const bf16x4 t = *(const bf16x4*)(q + 128 * i + 4 * l32);
+                v[4 * i] = (float)t[0]; v[4 * i + 1] = (float)t[1]; v[4 * i + 2] = (float)t[2]; v[4 * i + 3] = (float)t[3];
+            }
         };
         auto st12_bf16 = [&](bf16* q, const float (&v)[12]) {
 #pragma unroll
@@ -225,7 +213,62 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
         auto trow = [&](int it) { return 32 * (it >> 2) + hw + 8 * (it & 3); };
         constexpr int NIT = 14;                                      // 3 x 4 + 2
 
-        if constexpr (EPI == ROW_LN_FWD) {
+        if constexpr (EPI == ROW_BIAS_BF16 || EPI == ROW_RESID_F32 || EPI == ROW_MUL_BF16 || EPI == ROW_GELU_GRAD_BF16) {
+            // out[m, n0 .. n0+383] = f(acc + bias [, aux row]); the aux row of the NEXT row is in flight during this one
+            constexpr bool HAS_AUX = EPI == ROW_RESID_F32 || EPI == ROW_MUL_BF16;
+            float bs[12], anext[12];
+            auto ldaux = [&](int m, float (&v)[12]) {
+                if constexpr (EPI == ROW_RESID_F32) ld12((const float*)p.aux + (size_t)m * p.ldaux + n0, v);
+                else if constexpr (EPI == ROW_MUL_BF16) ld12_bf16((const bf16*)p.aux + (size_t)m * p.ldaux + n0, v);
+            };
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                dump(s);
+                if (s == 0) {
+                    if constexpr (HAS_AUX) ldaux(clampm(m0 + trow(0)), anext);
+                    if (p.bias) ld12(p.bias + n0, bs);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) bs[i] = 0.f;
+                    }
+                }
+                __syncthreads();
+                const int nq = s < 3 ? 4 : 2;
+#pragma nounroll
+                for (int q = 0; q < nq; ++q) {
+                    const int it = 4 * s + q, m = m0 + trow(it);
+                    float v[12], acur[12];
+                    ld12(slab + (hw + 8 * q) * SLD, v);
+                    if constexpr (HAS_AUX) {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) acur[i] = anext[i];
+                        if (it + 1 < NIT) ldaux(clampm(m0 + trow(it + 1)), anext);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) v[i] += bs[i];
+                    if (m < mend) {
+                        if constexpr (EPI == ROW_BIAS_BF16) {
+                            st12_bf16((bf16*)p.out + (size_t)m * p.ldo + n0, v);
+                        } else if constexpr (EPI == ROW_RESID_F32) {
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) v[i] += acur[i];
+                            st12((float*)p.out + (size_t)m * p.ldo + n0, v);
+                        } else if constexpr (EPI == ROW_MUL_BF16) {
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) v[i] *= acur[i];
+                            st12_bf16((bf16*)p.out + (size_t)m * p.ldo + n0, v);
+                        } else {
+                            float d[12];
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) gelu_and_grad(v[i], v[i], d[i]);
+                            st12_bf16((bf16*)p.out2 + (size_t)m * p.ldo2 + n0, d);
+                            st12_bf16((bf16*)p.out + (size_t)m * p.ldo + n0, v);
+                        }
+                    }
+                }
+                if (s < 3) __syncthreads();
+            }
+        } else if constexpr (EPI == ROW_LN_FWD) {
             float gm[12], bt[12], bs[12], rnext[12];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -369,24 +412,26 @@ int launch_row(RowParams& p, void* stream) {
         set = true;
     }
     // 32-bit byte offsets inside the kernel
-    if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)RBN * p.ldw * 2.0 >= 4294967296.0) return SAIS_ERR_ARG;
+    if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAIS_ERR_ARG;
     p.rows_per_tile = rows_per_tile(p.M);
-    const int grid = (p.M + p.rows_per_tile - 1) / p.rows_per_tile;
+    const int grid = (p.N / RBN) * ((p.M + p.rows_per_tile - 1) / p.rows_per_tile);
     hipLaunchKernelGGL(gemm_nt_row_kernel<EPI>, dim3(grid), dim3(256), ROW_LDS, (hipStream_t)stream, p);
     return sais_check_launch();
 }
 
 }  // namespace
 
-// plain N = 384 epilogues: called by sais_gemm_nt (gemm.hip) for the large-M ViT GEMMs
+// plain epilogues: called by sais_gemm_nt (gemm.hip) for the large-M ViT GEMMs whose N is a multiple of 384
 extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream) {
-    if (g->N != RBN) return SAIS_ERR_ARG;
+    if (g->N % RBN) return SAIS_ERR_ARG;
     RowParams p{};
     p.A = (const bf16*)g->A; p.W = (const bf16*)g->B; p.lda = g->lda; p.ldw = g->ldb;
-    p.M = g->M; p.K = g->K; p.bias = g->bias;
-    p.out = g->out; p.ldo = g->ldo; p.aux = g->aux; p.ldaux = g->ldaux;
+    p.M = g->M; p.N = g->N; p.K = g->K; p.bias = g->bias;
+    p.out = g->out; p.ldo = g->ldo; p.out2 = g->out2; p.ldo2 = g->ldo2; p.aux = g->aux; p.ldaux = g->ldaux;
     switch (g->epilogue) {
         case SAIS_EPI_BIAS_BF16: return launch_row<ROW_BIAS_BF16>(p, stream);
+        case SAIS_EPI_MUL_BF16: return launch_row<ROW_MUL_BF16>(p, stream);
+        case SAIS_EPI_BIAS_GELU_GRAD_BF16: return launch_row<ROW_GELU_GRAD_BF16>(p, stream);
         case SAIS_EPI_BIAS_RESID_F32: return g->out2 ? SAIS_ERR_ARG : launch_row<ROW_RESID_F32>(p, stream);
         default: return SAIS_ERR_ARG;
     }
@@ -403,7 +448,7 @@ extern "C" int sais_gemm_ln_fwd(const SaisGemmLn* g, void* stream) {
     if (check_ln(g) != SAIS_OK || !g->out32 || !g->out16 || !g->beta) return SAIS_ERR_ARG;
     RowParams p{};
     p.A = (const bf16*)g->A; p.W = (const bf16*)g->W; p.lda = g->lda; p.ldw = g->ldw;
-    p.M = g->M; p.K = g->K; p.bias = g->bias;
+    p.M = g->M; p.N = RBN; p.K = g->K; p.bias = g->bias;
     p.out = g->out32; p.ldo = g->ldo32; p.out2 = g->out16; p.ldo2 = g->ldo16; p.aux = g->resid; p.ldaux = g->ldr;
     p.gamma = g->gamma; p.beta = g->beta; p.eps = g->eps; p.mean = g->mean; p.rstd = g->rstd;
     return launch_row<ROW_LN_FWD>(p, stream);
@@ -415,7 +460,7 @@ extern "C" int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream) {
     if ((g->dgamma == nullptr) != (g->dbeta == nullptr) || g->lddres % 4) return SAIS_ERR_ARG;
     RowParams p{};
     p.A = (const bf16*)g->A; p.W = (const bf16*)g->W; p.lda = g->lda; p.ldw = g->ldw;
-    p.M = g->M; p.K = g->K;
+    p.M = g->M; p.N = RBN; p.K = g->K;
     p.out = g->out32; p.ldo = g->ldo32; p.out2 = g->out16; p.ldo2 = g->ldo16; p.aux = g->resid; p.ldaux = g->ldr;
     p.gamma = g->gamma; p.mean = g->mean; p.rstd = g->rstd;
     p.dres = g->dres; p.lddres = g->lddres; p.dgamma = g->dgamma; p.dbeta = g->dbeta;

@@ -62,7 +62,7 @@ def test_gemm_tn_exact_integers(ops):
 # second round); the last-but-one shape is 304 tiles x 9 column tiles = more tiles than persistent workgroups
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (50432 // 8, 1152, 384), (264, 2048, 384), (128, 384, 1536),
                                    (8192 + 3 * 128 + 57, 384, 384), (50432 - 128 * 90, 1152, 384),
-                                   (8192 + 128 + 5, 512, 384)])
+                                   (8192 + 128 + 5, 512, 384), (8192 + 99 * 3 + 7, 1536, 384)])
 def test_gemm_nt_epilogues(ops, M, N, K):
     from sais_amd import _lib as L
     a = rnd(M, K, seed=3, dtype=torch.bfloat16)
