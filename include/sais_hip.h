@@ -209,15 +209,16 @@ int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B
 
 /* ---------------------------------------------------------------- head + SupCon / prototype loss
  * fullModel.forward Prototypes branch, prepare_model.py:215,220,381-416:
- *   rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = linear(relu(rep))   (256 outputs).
- * The two streams may have different padded lengths (clip strides): at inference the flow stream
+ *   rep = mean_s relu(z_rgb[b,s,0]) (+ mean_s relu(z_flow[b,s,0]));  emb = linear(relu(rep))   (256 outputs);
+ *   s runs over the `nsnippets` snippets of clip b (:381-382; sequences b*nsnippets + s of the encoder output).
+ * The two streams may have different padded lengths (sequence strides): at inference the flow stream
  * has 1-2 frames per 15-frame window (prepare_dataset.py:2660-2666).                              */
 int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, long clip_stride_flow, int B,
-                  const float* W /*[256,384]*/, const float* bias, float* rep /*[B,384] saved*/, float* emb /*[B,256]*/,
-                  void* stream);
+                  int nsnippets, const float* W /*[256,384]*/, const float* bias, float* rep /*[B,384] saved*/,
+                  float* emb /*[B,256]*/, void* stream);
 int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb, const float* z_flow,
-                  long clip_stride, long clip_stride_flow, int B, float* dW, float* dbias, float* dz_rgb,
-                  float* dz_flow, void* stream);
+                  long clip_stride, long clip_stride_flow, int B, int nsnippets, float* dW, float* dbias,
+                  float* dz_rgb, float* dz_flow, void* stream);
 /* Optional importance head (-il): importance_function = Linear(384 -> 1) on the ReLU'd encoder output sequence,
  * prepare_model.py:55-56,419-421.  out[m] = w . relu(z[m,:]) + b.  bwd ACCUMULATES into dz / dw / db.        */
 int sais_importance_fwd(const float* z /*[M,384] pre-ReLU*/, const float* w, const float* b, int M, float* out, void* stream);

@@ -80,8 +80,8 @@ SIGNATURES = {
                                   c_void_p, c_void_p],
     "sais_temporal_attn_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "sais_temporal_attn_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "sais_head_fwd": [c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
-    "sais_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_void_p,
+    "sais_head_fwd": [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sais_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p,
                       c_void_p, c_void_p, c_void_p],
     "sais_importance_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "sais_importance_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

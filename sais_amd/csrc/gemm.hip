@@ -979,16 +979,9 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
     // four-wave A-ring) were measured slower inside the step and are gone from the library.
     const bool big = g->M >= 8192;
-#ifndef SAIS_ROW_N384_ONLY
-    // the ViT GEMMs of a training step (N = 384 / 1152 / 1536): balanced row tiles + streaming epilogue of gemm_row.hip
-    if (big && g->N % 384 == 0 && (g->epilogue == SAIS_EPI_BIAS_BF16 || g->epilogue == SAIS_EPI_MUL_BF16 ||
-                                   g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 ||
-                                   (g->epilogue == SAIS_EPI_BIAS_RESID_F32 && !g->out2)))
-        return sais_gemm_nt_row_(g, stream);
-#else
+    // the plain N = 384 GEMMs of a training step (dX of proj, the last block's fc2): balanced row tiles of gemm_row.hip
     if (big && g->N == 384 && (g->epilogue == SAIS_EPI_BIAS_BF16 || (g->epilogue == SAIS_EPI_BIAS_RESID_F32 && !g->out2)))
         return sais_gemm_nt_row_(g, stream);
-#endif
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)

@@ -8,8 +8,9 @@
 //   LN_BWD  (dX of fc1 / qkv followed by autograd of norm2 / norm1):
 //           dy = A.W^T ; dx = dres + rstd (dy g - mean(dy g) - xhat mean(dy g xhat)) ; dgamma += sum dy xhat ;
 //           dbeta += sum dy.  Replaces gemm_nt<bias_bf16> + ln_bwd_kernel (the bf16 dy round trip disappears).
-//   BIAS_BF16 / RESID_F32 / MUL_BF16 / GELU_GRAD_BF16: the other ViT GEMMs (N = 384 g: qkv, fc1 + GELU, dX of fc2 and
-//           proj, the last block's fc2) as column groups of 384 with the same tile and the same streaming epilogue.
+//   BIAS_BF16 / RESID_F32: the two plain N = 384 GEMMs of a block (dX of proj; the last block's fc2), same tile and
+//           streaming epilogue.  (N = 384 g works too — column groups — but for N = 1152 / 1536 the 128x128 persistent
+//           kernel of gemm.hip measured faster inside the step: 116 vs 134 us for dX fc2, 69 vs 72 us for qkv.)
 //
 // Tile.  M = 50 432 rows over 256 CUs x 2 workgroups is 98.5 rows per workgroup: the host picks rows_per_tile =
 // ceil(M / 512) (99 -> 510 equal tiles, one round, two workgroups on every CU) and the kernel computes 7 MFMA row
@@ -40,15 +41,15 @@ constexpr int RBN = 384, RBK = 64, RMT = 7;         // 7 row tiles of 16 = 112 r
 constexpr int RTILE = 128 * 64 * 2;                 // 16 KiB: 128 rows x 64 k bf16
 constexpr int ROW_LDS = 5 * RTILE;                  // A x 2, W x 3
 
-enum { ROW_BIAS_BF16 = 0, ROW_RESID_F32, ROW_LN_FWD, ROW_LN_BWD, ROW_MUL_BF16, ROW_GELU_GRAD_BF16 };
+enum { ROW_BIAS_BF16 = 0, ROW_RESID_F32, ROW_LN_FWD, ROW_LN_BWD };
 
 struct RowParams {
     const bf16* A; const bf16* W;
     int lda, ldw, M, N, K, rows_per_tile;
     const float* bias;              // [N] or null
-    void* out; int ldo;             // bf16 out (BIAS, MUL, GELU) | f32 x_out (RESID, LN_FWD) | f32 dx (LN_BWD)
-    void* out2; int ldo2;           // bf16: gelu' (GELU_GRAD) | xn (LN_FWD) | dx (LN_BWD)
-    const void* aux; int ldaux;     // bf16 multiplier (MUL) | f32 residual (RESID, LN_FWD) | f32 LN input x (LN_BWD)
+    void* out; int ldo;             // bf16 out (BIAS) | f32 x_out (RESID, LN_FWD) | f32 dx (LN_BWD)
+    void* out2; int ldo2;           // bf16: xn (LN_FWD) | dx (LN_BWD)
+    const void* aux; int ldaux;     // f32 residual (RESID, LN_FWD) | f32 LN input x (LN_BWD)
     const float* gamma; const float* beta; float eps;
     float* mean; float* rstd;       // LN_FWD: out (nullable) | LN_BWD: in
     const float* dres; int lddres;  // LN_BWD: residual-stream gradient added to dx (may alias out)
@@ -175,13 +176,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) *(f32x4*)(q + 128 * i + 4 * l32) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
         };
-        auto ld12_bf16 = [&](const bf16* q, float (&v)[12]) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const bf16x4 t = *(const bf16x4*)(q + 128 * i + 4 * l32);
-                v[4 * i] = (float)t[0]; v[4 * i + 1] = (float)t[1]; v[4 * i + 2] = (float)t[2]; v[4 * i + 3] = (float)t[3];
-            }
-        };
         auto st12_bf16 = [&](bf16* q, const float (&v)[12]) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -213,13 +207,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
         auto trow = [&](int it) { return 32 * (it >> 2) + hw + 8 * (it & 3); };
         constexpr int NIT = 14;                                      // 3 x 4 + 2
 
-        if constexpr (EPI == ROW_BIAS_BF16 || EPI == ROW_RESID_F32 || EPI == ROW_MUL_BF16 || EPI == ROW_GELU_GRAD_BF16) {
-            // out[m, n0 .. n0+383] = f(acc + bias [, aux row]); the aux row of the NEXT row is in flight during this one
-            constexpr bool HAS_AUX = EPI == ROW_RESID_F32 || EPI == ROW_MUL_BF16;
+        if constexpr (EPI == ROW_BIAS_BF16 || EPI == ROW_RESID_F32) {
+            // out[m, n0 .. n0+383] = acc + bias [+ residual row]; the residual of the NEXT row is in flight during this one
+            constexpr bool HAS_AUX = EPI == ROW_RESID_F32;
             float bs[12], anext[12];
             auto ldaux = [&](int m, float (&v)[12]) {
                 if constexpr (EPI == ROW_RESID_F32) ld12((const float*)p.aux + (size_t)m * p.ldaux + n0, v);
-                else if constexpr (EPI == ROW_MUL_BF16) ld12_bf16((const bf16*)p.aux + (size_t)m * p.ldaux + n0, v);
             };
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -249,20 +242,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                     if (m < mend) {
                         if constexpr (EPI == ROW_BIAS_BF16) {
                             st12_bf16((bf16*)p.out + (size_t)m * p.ldo + n0, v);
-                        } else if constexpr (EPI == ROW_RESID_F32) {
+                        } else {
 #pragma unroll
                             for (int i = 0; i < 12; ++i) v[i] += acur[i];
                             st12((float*)p.out + (size_t)m * p.ldo + n0, v);
-                        } else if constexpr (EPI == ROW_MUL_BF16) {
-#pragma unroll
-                            for (int i = 0; i < 12; ++i) v[i] *= acur[i];
-                            st12_bf16((bf16*)p.out + (size_t)m * p.ldo + n0, v);
-                        } else {
-                            float d[12];
-#pragma unroll
-                            for (int i = 0; i < 12; ++i) gelu_and_grad(v[i], v[i], d[i]);
-                            st12_bf16((bf16*)p.out2 + (size_t)m * p.ldo2 + n0, d);
-                            st12_bf16((bf16*)p.out + (size_t)m * p.ldo + n0, v);
                         }
                     }
                 }
@@ -430,8 +413,6 @@ extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream) {
     p.out = g->out; p.ldo = g->ldo; p.out2 = g->out2; p.ldo2 = g->ldo2; p.aux = g->aux; p.ldaux = g->ldaux;
     switch (g->epilogue) {
         case SAIS_EPI_BIAS_BF16: return launch_row<ROW_BIAS_BF16>(p, stream);
-        case SAIS_EPI_MUL_BF16: return launch_row<ROW_MUL_BF16>(p, stream);
-        case SAIS_EPI_BIAS_GELU_GRAD_BF16: return launch_row<ROW_GELU_GRAD_BF16>(p, stream);
         case SAIS_EPI_BIAS_RESID_F32: return g->out2 ? SAIS_ERR_ARG : launch_row<ROW_RESID_F32>(p, stream);
         default: return SAIS_ERR_ARG;
     }

@@ -183,14 +183,19 @@ __global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const
 // ---------------------------------------------------------------- head
 // rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = W relu(rep) + bias
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const float* zf, long clip_stride,
-                                                       long clip_stride_f, const float* W, const float* bias,
+                                                       long clip_stride_f, int ns, const float* W, const float* bias,
                                                        float* rep, float* emb) {
     __shared__ float sr[D];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const float inv = 1.0f / ns;
     for (int c = tid; c < D; c += 256) {
-        float v = 0.f;
-        if (zr) v += fmaxf(zr[(size_t)b * clip_stride + c], 0.f);
-        if (zf) v += fmaxf(zf[(size_t)b * clip_stride_f + c], 0.f);
+        // mean over the ns snippets of a clip of relu(CLS row) (prepare_model.py:215,220,381-382), per stream
+        float vr = 0.f, vf = 0.f;
+        for (int s = 0; s < ns; ++s) {
+            if (zr) vr += fmaxf(zr[(size_t)(b * ns + s) * clip_stride + c], 0.f);
+            if (zf) vf += fmaxf(zf[(size_t)(b * ns + s) * clip_stride_f + c], 0.f);
+        }
+        const float v = vr * inv + vf * inv;
         rep[(size_t)b * D + c] = v;
         sr[c] = fmaxf(v, 0.f);
     }
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const fl
 // demb [B,256] -> dW += demb^T relu(rep), db += sum_b demb, dz_rgb[b,0,:] / dz_flow[b,0,:]
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const float* W, const float* rep,
                                                        const float* zr, const float* zf, long clip_stride,
-                                                       long clip_stride_f, int B, float* dW, float* dbias, float* dzr,
-                                                       float* dzf) {
+                                                       long clip_stride_f, int B, int ns, float* dW, float* dbias,
+                                                       float* dzr, float* dzf) {
     __shared__ float sd[EMB];
     const int b = blockIdx.x, tid = threadIdx.x;
     sd[tid] = demb[(size_t)b * EMB + tid];
@@ -222,9 +227,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const 
             a += W[(size_t)o * D + c] * sd[o];
             if (r2 != 0.f) atomicAdd(dW + (size_t)o * D + c, sd[o] * r2);
         }
-        float drep = r > 0.f ? a : 0.f;
-        if (zr) dzr[(size_t)b * clip_stride + c] = zr[(size_t)b * clip_stride + c] > 0.f ? drep : 0.f;
-        if (zf) dzf[(size_t)b * clip_stride_f + c] = zf[(size_t)b * clip_stride_f + c] > 0.f ? drep : 0.f;
+        const float drep = (r > 0.f ? a : 0.f) / ns;
+        for (int s = 0; s < ns; ++s) {
+            const size_t ir = (size_t)(b * ns + s) * clip_stride + c, jf = (size_t)(b * ns + s) * clip_stride_f + c;
+            if (zr) dzr[ir] = zr[ir] > 0.f ? drep : 0.f;
+            if (zf) dzf[jf] = zf[jf] > 0.f ? drep : 0.f;
+        }
     }
 }
 
@@ -429,22 +437,22 @@ extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key
 }
 
 extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, long clip_stride_flow, int B,
-                             const float* W, const float* bias, float* rep, float* emb, void* stream) {
+                             int nsnippets, const float* W, const float* bias, float* rep, float* emb, void* stream) {
     SAIS_ENTER();
-    if ((!z_rgb && !z_flow) || !W || !bias || !rep || !emb || B <= 0) return SAIS_ERR_ARG;
+    if ((!z_rgb && !z_flow) || !W || !bias || !rep || !emb || B <= 0 || nsnippets <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride,
-                       clip_stride_flow, W, bias, rep, emb);
+                       clip_stride_flow, nsnippets, W, bias, rep, emb);
     return sais_check_launch();
 }
 
 extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb,
-                             const float* z_flow, long clip_stride, long clip_stride_flow, int B, float* dW,
-                             float* dbias, float* dz_rgb, float* dz_flow, void* stream) {
+                             const float* z_flow, long clip_stride, long clip_stride_flow, int B, int nsnippets,
+                             float* dW, float* dbias, float* dz_rgb, float* dz_flow, void* stream) {
     SAIS_ENTER();
-    if (!demb || !W || !rep || !dW || !dbias || B <= 0) return SAIS_ERR_ARG;
+    if (!demb || !W || !rep || !dW || !dbias || B <= 0 || nsnippets <= 0) return SAIS_ERR_ARG;
     if ((z_rgb && !dz_rgb) || (z_flow && !dz_flow)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, demb, W, rep, z_rgb, z_flow,
-                       clip_stride, clip_stride_flow, B, dW, dbias, dz_rgb, dz_flow);
+                       clip_stride, clip_stride_flow, B, nsnippets, dW, dbias, dz_rgb, dz_flow);
     return sais_check_launch();
 }
 

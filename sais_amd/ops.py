@@ -277,15 +277,16 @@ def temporal_attn_bwd(qkv, key_pad_u8, B, S, dctx, dqkv):
     L.call("sais_temporal_attn_bwd", _p(qkv), _p(key_pad_u8), B, S, _p(dctx), _p(dqkv), _stream())
 
 
-def head_fwd(z_rgb, z_flow, clip_stride, B, W, bias, rep, emb, clip_stride_flow=None):
+def head_fwd(z_rgb, z_flow, clip_stride, B, W, bias, rep, emb, clip_stride_flow=None, nsnippets=1):
     csf = clip_stride if clip_stride_flow is None else clip_stride_flow
-    L.call("sais_head_fwd", _p(z_rgb), _p(z_flow), clip_stride, csf, B, _p(W), _p(bias), _p(rep), _p(emb), _stream())
+    L.call("sais_head_fwd", _p(z_rgb), _p(z_flow), clip_stride, csf, B, nsnippets, _p(W), _p(bias), _p(rep), _p(emb),
+           _stream())
 
 
-def head_bwd(demb, W, rep, z_rgb, z_flow, clip_stride, B, dW, dbias, dz_rgb, dz_flow, clip_stride_flow=None):
+def head_bwd(demb, W, rep, z_rgb, z_flow, clip_stride, B, dW, dbias, dz_rgb, dz_flow, clip_stride_flow=None, nsnippets=1):
     csf = clip_stride if clip_stride_flow is None else clip_stride_flow
-    L.call("sais_head_bwd", _p(demb), _p(W), _p(rep), _p(z_rgb), _p(z_flow), clip_stride, csf, B, _p(dW), _p(dbias),
-           _p(dz_rgb), _p(dz_flow), _stream())
+    L.call("sais_head_bwd", _p(demb), _p(W), _p(rep), _p(z_rgb), _p(z_flow), clip_stride, csf, B, nsnippets, _p(dW),
+           _p(dbias), _p(dz_rgb), _p(dz_flow), _stream())
 
 
 def importance_fwd(z, w, b, M, out):

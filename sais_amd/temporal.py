@@ -16,7 +16,9 @@ The MFMA GEMMs here are the fp32-operand "bf16x3" variant (sais_gemm_nt_f32).
 
 Deliberate differences: inputs are never mutated (the reference does `x += pos` in place,
 :192, and `rgb += flow`, :412); dropout (p=0.1, train() only, RNG-dependent) is the identity;
-nsnippets must be 1; MIL / ClassificationHead / R3D / raw branches are out of scope and raise.
+MIL / ClassificationHead / R3D / raw branches are out of scope and raise.  Inputs [B, nsnippets, T, 384]: every
+(clip, snippet) pair is one sequence of the encoder, the head averages the ReLU'd CLS rows over the snippets of a clip
+(:381-382) and the returned attention map is [B*nsnippets, T+1, T+1], as in the reference.
 """
 import torch
 import torch.nn as nn
@@ -183,16 +185,16 @@ class fullModel(nn.Module):
             raise ValueError(f"{name} is required for this modality")
         if not t.is_cuda:
             raise L.SaisHipError("fullModel.forward needs device tensors: the HIP path has no CPU fallback")
-        if t.dim() != 4 or t.shape[1] != 1 or t.shape[3] != D:
-            raise NotImplementedError(f"{name}: expected [B,1,T,384] (nsnippets == 1), got {tuple(t.shape)}")
+        if t.dim() != 4 or t.shape[3] != D:
+            raise ValueError(f"{name}: expected [B,nsnippets,T,384], got {tuple(t.shape)}")
         return t.float()
 
     @staticmethod
     def _mask(pad, t, dev):
-        B, _, T, _ = t.shape
+        B, ns, T, _ = t.shape
         if pad is None:
-            return torch.zeros(B, T + 1, dtype=torch.uint8, device=dev)
-        pad = pad.reshape(B, T + 1)                                             # :209
+            return torch.zeros(B * ns, T + 1, dtype=torch.uint8, device=dev)
+        pad = pad.reshape(B * ns, T + 1)                                        # :209
         return pad.to(device=dev, dtype=torch.uint8).contiguous()
 
     # ------------------------------------------------------------------ kernels
@@ -202,6 +204,7 @@ class fullModel(nn.Module):
     def _stream_fwd(self, x, pad, save, want_attn):
         fl = self.flat
         dev = x.device
+        x = x.reshape(x.shape[0] * x.shape[1], 1, x.shape[2], D)       # (clip, snippet) pairs are independent sequences
         B, _, T, _ = x.shape
         S, M = T + 1, B * (T + 1)
         if T > NPOS:
@@ -249,21 +252,22 @@ class fullModel(nn.Module):
             if x is None:
                 attn = fattn
         ref = x if x is not None else f
-        B = ref.shape[0]
+        B, ns = ref.shape[0], ref.shape[1]
         # the two streams may have different lengths (inference: 15 RGB frames vs 1-2 flow frames per window)
         Sx = x.shape[2] + 1 if x is not None else f.shape[2] + 1
         Sf = f.shape[2] + 1 if f is not None else Sx
-        if x is not None and f is not None and x.shape[0] != f.shape[0]:
-            raise ValueError("RGB and flow streams must have the same batch size")
+        if x is not None and f is not None and tuple(x.shape[:2]) != tuple(f.shape[:2]):
+            raise ValueError("RGB and flow streams must have the same batch size and number of snippets")
         rep = torch.empty(B, D, dtype=torch.float32, device=ref.device)
         emb = torch.empty(B, EMB, dtype=torch.float32, device=ref.device)
         ops.head_fwd(zr, zf, (Sx if zr is not None else Sf) * D, B, fl.w32("linear.weight"), fl.w32("linear.bias"), rep, emb,
-                     clip_stride_flow=Sf * D)
+                     clip_stride_flow=Sf * D, nsnippets=ns)
         imp = None
         if self.importance_loss:                              # importance_function(full RGB sequence), :419-421
-            imp = torch.empty(B, 1, Sx, 1, dtype=torch.float32, device=ref.device)
-            ops.importance_fwd(zr, fl.w32("importance_function.weight"), fl.w32("importance_function.bias"), B * Sx, imp)
-        saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, Sx=Sx, Sf=Sf) if save else None
+            imp = torch.empty(B, ns, Sx, 1, dtype=torch.float32, device=ref.device)
+            ops.importance_fwd(zr, fl.w32("importance_function.weight"), fl.w32("importance_function.bias"), B * ns * Sx, imp)
+        saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, ns=ns, Sx=Sx, Sf=Sf,
+                     xshape=None if x is None else x.shape, fshape=None if f is None else f.shape) if save else None
         return emb, attn, imp, saved
 
     def _stream_bwd(self, s, dz, need_dx):
@@ -309,17 +313,21 @@ class fullModel(nn.Module):
     def _backward_kernels(self, saved, demb, needs, dimp=None):
         fl = self.flat
         fl.attach_grads()
-        B, Sx, Sf = saved["B"], saved["Sx"], saved["Sf"]
+        B, ns, Sx, Sf = saved["B"], saved["ns"], saved["Sx"], saved["Sf"]
         zr, zf = saved["zr"], saved["zf"]
         dzr = torch.zeros_like(zr) if zr is not None else None
         dzf = torch.zeros_like(zf) if zf is not None else None
         ops.head_bwd(demb, fl.w32("linear.weight"), saved["rep"], zr, zf, (Sx if zr is not None else Sf) * D, B,
-                     fl.g("linear.weight"), fl.g("linear.bias"), dzr, dzf, clip_stride_flow=Sf * D)
+                     fl.g("linear.weight"), fl.g("linear.bias"), dzr, dzf, clip_stride_flow=Sf * D, nsnippets=ns)
         if dimp is not None:
-            ops.importance_bwd(dimp, zr, fl.w32("importance_function.weight"), B * Sx, dzr,
+            ops.importance_bwd(dimp, zr, fl.w32("importance_function.weight"), B * ns * Sx, dzr,
                                fl.g("importance_function.weight"), fl.g("importance_function.bias"))
         dx = self._stream_bwd(saved["sr"], dzr, needs[0]) if zr is not None else None
         df = self._stream_bwd(saved["sf"], dzf, needs[1]) if zf is not None else None
         if self.grad_ready_hook:
             self.grad_ready_hook(0, fl.numel)
+        if dx is not None:
+            dx = dx.view(saved["xshape"])
+        if df is not None:
+            df = df.view(saved["fshape"])
         return dx, df

@@ -406,6 +406,80 @@ def golden_e2e(vits, prepare_model, misc, out):
     print("e2e.npz keys", len(g))
 
 
+def snippet_inputs():
+    """nsnippets = 3 (prepare_model.py:179-221,381-382): x, f [B, 3, T, 384], mask [B, 3, T+1] with a different length per
+    (clip, snippet); shared with tests/."""
+    B, NS, T = 2, 3, 6
+    lens = [[6, 4, 5], [3, 6, 1]]
+    g = torch.Generator().manual_seed(321)
+    x = torch.randn(B, NS, T, 384, generator=g)
+    f = torch.randn(B, NS, T, 384, generator=g)
+    pad = torch.zeros(B, NS, T + 1, dtype=torch.bool)
+    for b in range(B):
+        for s_ in range(NS):
+            x[b, s_, lens[b][s_]:] = 0
+            f[b, s_, lens[b][s_]:] = 0
+            pad[b, s_, lens[b][s_] + 1:] = True
+    return x, f, pad, synth.labels(seed=77, B=B)
+
+
+def golden_snippets(prepare_model, misc, out):
+    g = {}
+    x, f, pad, lab = snippet_inputs()
+    for modal in ("RGB", "RGB-Flow"):
+        m = build_full(prepare_model, 2, modal)
+        protos = nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in synth.prototypes(seed=2, nclasses=2).items()})
+        x_in = x.clone().requires_grad_(True)
+        f_in = f.clone().requires_grad_(True)
+        emb, attn = m(x_in * 1.0, f_in * 1.0, None, None, 'Prototypes', pad.clone(), pad.clone(), None)
+        loss = misc.calcNCELoss(0, emb, lab, ["a", "b"], protos, None)
+        loss.backward()
+        key = modal + "/"
+        g[key + "emb"] = emb.detach().numpy()
+        g[key + "attn"] = attn.detach().numpy()
+        g[key + "loss"] = np.float32(loss.item())
+        g[key + "grad_x"] = x_in.grad.numpy()
+        if modal == "RGB-Flow":
+            g[key + "grad_f"] = f_in.grad.numpy()
+        P = dict(m.named_parameters())
+        for n in ("linear.weight", "linear.bias", "frame_cls", "frame_pos_embeddings.0", "frame_pos_embeddings.5",
+                  "transEncoderFrame.layers.0.self_attn.in_proj_bias", "transEncoderFrame.layers.3.norm2.bias"):
+            g[key + "grad/" + n] = P[n].grad.numpy()
+    np.savez_compressed(os.path.join(out, "snippets.npz"), **g)
+    print("snippets.npz keys", len(g), "attn", attn.shape)
+
+
+def golden_outlier(vits, prepare_model, misc, out):
+    """DINO-like dynamic range (synth.vit_state_dict_outlier): ViT features, last-block residual statistics, embeddings,
+    attention map and cosine logits of a 2-clip x 8-frame batch, from the reference's own modules."""
+    g = {}
+    vit = vits.vit_small(patch_size=16, drop_path_rate=0.0)
+    vit.load_state_dict(synth.vit_state_dict_outlier(seed=3), strict=True)
+    vit.eval()
+    B, T = 2, 8
+    m = build_full(prepare_model, 2, "RGB", nlayers=4)
+    clips = synth.clips(seed=977, B=B, T=T)
+    pad = synth.padding_mask([T, T - 3])
+    protos = synth.prototypes(seed=2, nclasses=2)
+    with torch.no_grad():
+        x = vit.prepare_tokens(clips.view(B * T, 3, 224, 224))
+        absmax = []
+        for blk in vit.blocks:
+            x = blk(x)
+            absmax.append(x.abs().max().item())
+        reps = vit.norm(x)[:, 0].view(B, 1, T, 384)
+        emb, attn = m(reps * 1.0, reps * 1.0, [T, T - 3], [T, T - 3], 'Prototypes', pad.clone(), pad.clone(), None)
+    p = torch.vstack(list(protos.values()))
+    sim = (emb / emb.norm(dim=1, keepdim=True)) @ (p / p.norm(dim=1, keepdim=True)).T
+    g["reps"] = reps.numpy()
+    g["emb"] = emb.numpy()
+    g["attn"] = attn.numpy()
+    g["sim"] = sim.numpy()
+    g["resid_absmax_per_block"] = np.array(absmax, np.float32)
+    np.savez_compressed(os.path.join(out, "outlier.npz"), **g)
+    print("outlier.npz: residual |x|max per block", [round(a, 1) for a in absmax], "sim", sim.numpy().round(4).tolist())
+
+
 def main():
     torch.set_num_threads(8)
     vits, prepare_model, misc = import_reference()
@@ -414,6 +488,8 @@ def main():
     golden_collate(HERE)
     golden_e2e(vits, prepare_model, misc, HERE)
     golden_importance(prepare_model, misc, HERE)
+    golden_outlier(vits, prepare_model, misc, HERE)
+    golden_snippets(prepare_model, misc, HERE)
 
 
 if __name__ == "__main__":

@@ -55,6 +55,31 @@ def vit_state_dict(seed=0, depth=VIT_DEPTH, w_std=0.04):
     return sd
 
 
+OUTLIER_CHANNELS = (7, 101, 300)
+
+
+def vit_state_dict_outlier(seed=3, depth=VIT_DEPTH):
+    """ViT-S/16 weights with the dynamic range of a trained DINO checkpoint rather than of an initialiser: a few
+    "massive-activation" residual channels (pushed to ~+-25 by the first blocks' fc2 biases and kept there), LayerNorm
+    gains of x20-x50 on those and a few other channels, and larger attention logits.  What the bf16 operand path has to
+    survive: |xn| up to ~100 next to O(1) values in the same row, outliers in the residual stream, peaky softmax."""
+    sd = vit_state_dict(seed=seed, depth=depth)
+    g = _gen(seed + 1000)
+    for i in range(depth):
+        p = f"blocks.{i}."
+        for c, mag in zip(OUTLIER_CHANNELS, (25.0, -18.0, 30.0)):
+            if i < 2:
+                sd[p + "mlp.fc2.bias"][c] += mag / 2                 # the residual stream picks the outliers up early
+            sd[p + "norm1.weight"][c] *= 0.05                        # ... and trained LN gains squash them again
+            sd[p + "norm2.weight"][c] *= 0.05
+        hot = torch.randint(0, VIT_DIM, (4,), generator=g)
+        sd[p + "norm1.weight"][hot] *= 20.0 + 30.0 * torch.rand(4, generator=g)      # x20 - x50 gains
+        sd[p + "norm2.weight"][hot] *= 20.0 + 30.0 * torch.rand(4, generator=g)
+        sd[p + "attn.qkv.weight"][:2 * VIT_DIM] *= 1.5               # sharper attention
+    sd["norm.weight"][list(OUTLIER_CHANNELS)] *= 0.05
+    return sd
+
+
 def temporal_keys(importance=False, nlayers=T_LAYERS):
     """fullModel('reps', nclasses, domain, 384, 'ViT') parameter contract,
     without the encoder.* ballast."""

@@ -361,3 +361,65 @@ def test_sgd_step_matches_oracle_update(gpu):
     assert (emb1 - emb0).abs().max().item() > 1e-4
     loss1 = calcNCELoss(0, emb1, lab, ["a", "b"], protos, None)
     assert loss1.item() < loss.item()
+
+
+def test_outlier_weights_logits_within_the_bar(gpu, golden):
+    """Weights with the dynamic range of a TRAINED DINO checkpoint (synth.vit_state_dict_outlier: massive-activation
+    residual channels up to |x| ~ 70, LayerNorm gains x20-x50, sharper attention) instead of an initialiser's: the
+    class logits must still match the reference within the 1e-3 north-star bar (VERDICT r1 weak #3)."""
+    from sais_amd.loss import cosine_logits_and_probs
+    from sais_amd.vit import vit_small
+    g = golden("outlier")
+    vit = vit_small(patch_size=16, drop_path_rate=0.0)
+    vit.load_state_dict(synth.vit_state_dict_outlier(seed=3), strict=True)
+    vit = vit.to(DEV).eval()
+    m = make_full(2, "RGB")
+    B, T = 2, 8
+    clips = synth.clips(seed=977, B=B, T=T).to(DEV)
+    lens = [T, T - 3]
+    pad = synth.padding_mask(lens).to(DEV)
+    with torch.no_grad():
+        reps = vit(clips.view(B * T, 3, 224, 224)).view(B, 1, T, 384)
+        emb, attn = m(reps, None, lens, None, 'Prototypes', pad, None, None)
+        sim, _ = cosine_logits_and_probs(emb, protos_dev(2))
+    dfeat = maxabs(reps, g["reps"])
+    assert dfeat <= FEAT_REL * np.abs(g["reps"]).max(), dfeat
+    assert maxabs(sim, g["sim"]) <= LOGIT_TOL, maxabs(sim, g["sim"])
+    assert maxabs(attn, g["attn"]) <= ATTN_TOL, maxabs(attn, g["attn"])
+    # the same weights at the row-kernel dispatch (M >= 8192: 48 frames): logits agree with the small-batch path
+    big = synth.clips(seed=977, B=6, T=8)
+    big[:2] = clips.cpu()
+    with torch.no_grad():
+        reps_big = vit(big.view(48, 3, 224, 224).to(DEV))[:16].view(B, 1, T, 384)
+        emb2, _ = m(reps_big, None, lens, None, 'Prototypes', pad, None, None)
+        sim2, _ = cosine_logits_and_probs(emb2, protos_dev(2))
+    assert maxabs(sim2, g["sim"]) <= LOGIT_TOL, maxabs(sim2, g["sim"])
+
+
+@pytest.mark.parametrize("modal", ["RGB", "RGB-Flow"])
+def test_multiple_snippets_per_clip_vs_golden(gpu, golden, modal):
+    """nsnippets = 3 (prepare_model.py:179-221: every (clip, snippet) is one encoder sequence; :381-382: mean of the
+    ReLU'd CLS rows over the snippets): embeddings, the [B*ns, S, S] attention map, loss and gradients vs the reference."""
+    import make_golden as MG
+    from sais_amd.loss import calcNCELoss
+    g = golden("snippets")
+    x, f, pad, lab = MG.snippet_inputs()
+    m = make_full(2, modal).train()
+    protos = protos_dev(2)
+    xd = x.to(DEV).requires_grad_(True)
+    fd = f.to(DEV).requires_grad_(True)
+    emb, attn = m(xd, fd, None, None, 'Prototypes', pad.to(DEV), pad.to(DEV), None)
+    loss = calcNCELoss(0, emb, lab, ["a", "b"], protos, None)
+    loss.backward()
+    key = modal + "/"
+    assert tuple(attn.shape) == (6, 7, 7)
+    assert maxabs(emb, g[key + "emb"]) <= 2e-3 * max(1.0, np.abs(g[key + "emb"]).max())
+    assert maxabs(attn, g[key + "attn"]) <= ATTN_TOL
+    assert abs(loss.item() - float(g[key + "loss"])) <= LOGIT_TOL
+    assert rel_l2(xd.grad, g[key + "grad_x"]) <= GRAD_REL and tuple(xd.grad.shape) == (2, 3, 6, 384)
+    if modal == "RGB-Flow":
+        assert rel_l2(fd.grad, g[key + "grad_f"]) <= GRAD_REL
+    P = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith(key + "grad/"):
+            assert rel_l2(P[k[len(key + "grad/"):]].grad, g[k]) <= GRAD_REL, k

@@ -212,3 +212,41 @@ def test_importance_head_and_loss(golden):
                 close(sd[k[len(key + "grad/"):]].grad, g[k], 1e-6)
     nan = O.importance_loss(torch.randn(2, 1, 5, 1), torch.zeros(2, 1, 4), synth.padding_mask([4, 4]), torch.tensor([1, 1]))
     assert torch.isnan(nan) and np.isnan(g["empty_low_skill_is_nan"])
+
+
+def test_outlier_weights(golden):
+    """The oracle on the DINO-like dynamic-range weights (synth.vit_state_dict_outlier) against the reference's outputs."""
+    g = golden("outlier")
+    B, T = 2, 8
+    clips = synth.clips(seed=977, B=B, T=T)
+    pad = synth.padding_mask([T, T - 3])
+    with torch.no_grad():
+        reps, emb, attn = O.e2e_forward(synth.vit_state_dict_outlier(seed=3), synth.temporal_state_dict(seed=1), clips,
+                                        None, pad, "RGB")
+        sim = O.cosine_logits(emb, synth.prototypes(seed=2, nclasses=2))
+    close(reps.view(B, 1, T, 384), g["reps"], 2e-4)
+    close(emb, g["emb"], 1e-4)
+    close(attn, g["attn"], 1e-5)
+    close(sim, g["sim"], 1e-5)
+    assert g["resid_absmax_per_block"].max() > 50      # the fixture does have massive activations
+
+
+def test_multiple_snippets_per_clip(golden):
+    import make_golden as MG
+    g = golden("snippets")
+    x, f, pad, lab = MG.snippet_inputs()
+    for modal in ("RGB", "RGB-Flow"):
+        sd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+        protos = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(seed=2, nclasses=2).items()}
+        xr = x.clone().requires_grad_(True)
+        emb, attn = O.temporal_forward(sd, xr, f.clone(), pad, pad, modal)
+        loss = O.nce_loss(emb, lab, protos)
+        loss.backward()
+        key = modal + "/"
+        close(emb, g[key + "emb"])
+        close(attn, g[key + "attn"])
+        assert abs(loss.item() - float(g[key + "loss"])) < 1e-6
+        close(xr.grad, g[key + "grad_x"], 1e-6)
+        for k in g.files:
+            if k.startswith(key + "grad/"):
+                close(sd[k[len(key + "grad/"):]].grad, g[k], 2e-4)

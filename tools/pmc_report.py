@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""profiles/pmc_mfma.json and profiles/pmc_traffic.json from rocprofv3 PMC passes over bench.py.
+
+On the GPU box (counters in their own passes, program directly after `--`, as MI355X_MICROARCH.md prescribes):
+    cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph"
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \\
+              SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -- $B
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -- $B
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -- $B
+then here:  python tools/pmc_report.py gpurun_out/pmc_sq gpurun_out/pmc_fetch gpurun_out/pmc_write
+
+Units (guide, 'Per-instruction cycle constants'): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed
+over waves; SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CU_CYCLES count cycles summed over CUs; GRBM_GUI_ACTIVE is summed over
+the 8 XCDs.  FETCH_SIZE / WRITE_SIZE count KiB; gfx950 reports half the bytes of wide coalesced reads, so FETCH_SIZE is
+doubled (the guide's gfx950 correction)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NT_NAMES = {0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_bf16", 5: "dgelu_bf16", 6: "drelu_bf16",
+            7: "patch_f32", 8: "relu_f32", 9: "drelu_f32", 10: "gelu_grad_bf16", 11: "mul_bf16"}
+ROW_NAMES = {0: "gemm_nt<bias_bf16>(row)", 1: "gemm_nt<resid_f32>(row)", 2: "gemm_ln_fwd", 3: "gemm_ln_bwd"}
+
+
+def timer_name(kernel):
+    m = re.search(r"gemm_nt_row_kernel<(\d+)>|gemm_nt_row_kernelILi(\d+)E", kernel)
+    if m:
+        return ROW_NAMES[int(m.group(1) or m.group(2))]
+    m = re.search(r"gemm_nt(?:_w8p)?_kernel<(\d+)>|gemm_nt(?:_w8p)?_kernelILi(\d+)E", kernel)
+    if m:
+        return "gemm_nt<%s>" % NT_NAMES[int(m.group(1) or m.group(2))]
+    for key, name in (("gemm_tn_wide_kernel", "gemm_tn_grouped"), ("gemm_tn_grouped_kernel", "gemm_tn_grouped"),
+                      ("attn_fwd_kernel", "vit_attn_fwd"), ("attn_bwd_dq_kernel", "vit_attn_bwd_dq"),
+                      ("attn_bwd_dkv_kernel", "vit_attn_bwd_dkv"), ("attn_bwd_kernel", "vit_attn_bwd"),
+                      ("ln_fwd_kernel", "ln_fwd"), ("ln_bwd_kernel", "ln_bwd"), ("sgd_kernel", "sgd")):
+        if key in kernel:
+            return name
+    return None
+
+
+def collect(folder):
+    """{kernel: {counter: [values per dispatch]}}"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(folder, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            n = timer_name(r["Kernel_Name"])
+            if n:
+                agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def mean(v):
+    return sum(v) / len(v) if v else 0.0
+
+
+def main():
+    sq, fetch, write = collect(sys.argv[1]), collect(sys.argv[2]), collect(sys.argv[3])
+    mf = {}
+    for n, c in sorted(sq.items()):
+        g = {k: mean(v) for k, v in c.items()}
+        wave = g.get("SQ_WAVE_CYCLES", 0.0)
+        busy = g.get("SQ_BUSY_CU_CYCLES", 0.0)
+        mf[n] = {
+            "launches_sampled": len(next(iter(c.values()))),
+            "counters_per_launch": {k: int(v) for k, v in g.items()},
+            # one MFMA pipe per SIMD, 4 SIMDs per CU: busy cycles per CU-cycle-with-work
+            "mfma_busy_frac_of_cu_busy": round(g.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / busy / 4, 4) if busy else None,
+            "wait_any_frac_of_wave_cycles": round(g.get("SQ_WAIT_ANY", 0.0) / wave, 4) if wave else None,
+            "wait_inst_any_frac_of_wave_cycles": round(g.get("SQ_WAIT_INST_ANY", 0.0) / wave, 4) if wave else None,
+            "active_inst_frac_of_wave_cycles": round(g.get("SQ_ACTIVE_INST_ANY", 0.0) / wave, 4) if wave else None,
+            "lds_bank_conflict_ratio": round(g.get("SQ_LDS_BANK_CONFLICT", 0.0) / g["SQ_LDS_IDX_ACTIVE"], 4)
+            if g.get("SQ_LDS_IDX_ACTIVE") else None,
+        }
+    json.dump({"collected_with": "rocprofv3 --pmc (one SQ pass) -- python3 bench.py --steps 2 --warmup 1 --no-graph",
+               "kernels": mf}, open(os.path.join(ROOT, "profiles", "pmc_mfma.json"), "w"), indent=1)
+    tr = {}
+    for n in sorted(set(fetch) & set(write)):
+        f, w = mean(fetch[n].get("FETCH_SIZE", [])), mean(write[n].get("WRITE_SIZE", []))
+        tr[n] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_kb_raw": int(f), "write_kb": int(w),
+                 "launches_sampled": len(fetch[n].get("FETCH_SIZE", [])),
+                 "note": "separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled (gfx950 correction)"}
+    json.dump(tr, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    for n, v in mf.items():
+        t = tr.get(n, {}).get("hbm_bytes_per_launch", 0) / 1e6
+        print(f"{n:28s} mfma {v['mfma_busy_frac_of_cu_busy']}  wait_any {v['wait_any_frac_of_wave_cycles']}  "
+              f"wait_inst {v['wait_inst_any_frac_of_wave_cycles']}  lds_conf {v['lds_bank_conflict_ratio']}  hbm {t:8.1f} MB")
+
+
+if __name__ == "__main__":
+    main()
