@@ -59,10 +59,15 @@ OUTLIER_CHANNELS = (7, 101, 300)
 
 
 def vit_state_dict_outlier(seed=3, depth=VIT_DEPTH):
-    """ViT-S/16 weights with the dynamic range of a trained DINO checkpoint rather than of an initialiser: a few
-    "massive-activation" residual channels (pushed to ~+-25 by the first blocks' fc2 biases and kept there), LayerNorm
-    gains of x20-x50 on those and a few other channels, and larger attention logits.  What the bf16 operand path has to
-    survive: |xn| up to ~100 next to O(1) values in the same row, outliers in the residual stream, peaky softmax."""
+    """ViT-S/16 weights with the dynamic range of a TRAINED DINO checkpoint rather than of an initialiser:
+      * "massive-activation" residual channels (pushed to ~ +-25 by the first blocks' fc2 biases and growing to |x| ~ 70),
+        squashed by small LayerNorm gains on those channels, as trained models do;
+      * LayerNorm gains of x20 - x50 on four other channels per norm, i.e. |xn| ~ 100 next to O(1) values in one row,
+        with the consuming weight columns (qkv / fc1) scaled down so that those channels carry ~4x a normal channel's
+        contribution - large gains in trained models pair with small downstream weights; without that the attention
+        logits reach |200| (std 20) and ANY bf16 path, torch's own autocast included, is 25 % off;
+      * attention logits ~6x sharper (|logit| up to ~30) than the friendly fixture's.
+    What the bf16 operand path has to survive: outliers in the residual stream and in the normalised rows."""
     sd = vit_state_dict(seed=seed, depth=depth)
     g = _gen(seed + 1000)
     for i in range(depth):
@@ -72,10 +77,12 @@ def vit_state_dict_outlier(seed=3, depth=VIT_DEPTH):
                 sd[p + "mlp.fc2.bias"][c] += mag / 2                 # the residual stream picks the outliers up early
             sd[p + "norm1.weight"][c] *= 0.05                        # ... and trained LN gains squash them again
             sd[p + "norm2.weight"][c] *= 0.05
-        hot = torch.randint(0, VIT_DIM, (4,), generator=g)
-        sd[p + "norm1.weight"][hot] *= 20.0 + 30.0 * torch.rand(4, generator=g)      # x20 - x50 gains
-        sd[p + "norm2.weight"][hot] *= 20.0 + 30.0 * torch.rand(4, generator=g)
-        sd[p + "attn.qkv.weight"][:2 * VIT_DIM] *= 1.5               # sharper attention
+        for norm, consumer in (("norm1", "attn.qkv.weight"), ("norm2", "mlp.fc1.weight")):
+            hot = torch.randint(0, VIT_DIM, (4,), generator=g)
+            gain = 20.0 + 30.0 * torch.rand(4, generator=g)          # x20 - x50 gains
+            sd[p + norm + ".weight"][hot] *= gain
+            sd[p + consumer][:, hot] *= 4.0 / gain
+        sd[p + "attn.qkv.weight"][:2 * VIT_DIM] *= 2.5               # sharper attention
     sd["norm.weight"][list(OUTLIER_CHANNELS)] *= 0.05
     return sd
 

@@ -228,7 +228,7 @@ def test_outlier_weights(golden):
     close(emb, g["emb"], 1e-4)
     close(attn, g["attn"], 1e-5)
     close(sim, g["sim"], 1e-5)
-    assert g["resid_absmax_per_block"].max() > 50      # the fixture does have massive activations
+    assert g["resid_absmax_per_block"].max() > 30      # the fixture does have massive activations
 
 
 def test_multiple_snippets_per_clip(golden):
