@@ -15,21 +15,13 @@
 #include <stdlib.h>
 #include "common.hpp"
 #include "../../include/sais_hip.h"
+#include "gemm_nt_epi.hpp"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand per stage
 
-struct NtParams {
-    const bf16* A; const bf16* B;
-    int lda, ldb, M, N, K;
-    const float* bias;
-    void* out; int ldo;
-    void* out2; int ldo2;
-    const void* aux; int ldaux;
-    int grp_in, grp_out, grp_off;
-};
 
 // Epilogue in two phases.  vmcnt is in-order and counts stores on CDNA4, so a load issued after a store cannot be
 // consumed before that store has been acknowledged: phase A issues EVERY load a lane needs (bias once, the
@@ -215,97 +207,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Eight-wave form of the A-ring kernel: the same 128x128x64 tile and LDS image, but 512 threads (2 x 4 waves of
-// 64 x 32), so that each wave issues 4 instead of 8 LDS-DMA instructions per K-step (an issue holds the wave for
-// 65-85 cycles) and four waves per SIMD (two workgroups per CU) cover each other's stalls.  Needs <= 128 VGPRs.
-// Weight rows are permuted inside each 32-row panel (LDS row 16 t + 4 a + b <- panel column 8 a + 4 t + b) so that a
-// lane owns 8 CONTIGUOUS output columns of a row: one 16-B bf16 store or two fp32 ones.
-DEVINL int perm_row32(int n) { return (n & ~31) | (((n >> 2) & 3) << 3) | (((n >> 4) & 1) << 2) | (n & 3); }
-
-struct EpiAux8 {
-    f32x4 r[4][2];        // f32 aux: 8 columns x 4 sub-tiles
-    bf16x8 u[4];          // bf16 aux
-};
-
-template <int EPI>
-DEVINL void epilogue_loads8(const NtParams& p, int mbase, int li, int n, float (&b)[8], EpiAux8& a) {
-    if (p.bias) {
-        const f32x4 t0 = *(const f32x4*)(p.bias + n), t1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { b[i] = t0[i]; b[4 + i] = t1[i]; }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = 0.f;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        int m = mbase + mt * 16 + li;
-        m = m < p.M ? m : p.M - 1;
-        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
-            const float* r = (const float*)p.aux + (size_t)m * p.ldaux + n;
-            a.r[mt][0] = *(const f32x4*)r;
-            a.r[mt][1] = *(const f32x4*)(r + 4);
-        } else if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16 || EPI == SAIS_EPI_MUL_BF16) {
-            a.u[mt] = *(const bf16x8*)((const bf16*)p.aux + (size_t)m * p.ldaux + n);
-        }
-    }
-}
-
-template <int EPI>
-DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], const float (&b)[8], const EpiAux8& a, int mt) {
-    float y[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = v[i] + b[i];
-    auto store_bf16 = [&](void* base, int ld, const float (&z)[8]) {
-        bf16x8 o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = (bf16)z[i];
-        *(bf16x8*)((bf16*)base + (size_t)m * ld + n) = o;
-    };
-    auto store_f32 = [&](void* base, int ld, const float (&z)[8]) {
-        float* o = (float*)base + (size_t)m * ld + n;
-        *(f32x4*)o = f32x4{z[0], z[1], z[2], z[3]};
-        *(f32x4*)(o + 4) = f32x4{z[4], z[5], z[6], z[7]};
-    };
-    if constexpr (EPI == SAIS_EPI_BIAS_BF16) {
-        store_bf16(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_BIAS_RELU_BF16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = fmaxf(y[i], 0.f);
-        store_bf16(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_BIAS_F32) {
-        store_f32(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] += a.r[mt][i >> 2][i & 3];
-        store_f32(p.out, p.ldo, y);
-        if (p.out2) store_bf16(p.out2, p.ldo2, y);
-    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
-        if (p.out2) store_bf16(p.out2, p.ldo2, y);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = gelu_erf(y[i]);
-        store_bf16(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) {
-        float d[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) gelu_and_grad(y[i], y[i], d[i]);
-        store_bf16(p.out2, p.ldo2, d);
-        store_bf16(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] *= (float)a.u[mt][i];
-        store_bf16(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] *= dgelu_erf((float)a.u[mt][i]);
-        store_bf16(p.out, p.ldo, y);
-    } else if constexpr (EPI == SAIS_EPI_DRELU_BF16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = (float)a.u[mt][i] > 0.f ? y[i] : 0.f;
-        store_bf16(p.out, p.ldo, y);
-    }
-}
-
 // Persistent form of the eight-wave kernel: a workgroup walks tiles b, b + G, ... and issues the first LDS-DMA loads of
 // its NEXT tile (A'(0), W'(0), A'(1)) before the epilogue of the current one, so the per-tile prologue (the first
 // K-tile's round trip, ~19 % of a K = 384 tile) runs under the epilogue's arithmetic and stores.  vmcnt is in-order
@@ -961,7 +862,8 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
             hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
         break;
 
-extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream);      // gemm_row.hip: 128 x 384 row-owning tiles
+extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream);      // gemm_row.hip: row-owning tiles, N = 384
+extern "C" int sais_gemm_nt_wstat_(const SaisGemm* g, void* stream);    // gemm_wstat.hip: weight-stationary, K <= 384
 
 extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     SAIS_ENTER();
@@ -979,6 +881,13 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
     // four-wave A-ring) were measured slower inside the step and are gone from the library.
     const bool big = g->M >= 8192;
+#ifndef SAIS_NO_WSTAT
+    // K = 384, wide N (qkv, fc1 + GELU, dX of fc2): the W panel stays in LDS, only A streams (gemm_wstat.hip)
+    if (big && g->K >= 256 && g->K <= 384 && g->N >= 1152 && g->N <= 256 * 128 &&
+        (g->epilogue == SAIS_EPI_BIAS_BF16 || g->epilogue == SAIS_EPI_MUL_BF16 ||
+         g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16))
+        return sais_gemm_nt_wstat_(g, stream);
+#endif
     // the plain N = 384 GEMMs of a training step (dX of proj, the last block's fc2): balanced row tiles of gemm_row.hip
     if (big && g->N == 384 && (g->epilogue == SAIS_EPI_BIAS_BF16 || (g->epilogue == SAIS_EPI_BIAS_RESID_F32 && !g->out2)))
         return sais_gemm_nt_row_(g, stream);
