@@ -327,6 +327,151 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16* qkv, l
     }
 }
 
+// ------------------------------------------------------------------------------------------ backward, single pass
+// One persistent 1024-thread workgroup per CU walks the (frame, head) problems.  Q, dO and K of a head are staged ONCE
+// into LDS (160-B rows: row and transposed reads conflict-free); P is rebuilt ONCE per (query, key) from the saved
+// log-sum-exp with the KEY on the lane (S = Q K^T, dP = dO V^T: K / V fragments of a wave's key tile live in its
+// registers), so that P and dS are already the B operands of dV^T += dO^T P and dK^T += Q^T dS (accumulated in
+// registers over the query sweep: no cross-workgroup sums).  Only dS crosses LDS, once, as a bf16 [key][query] image
+// (double-buffered, 96-B rows: conflict-free transposed reads): after the barrier eight waves turn it into
+// dQ^T = K^T dS^T for the 32 queries of the step — complete over all keys, so dQ goes straight to HBM.
+// delta_q = sum_d dO O is computed while staging.  Five MFMA products per (query, key) tile instead of seven, one
+// exponential instead of two, every operand staged once (the two-kernel version re-staged K, V, Q, dO: 470 vs 348 MB).
+constexpr int SROW = 96;                                   // bytes per key row of the dS image (32 queries bf16 + pad)
+constexpr int S_BYTES = TILE_ROWS * SROW;                  // 21504
+constexpr int BWD_LDS = 3 * MAT_BYTES + 2 * TILE_ROWS * 4 + 2 * S_BYTES;     // 152320
+
+__global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+                                                        const bf16* out, long ldout, const float* lse, int nprob,
+                                                        bf16* dqkv, long lddq, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sQ = smem;
+    char* const sO = smem + MAT_BYTES;
+    char* const sK = smem + 2 * MAT_BYTES;
+    float* const sL = (float*)(smem + 3 * MAT_BYTES);      // lse * log2e   [224]
+    float* const sD = sL + TILE_ROWS;                      // delta         [224]
+    char* const sS = (char*)(sD + TILE_ROWS);              // 2 x [224 keys][32 q] bf16
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float c = scale * LOG2E;
+    for (int prob = blockIdx.x; prob < nprob; prob += gridDim.x) {
+        const int f = prob / NH, h = prob - f * NH;
+        const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
+        const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
+        const bf16* ob = out + (size_t)f * NTOK * ldout + h * HD;
+        // ---- stage Q, dO, K (rows >= 197 zero) and delta = rowsum(dO * O); 8 threads per row, 128 rows per pass
+        {
+            const int cch = tid & 7, r0 = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = r0 + 128 * i;
+                if (r < TILE_ROWS) {
+                    const bool ok = r < NTOK;
+                    const u32x4 z = {0, 0, 0, 0};
+                    const u32x4 vq = ok ? *(const u32x4*)(base + (size_t)r * ldq + cch * 8) : z;
+                    const u32x4 vk = ok ? *(const u32x4*)(base + DM + (size_t)r * ldq + cch * 8) : z;
+                    const u32x4 vd = ok ? *(const u32x4*)(dob + (size_t)r * ldo + cch * 8) : z;
+                    const u32x4 vo = ok ? *(const u32x4*)(ob + (size_t)r * ldout + cch * 8) : z;
+                    *(u32x4*)(sQ + r * ROWB + cch * 16) = vq;
+                    *(u32x4*)(sK + r * ROWB + cch * 16) = vk;
+                    *(u32x4*)(sO + r * ROWB + cch * 16) = vd;
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, vd), b = __builtin_bit_cast(bf16x8, vo);
+                    float dl = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)a[e], (float)b[e], dl);
+                    dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4);
+                    if (cch == 0) {
+                        sD[r] = dl;
+                        sL[r] = ok ? lse[((size_t)f * NH + h) * NTOK + r] * LOG2E : INFINITY;    // exp2(-inf) = 0: pad queries
+                    }
+                }
+            }
+        }
+        // this wave's key tile: K and V fragments in registers (key on the lane)
+        const int kt = wid;                                // waves 13..15 own no key tile
+        const int key = kt * 16 + li;
+        bf16x8 fk[2], fv[2];
+        if (kt < NKT) {
+            load_q_frags(base + DM, ldq, key, g, fk);
+            load_q_frags(base + 2 * DM, ldq, key, g, fv);
+        }
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+        __syncthreads();
+#pragma unroll 1
+        for (int qs = 0; qs < NKS; ++qs) {
+            char* const sb = sS + (qs & 1) * S_BYTES;
+            if (kt < NKT) {
+                f32x4 p[2], ds[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qrow = 32 * qs + 16 * u;      // lane holds q = qrow + 4 g + r, key = 16 kt + li
+                    f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        a = mfma16(row_frag(sQ, qrow + li, 4 * ks + g), fk[ks], a);     // S[q][key]
+                        b = mfma16(row_frag(sO, qrow + li, 4 * ks + g), fv[ks], b);     // dP[q][key]
+                    }
+                    const f32x4 l4 = *(const f32x4*)(sL + qrow + 4 * g);
+                    const f32x4 d4 = *(const f32x4*)(sD + qrow + 4 * g);
+                    bf16x4 dsb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = fast_exp2(__builtin_fmaf(a[r], c, -l4[r]));
+                        p[u][r] = pv;
+                        const float t = pv * (b[r] - d4[r]);             // x scale at the dK / dQ stores
+                        ds[u][r] = t;
+                        dsb[r] = (bf16)(key < NTOK ? t : 0.f);           // pad keys must not reach dQ
+                    }
+                    *(bf16x4*)(sb + key * SROW + (16 * u + 4 * g) * 2) = dsb;
+                }
+                const bf16x8 pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma16(tr_frag(sO, qs, dt, g, li), pf, dv[dt]);            // dV^T[d][key]
+                    dk[dt] = mfma16(tr_frag(sQ, qs, dt, g, li), dsf, dk[dt]);           // dK^T[d][key]
+                }
+            } else {                                        // rows 208..223 of the dS image belong to no key tile
+                if (qs < 2) {
+                    for (int i = lane + 64 * (wid - NKT); i < 16 * SROW / 8; i += 64 * (16 - NKT))
+                        *(u32x2*)(sS + qs * S_BYTES + NKT * 16 * SROW + i * 8) = u32x2{0, 0};
+                }
+            }
+            __syncthreads();                                // dS of this query step is complete
+            if (wid >= 8) {                                 // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+                const int w = wid - 8, qt = w >> 2, dt = w & 3;
+                f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const char* ps = sb + (32 * ks + 4 * g + (li >> 2)) * SROW + (16 * qt + 4 * (li & 3)) * 2;
+                    const bf16x8 fs = cat4(lds_read_tr16(ps), lds_read_tr16(ps + 16 * SROW));
+                    o = mfma16(tr_frag(sK, ks, dt, g, li), fs, o);
+                }
+                const int q = 32 * qs + 16 * qt + li;       // lane: query q, d = 16 dt + 4 g + r
+                if (q < NTOK) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[r] * scale);
+                    *(bf16x4*)(dqkv + ((size_t)f * NTOK + q) * lddq + h * HD + 16 * dt + 4 * g) = v;
+                }
+            }
+        }
+        if (kt < NKT && key < NTOK) {
+            bf16* krow = dqkv + ((size_t)f * NTOK + key) * lddq + DM + h * HD + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                bf16x4 a, b;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = (bf16)(dk[dt][r] * scale); b[r] = (bf16)dv[dt][r]; }
+                *(bf16x4*)(krow + 16 * dt) = a;
+                *(bf16x4*)(krow + DM + 16 * dt) = b;
+            }
+        }
+        __syncthreads();                                    // every read of this problem's images is done
+    }
+}
+
 constexpr int FWD_LDS = 2 * MAT_BYTES;
 constexpr int DKV_LDS = 2 * MAT_BYTES + 2 * TILE_ROWS * 4;
 
@@ -362,6 +507,14 @@ extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, 
     if (!qkv || !dout || !out || !lse || !delta_ws || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) ||
         (ldout & 7) || (lddqkv & 3))
         return SAIS_ERR_ARG;
+#ifndef SAIS_ATTN_BWD_TWO_PASS
+    if (set_lds(attn_bwd_kernel, BWD_LDS)) return SAIS_ERR_LAUNCH;
+    const int nprob = frames * NH;
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(nprob < 256 ? nprob : 256), dim3(1024), BWD_LDS, (hipStream_t)stream,
+                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, nprob,
+                       (bf16*)dqkv, lddqkv, 0.125f);
+    return sais_check_launch();
+#endif
     if (set_lds(attn_bwd_dq_kernel, FWD_LDS) || set_lds(attn_bwd_dkv_kernel, DKV_LDS)) return SAIS_ERR_LAUNCH;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(NH, frames), dim3(512), FWD_LDS, (hipStream_t)stream,
                        (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, delta_ws,

@@ -863,7 +863,6 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
         break;
 
 extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream);      // gemm_row.hip: row-owning tiles, N = 384
-extern "C" int sais_gemm_nt_wstat_(const SaisGemm* g, void* stream);    // gemm_wstat.hip: weight-stationary, K <= 384
 
 extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     SAIS_ENTER();
@@ -881,13 +880,6 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
     // four-wave A-ring) were measured slower inside the step and are gone from the library.
     const bool big = g->M >= 8192;
-#ifndef SAIS_NO_WSTAT
-    // K = 384, wide N (qkv, fc1 + GELU, dX of fc2): the W panel stays in LDS, only A streams (gemm_wstat.hip)
-    if (big && g->K >= 256 && g->K <= 384 && g->N >= 1152 && g->N <= 256 * 128 &&
-        (g->epilogue == SAIS_EPI_BIAS_BF16 || g->epilogue == SAIS_EPI_MUL_BF16 ||
-         g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16))
-        return sais_gemm_nt_wstat_(g, stream);
-#endif
     // the plain N = 384 GEMMs of a training step (dX of proj, the last block's fc2): balanced row tiles of gemm_row.hip
     if (big && g->N == 384 && (g->epilogue == SAIS_EPI_BIAS_BF16 || (g->epilogue == SAIS_EPI_BIAS_RESID_F32 && !g->out2)))
         return sais_gemm_nt_row_(g, stream);

@@ -209,24 +209,20 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const fl
     emb[(size_t)b * EMB + tid] = a;
 }
 
-// demb [B,256] -> dW += demb^T relu(rep), db += sum_b demb, dz_rgb[b,0,:] / dz_flow[b,0,:]
+// demb [B,256] -> dz_rgb[b,s,0,:] / dz_flow[b,s,0,:] (one workgroup per clip), then dW += demb^T relu(rep) and
+// db += sum_b demb with one OWNER thread per output element (a loop over the clips instead of B x 256 x 384 atomics:
+// 54 us -> a few us at B = 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const float* W, const float* rep,
                                                        const float* zr, const float* zf, long clip_stride,
-                                                       long clip_stride_f, int B, int ns, float* dW, float* dbias,
-                                                       float* dzr, float* dzf) {
+                                                       long clip_stride_f, int B, int ns, float* dzr, float* dzf) {
     __shared__ float sd[EMB];
     const int b = blockIdx.x, tid = threadIdx.x;
     sd[tid] = demb[(size_t)b * EMB + tid];
     __syncthreads();
-    atomicAdd(dbias + tid, sd[tid]);
     for (int c = tid; c < D; c += 256) {
-        float r = rep[(size_t)b * D + c];
-        float r2 = fmaxf(r, 0.f);
+        const float r = rep[(size_t)b * D + c];
         float a = 0.f;
-        for (int o = 0; o < EMB; ++o) {
-            a += W[(size_t)o * D + c] * sd[o];
-            if (r2 != 0.f) atomicAdd(dW + (size_t)o * D + c, sd[o] * r2);
-        }
+        for (int o = 0; o < EMB; ++o) a += W[(size_t)o * D + c] * sd[o];
         const float drep = (r > 0.f ? a : 0.f) / ns;
         for (int s = 0; s < ns; ++s) {
             const size_t ir = (size_t)(b * ns + s) * clip_stride + c, jf = (size_t)(b * ns + s) * clip_stride_f + c;
@@ -234,6 +230,20 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const 
             if (zf) dzf[jf] = zf[jf] > 0.f ? drep : 0.f;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* demb, const float* rep, int B, float* dW,
+                                                          float* dbias) {
+    const int c = blockIdx.x, o = threadIdx.x;               // grid D (+1 block for the bias), 256 threads = EMB
+    if (c == D) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += demb[(size_t)b * EMB + o];
+        dbias[o] += a;
+        return;
+    }
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += demb[(size_t)b * EMB + o] * fmaxf(rep[(size_t)b * D + c], 0.f);
+    dW[(size_t)o * D + c] += a;
 }
 
 // ---------------------------------------------------------------- importance head (-il): Linear(384 -> 1) on relu(z)
@@ -452,7 +462,8 @@ extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep
     if (!demb || !W || !rep || !dW || !dbias || B <= 0 || nsnippets <= 0) return SAIS_ERR_ARG;
     if ((z_rgb && !dz_rgb) || (z_flow && !dz_flow)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, demb, W, rep, z_rgb, z_flow,
-                       clip_stride, clip_stride_flow, B, nsnippets, dW, dbias, dz_rgb, dz_flow);
+                       clip_stride, clip_stride_flow, B, nsnippets, dz_rgb, dz_flow);
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(D + 1), dim3(EMB), 0, (hipStream_t)stream, demb, rep, B, dW, dbias);
     return sais_check_launch();
 }
 

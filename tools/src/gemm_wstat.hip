@@ -1,3 +1,8 @@
+// NOT PART OF libsais_hip.so — kept as the record of a round-2 experiment (correct: it passed test_gemm_nt_epilogues
+// when wired into sais_gemm_nt; measured inside the training step on MI355X: fc1+GELU 142.5 vs 145.8 us, dX fc2 121.0 vs
+// 114.4 us, qkv 72.4 vs 69.7 us against the 128x128 persistent kernel, i.e. no gain: these GEMMs are not bound by the
+// LDS fill stream).  Include path when rebuilding: -I sais_amd/csrc.
+//
 // Weight-stationary bf16 MFMA GEMM for the short-K, wide-N GEMMs of a ViT block (gfx950):
 //     C[M,N] = A[M,K] . W[N,K]^T + epilogue,   K <= 384, N >= 1152   (qkv; fc1 + GELU / GELU'; dX of fc2 x GELU')
 //     — Attention.qkv / Mlp.fc1 of dino-main/vision_transformer.py:59-65,80-92 and the dX of Mlp.fc2.
