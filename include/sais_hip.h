@@ -144,7 +144,8 @@ int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float* dy_f32, lo
 int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, float* lse, float* probs,
                       void* stream);
 /* dqkv bf16 [frames*197, 1152] from dout bf16 [frames*197, 384] and the saved forward output `out` (same shape:
- * delta_q = sum_d dout[q,d] out[q,d] is the softmax-backward row term); delta_ws f32 [frames,6,197] scratch.     */
+ * delta_q = sum_d dout[q,d] out[q,d] is the softmax-backward row term, computed in the kernel).  One single-pass
+ * kernel: P is rebuilt once per (query, key) from lse.  delta_ws is unused since ABI 2 (may be NULL).              */
 int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout,
                       const float* lse, float* delta_ws, int frames, void* dqkv, long lddqkv, void* stream);
 

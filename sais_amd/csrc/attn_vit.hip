@@ -34,19 +34,6 @@ DEVINL void stage_matrix(char* lds, const bf16* src, long ld, int tid) {
         *(u32x4*)(lds + r * ROWB + c * 16) = v;
     }
 }
-// the same for a 512-thread workgroup (the backward kernels run 8 waves per (frame, head))
-DEVINL void stage_matrix512(char* lds, const bf16* src, long ld, int tid) {
-    const int c = tid & 7, r0 = tid >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = r0 + 64 * i;
-        if (r < TILE_ROWS) {
-            u32x4 v = r < NTOK ? *(const u32x4*)(src + (size_t)r * ld + c * 8) : u32x4{0, 0, 0, 0};
-            *(u32x4*)(lds + r * ROWB + c * 16) = v;
-        }
-    }
-}
-
 DEVINL bf16x8 row_frag(const char* lds, int row, int chunk) { return *(const bf16x8*)(lds + row * ROWB + chunk * 16); }
 
 // transposed fragment for k-step s (32 tokens) and 16-wide column tile ct
@@ -160,168 +147,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
                         int key = 16 * t + 4 * g + r;
                         if (key < NTOK) pr[key] = s[t][r] * inv;
                     }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ backward, dQ
-// Same orientation as forward (query on the lane).  P^T is rebuilt from the saved log-sum-exp, dP^T = V dO^T,
-// dS^T = P (dP - delta) scale, dQ^T = K^T dS^T, with delta_q = sum_d dO[q,d] O[q,d] (= sum_k P dP, taken from the saved
-// forward output so that it is known BEFORE the key sweep).  That makes the sweep streaming: 32 keys at a time are
-// scored, turned into dS and fed to the dQ MFMAs, and nothing but the 16 dQ accumulators outlives a step.  The first
-// version kept the full 16 x 208 P and dP strips (104 fp32 registers + their copies out of the accumulator file):
-// 378 VGPRs, one wave per SIMD, 105 us per ViT block; this one fits two workgroups per CU.
-__global__ __launch_bounds__(512, 2) void attn_bwd_dq_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
-                                                             const bf16* out, long ldout, const float* lse,
-                                                             float* delta, bf16* dqkv, long lddq, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sK = smem;
-    char* sV = smem + MAT_BYTES;
-    const int h = blockIdx.x, f = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
-    const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
-    const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
-    const bf16* ob = out + (size_t)f * NTOK * ldout + h * HD;
-    stage_matrix512(sK, base + DM, ldq, tid);
-    stage_matrix512(sV, base + 2 * DM, ldq, tid);
-    __syncthreads();
-    const float c = scale * LOG2E;
-    const int nmine = wid + 8 < NKT ? 2 : 1;                 // 13 query tiles over 8 waves: tiles w and w + 8
-    bf16x8 fq[2], fdo[2], fo[2], fq_next[2], fdo_next[2], fo_next[2];
-    load_q_frags(base, ldq, wid * 16 + li, g, fq);
-    load_q_frags(dob, ldo, wid * 16 + li, g, fdo);
-    load_q_frags(ob, ldout, wid * 16 + li, g, fo);
-    for (int it = 0; it < nmine; ++it) {
-        const int qt = wid + 8 * it;
-        const int q = qt * 16 + li, qc = q < NTOK ? q : NTOK - 1;
-        if (it + 1 < nmine) {                                                   // prefetch the next tile's rows
-            load_q_frags(base, ldq, (wid + 8 * (it + 1)) * 16 + li, g, fq_next);
-            load_q_frags(dob, ldo, (wid + 8 * (it + 1)) * 16 + li, g, fdo_next);
-            load_q_frags(ob, ldout, (wid + 8 * (it + 1)) * 16 + li, g, fo_next);
-        }
-        const float nl2 = -lse[((size_t)f * NH + h) * NTOK + qc] * LOG2E;
-        float dl = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)fdo[ks][e], (float)fo[ks][e], dl);
-        dl = group_sum(dl);
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0, 0, 0, 0};
-#pragma unroll 1
-        for (int ks = 0; ks < NKS; ++ks) {
-            f32x4 ds[2];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int t = 2 * ks + half;
-                if (t >= NKT) { ds[half] = f32x4{0, 0, 0, 0}; continue; }
-                f32x4 sc = {0, 0, 0, 0}, dp = {0, 0, 0, 0};
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    sc = mfma16(row_frag(sK, 16 * t + li, 4 * kk + g), fq[kk], sc);
-                    dp = mfma16(row_frag(sV, 16 * t + li, 4 * kk + g), fdo[kk], dp);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = fast_exp2(__builtin_fmaf(sc[r], c, nl2));
-                    if (t == NKT - 1 && 192 + 4 * g + r >= NTOK) p = 0.f;      // keys past 197 (zero rows of K, V)
-                    ds[half][r] = p * (dp[r] - dl);
-                }
-            }
-            // the 1/sqrt(d) factor is applied to the 16 dQ outputs instead of the scores
-            const bf16x8 pf = pack_p(ds[0], ds[1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(tr_frag(sK, ks, dt, g, li), pf, o[dt]);
-        }
-        fq[0] = fq_next[0]; fq[1] = fq_next[1]; fdo[0] = fdo_next[0]; fdo[1] = fdo_next[1];
-        fo[0] = fo_next[0]; fo[1] = fo_next[1];
-        if (q < NTOK) {
-            bf16* orow = dqkv + ((size_t)f * NTOK + q) * lddq + h * HD + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                bf16x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (bf16)(o[dt][r] * scale);
-                *(bf16x4*)(orow + 16 * dt) = v;
-            }
-            if (g == 0) delta[((size_t)f * NH + h) * NTOK + q] = dl;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ backward, dK / dV
-// Key on the lane: S = Q K^T and dP = dO V^T put P / dS in exactly the B-operand layout of
-// dV^T = dO^T P and dK^T = Q^T dS (sum over queries).  Each wave owns key tiles {w, w+4, ...} and
-// sweeps the 7 query k-steps; Q and dO of the head live in LDS (row + transposed reads).
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
-                                                           const float* lse, const float* delta, bf16* dqkv,
-                                                           long lddq, float scale) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sQ = smem;
-    char* sO = smem + MAT_BYTES;
-    float* sL = (float*)(smem + 2 * MAT_BYTES);     // lse * log2e   [224]
-    float* sD = sL + TILE_ROWS;                     // delta         [224]
-    const int h = blockIdx.x, f = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
-    const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
-    const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
-    stage_matrix512(sQ, base, ldq, tid);
-    stage_matrix512(sO, dob, ldo, tid);
-    if (tid < TILE_ROWS) {
-        bool ok = tid < NTOK;
-        size_t idx = ((size_t)f * NH + h) * NTOK + tid;
-        sL[tid] = ok ? lse[idx] * LOG2E : INFINITY;     // exp2(-inf) = 0 for pad queries
-        sD[tid] = ok ? delta[idx] : 0.f;
-    }
-    __syncthreads();
-    const float c = scale * LOG2E;
-    for (int kt = wid; kt < NKT; kt += 8) {
-        const int key = kt * 16 + li;
-        bf16x8 fk[2], fv[2];
-        load_q_frags(base + DM, ldq, key, g, fk);
-        load_q_frags(base + 2 * DM, ldq, key, g, fv);
-        f32x4 dk[4], dv[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
-#pragma unroll 1
-        for (int qs = 0; qs < NKS; ++qs) {
-            f32x4 p[2], ds[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int qrow = 32 * qs + 16 * u;          // query tile base; lane holds q = qrow + 4 g + r
-                f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    a = mfma16(row_frag(sQ, qrow + li, 4 * ks + g), fk[ks], a);     // S[q][key]
-                    b = mfma16(row_frag(sO, qrow + li, 4 * ks + g), fv[ks], b);     // dP[q][key]
-                }
-                f32x4 l4 = *(const f32x4*)(sL + qrow + 4 * g);
-                f32x4 d4 = *(const f32x4*)(sD + qrow + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float pv = fast_exp2(__builtin_fmaf(a[r], c, -l4[r]));
-                    p[u][r] = pv;
-                    ds[u][r] = pv * (b[r] - d4[r]);                 // x scale at the dK store
-                }
-            }
-            bf16x8 pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = mfma16(tr_frag(sO, qs, dt, g, li), pf, dv[dt]);            // dV^T[d][key]
-                dk[dt] = mfma16(tr_frag(sQ, qs, dt, g, li), dsf, dk[dt]);           // dK^T[d][key]
-            }
-        }
-        if (key < NTOK) {
-            bf16* krow = dqkv + ((size_t)f * NTOK + key) * lddq + DM + h * HD + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                bf16x4 a, b;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { a[r] = (bf16)(dk[dt][r] * scale); b[r] = (bf16)dv[dt][r]; }
-                *(bf16x4*)(krow + 16 * dt) = a;
-                *(bf16x4*)(krow + DM + 16 * dt) = b;
             }
         }
     }
@@ -473,7 +298,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
 }
 
 constexpr int FWD_LDS = 2 * MAT_BYTES;
-constexpr int DKV_LDS = 2 * MAT_BYTES + 2 * TILE_ROWS * 4;
 
 // raise the dynamic-LDS limit of a kernel once per process and device (not per call: keeps the launch
 // path free of runtime-API calls so it can be captured into a hipGraph); the limit only ever grows.
@@ -504,22 +328,14 @@ extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, 
                                  const float* lse, float* delta_ws, int frames, void* dqkv, long lddqkv,
                                  void* stream) {
     SAIS_ENTER();
-    if (!qkv || !dout || !out || !lse || !delta_ws || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) ||
+    (void)delta_ws;      // the single-pass kernel computes delta = rowsum(dO * O) while staging; kept in the ABI
+    if (!qkv || !dout || !out || !lse || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) ||
         (ldout & 7) || (lddqkv & 3))
         return SAIS_ERR_ARG;
-#ifndef SAIS_ATTN_BWD_TWO_PASS
     if (set_lds(attn_bwd_kernel, BWD_LDS)) return SAIS_ERR_LAUNCH;
     const int nprob = frames * NH;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(nprob < 256 ? nprob : 256), dim3(1024), BWD_LDS, (hipStream_t)stream,
                        (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, nprob,
                        (bf16*)dqkv, lddqkv, 0.125f);
-    return sais_check_launch();
-#endif
-    if (set_lds(attn_bwd_dq_kernel, FWD_LDS) || set_lds(attn_bwd_dkv_kernel, DKV_LDS)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(NH, frames), dim3(512), FWD_LDS, (hipStream_t)stream,
-                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, delta_ws,
-                       (bf16*)dqkv, lddqkv, 0.125f);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(NH, frames), dim3(512), DKV_LDS, (hipStream_t)stream,
-                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, lse, delta_ws, (bf16*)dqkv, lddqkv, 0.125f);
     return sais_check_launch();
 }
