@@ -184,3 +184,23 @@ def test_window_sampler_and_tta_indices_follow_the_reference_quirks():
     assert [tuple(t.shape) for t in c["x"]] == [(2, 1, 15, 384), (2, 1, 12, 384), (2, 1, 9, 384)]
     assert tuple(c["xpad"][0].shape) == (2, 1, 16) and not c["xpad"][0].any()
     assert c["flens"][0] == [2, 2] and tuple(c["f"][0].shape) == (2, 1, 2, 384)
+
+
+def test_window_sampler_matches_the_reference_dataset(golden):
+    """Frame / flow-row indices of every Custom_inference window and TTA version vs tests/golden/sampler.npz, which
+    was produced by the reference's own VideoDataset.__getitem__ (make_golden_sampler.py)."""
+    import numpy as np
+    from sais_amd.inference import gesture_windows, sample_window
+    g = golden("sampler")
+    for name, n in (("n512", 512), ("n77", 77), ("n45", 45), ("n15", 15)):
+        nflow = max(n // 15, 1)
+        rgb = torch.arange(float(n)).view(n, 1).repeat(1, 384)
+        flow = torch.arange(float(nflow)).view(nflow, 1).repeat(1, 384)
+        wins = gesture_windows(n)
+        assert len(wins) == int(g[name + "/nwindows"])
+        for w, (s, e) in enumerate(wins):
+            xs, fs = sample_window(rgb, flow, s, e)
+            for v in range(3):
+                assert np.array_equal(xs[v][0, :, 0].numpy().astype(np.int64), g[f"{name}/w{w}/rgb{v}"]), (name, w, v)
+                assert np.array_equal(fs[v][0, :, 0].numpy().astype(np.int64), g[f"{name}/w{w}/flow{v}"]), (name, w, v)
+            assert xs[0].shape[1] == int(g[f"{name}/w{w}/imp_len"])
