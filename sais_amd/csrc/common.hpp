@@ -56,34 +56,65 @@ DEVINL float wave_max(float v) {
 
 // exact-erf GELU (nn.GELU(), vision_transformer.py:49-65) without libm's erff: Abramowitz-Stegun 7.1.26,
 //   erf(x) = 1 - (a1 t + ... + a5 t^5) exp(-x^2),  t = 1/(1 + p x),  |error| <= 1.5e-7  (x >= 0, odd extension)
-// = 1 rcp + 1 exp + ~10 FMA per element, and exp(-x^2) = exp(-u^2/2) is shared with the Gaussian pdf of GELU'.
-DEVINL void erf_parts(float u, float& erf_abs, float& e) {      // erf(|u|/sqrt2), exp(-u^2/2)
-    const float x = fabsf(u) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
-    e = __expf(-x * x);
-    float pl = fmaf(1.061405429f, t, -1.453152027f);
-    pl = fmaf(pl, t, 1.421413741f);
-    pl = fmaf(pl, t, -0.284496736f);
-    pl = fmaf(pl, t, 0.254829592f);
-    erf_abs = fmaf(-pl * t, e, 1.0f);
+// and exp(-x^2) = exp(-u^2/2) is shared with the Gaussian pdf of GELU'.  The epilogue of the fc1 GEMM evaluates this
+// 77 M times per launch, which is VALU time no MFMA hides (all waves of a workgroup are in the epilogue together), so
+// the arithmetic is kept to 1 v_rcp_f32 + 1 v_exp_f32 (quarter rate) + packed-fp32 FMAs on PAIRS of elements:
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence, exp2 with log2(e) folded into the argument scale.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVINL void erf_parts2(f32x2 u, f32x2& erf_abs, f32x2& e) {     // erf(|u|/sqrt2), exp(-u^2/2) of two elements
+    const f32x2 au = {fabsf(u.x), fabsf(u.y)};
+    const f32x2 d = au * 0.23164189f + 1.0f;                    // 1 + p |u| / sqrt2,  p = 0.3275911
+    const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2 z = (u * -0.72134752f) * u;                     // -u^2/2 * log2(e)
+    e = f32x2{__builtin_amdgcn_exp2f(z.x), __builtin_amdgcn_exp2f(z.y)};
+    f32x2 pl = t * 1.061405429f + -1.453152027f;
+    pl = pl * t + 1.421413741f;
+    pl = pl * t + -0.284496736f;
+    pl = pl * t + 0.254829592f;
+    erf_abs = 1.0f - (pl * t) * e;
 }
-DEVINL float gelu_erf(float u) {
-    float ea, e;
-    erf_parts(u, ea, e);
-    return 0.5f * u * (1.0f + copysignf(ea, u));
+DEVINL f32x2 cdf2(f32x2 u, f32x2 erf_abs) {                     // 0.5 (1 + sign(u) erf(|u|/sqrt2))
+    const f32x2 s = {copysignf(0.5f, u.x), copysignf(0.5f, u.y)};
+    return erf_abs * s + 0.5f;
+}
+DEVINL void gelu_erf2(f32x2 u, f32x2& y) {
+    f32x2 ea, e;
+    erf_parts2(u, ea, e);
+    y = u * cdf2(u, ea);
+}
+DEVINL void dgelu_erf2(f32x2 u, f32x2& dy) {
+    f32x2 ea, e;
+    erf_parts2(u, ea, e);
+    dy = (u * 0.3989422804014327f) * e + cdf2(u, ea);
+}
+DEVINL void gelu_and_grad2(f32x2 u, f32x2& y, f32x2& dy) {      // both from one erf/exp evaluation
+    f32x2 ea, e;
+    erf_parts2(u, ea, e);
+    const f32x2 cdf = cdf2(u, ea);
+    y = u * cdf;
+    dy = (u * 0.3989422804014327f) * e + cdf;
+}
+// in-place forms over an even-length register array
+template <int N> DEVINL void gelu_erf_n(float (&y)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+        f32x2 o;
+        gelu_erf2(f32x2{y[i], y[i + 1]}, o);
+        y[i] = o.x, y[i + 1] = o.y;
+    }
+}
+template <int N> DEVINL void gelu_and_grad_n(float (&y)[N], float (&d)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+        f32x2 o, g;
+        gelu_and_grad2(f32x2{y[i], y[i + 1]}, o, g);
+        y[i] = o.x, y[i + 1] = o.y, d[i] = g.x, d[i + 1] = g.y;
+    }
 }
 DEVINL float dgelu_erf(float u) {
-    float ea, e;
-    erf_parts(u, ea, e);
-    return fmaf(u * 0.3989422804014327f, e, 0.5f * (1.0f + copysignf(ea, u)));
-}
-
-DEVINL void gelu_and_grad(float u, float& y, float& dy) {      // both from one erf/exp evaluation
-    float ea, e;
-    erf_parts(u, ea, e);
-    const float cdf = 0.5f * (1.0f + copysignf(ea, u));
-    y = u * cdf;
-    dy = fmaf(u * 0.3989422804014327f, e, cdf);
+    f32x2 g;
+    dgelu_erf2(f32x2{u, u}, g);
+    return g.x;
 }
 
 // ---- shared by the GEMM kernels (gemm.hip, gemm_row.hip) --------------------------------------------------------

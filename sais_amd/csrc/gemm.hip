@@ -100,13 +100,11 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16], cons
             if (p.out2) store_bf16(p.out2, p.ldo2, y);
     } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
         if (p.out2) store_bf16(p.out2, p.ldo2, y);          // pre-activation u (training)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) y[i] = gelu_erf(y[i]);
+        gelu_erf_n(y);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) {
         float d[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) gelu_and_grad(y[i], y[i], d[i]);
+        gelu_and_grad_n(y, d);
         store_bf16(p.out2, p.ldo2, d);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
@@ -115,7 +113,11 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16], cons
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) y[i] *= dgelu_erf((float)a.u[mt][i >> 3][i & 7]);
+        for (int i = 0; i < 16; i += 2) {
+            f32x2 g;
+            dgelu_erf2(f32x2{(float)a.u[mt][i >> 3][i & 7], (float)a.u[mt][i >> 3][(i & 7) + 1]}, g);
+            y[i] *= g.x, y[i + 1] *= g.y;
+        }
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DRELU_BF16) {
 #pragma unroll
@@ -848,6 +850,142 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
         }
 }
 
+
+// Ping-pong schedule of the wide dW kernel.  Same tile (128 x 384), same LDS image, same register staging; what changes
+// is WHEN each wave does what.  In gemm_tn_wide_kernel all eight waves read fragments together, run their 48 MFMAs
+// together and meet at one barrier per step, so the MFMA pipe of a SIMD idles while both of its waves are in the LDS
+// phase (PMC: MFMA busy 39 %).  Here a step is four barrier intervals per wave,
+//     R0: fragments of k-half 0 + first half of the next tile's LDS writes / global loads
+//     M0: 24 MFMAs          R1: fragments of k-half 1 + second half of the writes / loads          M1: 24 MFMAs
+// and the waves 4-7 (the SIMD partners of 0-3) run ONE INTERVAL BEHIND (one extra barrier before the loop, the other
+// group takes it after): in every interval one wave of each SIMD owns the MFMA pipe while its partner is in the LDS.
+// Hazards (intervals numbered globally; group A's step s is 4s..4s+3, group B's 4s+1..4s+4): tile s+1 is written into
+// buffer (s+1)&1 during 4s..4s+3 and first read in 4s+4; the old contents (tile s-1) were last read in 4s-2 (A) and
+// 4s-1 (B), and every R interval ends with lgkmcnt(0) BEFORE its barrier, so those reads have returned.
+__global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
+    extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wg / gp.ntiles;
+    int t = wg - split * gp.ntiles, it0 = 0;
+    while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;
+    if (it0 > 0) t -= gp.tile_end[it0 - 1];
+    const TnParams& p = gp.item[it0];
+    const int nt2 = p.N2 / WQ;
+    const int n1_0 = (t / nt2) * 128, n2_0 = (t % nt2) * WQ;
+    const int mbeg = split * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    if (mbeg >= mend) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
+    const int blk = wid >> 1;
+    const bf16* src0 = blk == 0 ? (const bf16*)p.P + n1_0 : (const bf16*)p.Q + n2_0 + (blk - 1) * 128;
+    const int ld = blk == 0 ? p.ldp : p.ldq;
+    const bf16* pbase = src0 + (size_t)(mbeg + 32 * (wid & 1) + (lane >> 4)) * ld + (lane & 15) * 8;
+    const int nsteps = (mend - mbeg) / TK;
+    u32x4 stg[2][8];
+    auto gload4 = [&](int step, u32x4 (&dst)[8], int h) {
+        step = step < nsteps ? step : nsteps - 1;
+#pragma unroll
+        for (int j = 4 * h; j < 4 * h + 4; ++j) dst[j] = *(const u32x4*)(pbase + (size_t)(step * TK + 4 * j) * ld);
+    };
+    auto lwrite4 = [&](int stage, const u32x4 (&src)[8], int h) {
+        char* s = wsmem + stage * WSTAGE + blk * WBLK;
+#pragma unroll
+        for (int j = 4 * h; j < 4 * h + 4; ++j) {
+            const int r = 4 * (8 * (wid & 1) + j) + (lane >> 4), c = lane & 15;
+            *(u32x4*)(s + r * 256 + ((((c >> 1) ^ (r & 7)) << 5) | ((c & 1) << 4))) = src[j];
+        }
+    };
+    f32x4 acc[4][6];
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    }
+    const bool do_bias = p.db != nullptr && n2_0 == 0 && wc == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
+    const int q4 = li >> 2, p4 = li & 3;
+    bf16x8 fp[4], fq[6];
+    auto frags = [&](int cur, int ks) {
+        const char* sp = wsmem + cur * WSTAGE;
+        const char* sq = sp + WBLK;
+        const int row = ks * 32 + 4 * g + q4;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int cp = wr * 64 + tt * 16 + 4 * p4;
+            fp[tt] = cat4(lds_read_tr16(tr_addr(sp, row, cp)), lds_read_tr16(tr_addr(sp, row + 16, cp)));
+        }
+#pragma unroll
+        for (int tt = 0; tt < 6; ++tt) {
+            const int c = wc * 96 + tt * 16;
+            const char* qb = sq + (c >> 7) * WBLK;
+            const int cq = (c & 127) + 4 * p4;
+            fq[tt] = cat4(lds_read_tr16(tr_addr(qb, row, cq)), lds_read_tr16(tr_addr(qb, row + 16, cq)));
+        }
+    };
+    auto fence = [&] {                                            // end of an LDS interval
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma = [&] {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = mfma16(fp[i], fq[j], acc[i][j]);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accb[i] = mfma16(fp[i], ones, accb[i]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one step on buffer `cur`: stg[s] holds tile st+1 (goes to the other buffer), tile st+3 is loaded into it afterwards
+    auto step = [&](int cur, int st, u32x4 (&sreg)[8]) {
+        frags(cur, 0);
+        lwrite4(cur ^ 1, sreg, 0);
+        gload4(st + 3, sreg, 0);
+        fence();
+        mma();
+        frags(cur, 1);
+        lwrite4(cur ^ 1, sreg, 1);
+        gload4(st + 3, sreg, 1);
+        fence();
+        mma();
+    };
+    gload4(0, stg[0], 0); gload4(0, stg[0], 1);
+    gload4(1, stg[1], 0); gload4(1, stg[1], 1);
+    lwrite4(0, stg[0], 0); lwrite4(0, stg[0], 1);
+    gload4(2, stg[0], 0); gload4(2, stg[0], 1);
+    __syncthreads();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                    // waves 4-7 run one interval behind
+    for (int st = 0; st < nsteps; st += 2) {
+        step(0, st, stg[1]);
+        if (st + 1 < nsteps) step(1, st + 1, stg[0]);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n1 = n1_0 + wr * 64 + i * 16 + 4 * g + r;
+            float* row = p.dW + (size_t)n1 * p.ldw + n2_0 + wc * 96 + li;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) atomicAdd(row + j * 16, acc[i][j][r]);
+            if (do_bias && li == 0) atomicAdd(p.db + n1, accb[i][r]);
+        }
+}
+
 }  // namespace
 
 #define LAUNCH_NT(E)                                                                        \
@@ -1024,14 +1162,18 @@ extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, 
         int wrows = ((M + wns - 1) / wns + TK - 1) / TK * TK;
         wns = (M + wrows - 1) / wrows;
         for (int i = 0; i < nitems; ++i) { wg.item[i] = gp.item[i]; wg.item[i].rows_per_split = wrows; }
+#ifdef SAIS_TN_WIDE_V1
+        auto* kern = gemm_tn_wide_kernel;
+#else
+        auto* kern = gemm_tn_pp_kernel;
+#endif
         static thread_local bool lds_set = false;
         if (!lds_set) {
-            if (hipFuncSetAttribute((const void*)gemm_tn_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    2 * WSTAGE) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE) != hipSuccess)
                 return SAIS_ERR_LAUNCH;
             lds_set = true;
         }
-        hipLaunchKernelGGL(gemm_tn_wide_kernel, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg);
+        hipLaunchKernelGGL(kern, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg);
         return sais_check_launch();
     }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total * ns), dim3(256), 0, (hipStream_t)stream, gp);

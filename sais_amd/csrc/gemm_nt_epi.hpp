@@ -83,13 +83,11 @@ DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], cons
         if (p.out2) store_bf16(p.out2, p.ldo2, y);
     } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
         if (p.out2) store_bf16(p.out2, p.ldo2, y);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = gelu_erf(y[i]);
+        gelu_erf_n(y);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) {
         float d[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) gelu_and_grad(y[i], y[i], d[i]);
+        gelu_and_grad_n(y, d);
         store_bf16(p.out2, p.ldo2, d);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
@@ -98,7 +96,11 @@ DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], cons
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] *= dgelu_erf((float)a.u[mt][i]);
+        for (int i = 0; i < 8; i += 2) {
+            f32x2 g;
+            dgelu_erf2(f32x2{(float)a.u[mt][i], (float)a.u[mt][i + 1]}, g);
+            y[i] *= g.x, y[i + 1] *= g.y;
+        }
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DRELU_BF16) {
 #pragma unroll

@@ -399,10 +399,11 @@ def test_nce_loss_and_grads(ops, B, C):
     assert_close(dpro, torch.cat([pd[str(c)].grad for c in range(C)]), atol=1e-7)
 
 
-@pytest.mark.parametrize("M", [197 * 16, 197 * 64, 197 * 64 + 32])
+@pytest.mark.parametrize("M", [197 * 16, 197 * 64, 197 * 64 + 32, 197 * 256, 197 * 64 + 64])
 def test_gemm_tn_grouped_matches_individual(ops, M):
-    """The four weight-gradient GEMMs of a ViT block in one launch == four separate launches.  M = 12 608 (a whole
-    number of 64-row steps, >= 8192) takes the wide 128x384 kernel, the other two the 128x128 one."""
+    """The four weight-gradient GEMMs of a ViT block in one launch == four separate launches.  M = 12 608, 50 432 and
+    12 672 (whole numbers of 64-row steps, >= 8192; even and odd step counts per split) take the wide 128x384 kernel,
+    the other two the 128x128 one."""
     shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]
     items, refs = [], []
     for i, (n1, n2) in enumerate(shapes):
