@@ -77,6 +77,9 @@ def build(dev, B, T, C, lr):
     vit = vit_small(patch_size=16, drop_path_rate=0.0)    # constructor init (trunc-normal .02), seed 0
     vit = vit.to(dev).train()
     model = fullModel('reps', C, 'in_vs_out', 384, 'ViT', modalities='RGB').to(dev).train()
+    # train mode = the reference's: dropout 0.1 in the temporal encoder (prepare_model.py:75, train.py:59); every rank its
+    # own mask stream
+    model.dropout_seed = int(os.environ.get("RANK", "0"))
     protos = torch.nn.ParameterDict({str(c): torch.nn.Parameter(torch.rand(1, 256, device=dev)) for c in range(C)})
     opt = SGD(list(vit.parameters()) + list(model.parameters()) + list(protos.values()), lr=lr, engines=[vit, model])
     return vit, model, protos, opt
@@ -268,14 +271,17 @@ def main():
                     payload="fp32 flat gradient slices, one all-reduce per ViT block issued from the backward hooks")
     timed_loss = float(loss.detach())
 
-    # parity of the measured code path: one hipGraph replay and one eager step from the SAME weights must give the
-    # same loss (the forward has no atomics, so this is exact up to nothing)
+    # parity of the measured code path: one hipGraph replay and one eager step from the SAME weights and the same dropout
+    # RNG state must give the same loss (the forward has no atomics, so this is exact up to nothing)
     graph_check = None
     if use_graph and rank == 0:
         snap = [vit.flat.flat.clone(), model.flat.flat.clone()] + [p.detach().clone() for p in protos.values()]
+        rng_snap = None if model._rng is None else model._rng.clone()       # train-mode dropout: same masks for both runs
 
         def restore():
             with torch.no_grad():
+                if rng_snap is not None:
+                    model._rng.copy_(rng_snap)
                 vit.flat.flat.copy_(snap[0])
                 model.flat.flat.copy_(snap[1])
                 for p, s in zip(protos.values(), snap[2:]):
@@ -344,7 +350,8 @@ def main():
             "config": {"workload": f"BASELINE config 2: ViT-S/16 + 4-layer temporal encoder + SupCon prototype loss, "
                                    f"fwd+bwd+SGD, {B} clips x {T} frames x 224x224 per GPU (global {world * B} clips), "
                                    f"random-init weights, RGB stream", "clips_per_gpu": B, "frames_per_clip": T,
-                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager"},
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
+                       "temporal_dropout": model.dropout_p},
             "step_tflops": round(step_flops * world * args.steps / dt / 1e12, 1),
             "frac_of_mfma_roofline": round(step_flops * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "loss": round(timed_loss, 6),

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 2
+#define SAIS_ABI_VERSION 3
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -204,9 +204,23 @@ int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf16 /*optiona
 #define SAIS_TEMPORAL_MAX_S_FWD 96
 #define SAIS_TEMPORAL_MAX_S_BWD 64
 int sais_temporal_attn_fwd(const float* qkv /*[B*S,1152]*/, const unsigned char* key_pad /*[B,S]*/, int B, int S,
-                           float* ctx /*[B*S,384]*/, float* attn_avg, void* stream);
+                           float* ctx /*[B*S,384]*/, float* attn_avg, float p_drop, const unsigned long long* rng_state,
+                           unsigned site, void* stream);
 int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B, int S, const float* dctx,
-                           float* dqkv, void* stream);
+                           float* dqkv /*[B*S,1152]*/, float p_drop, const unsigned long long* rng_state, unsigned site,
+                           void* stream);
+/* Train mode (model.train(), train.py:59): nn.TransformerEncoderLayer's default dropout = 0.1 (prepare_model.py:75) acts at
+ * four sites per layer: on the attention weights (p_drop above: after the softmax, before P v; the returned map is the
+ * dropped one, as in torch 1.8), after out_proj (dropout1), after the ReLU (dropout) and after linear2 (dropout2).
+ * Masks come from Philox4x32-10 keyed by rng_state = {seed, offset} in DEVICE memory (graph replays draw fresh masks:
+ * sais_rng_advance is a graph node), the site id and the element index; forward and backward regenerate them, nothing is
+ * stored.  sais_dropout_f32: out = (resid ? resid : 0) + x * keep / (1 - p) (out may alias x); applied to a gradient with
+ * the same (state, site) it is the backward of itself.  sais_dropout_mask exports the keep mask (tests feed it to the oracle).
+ * The stream of numbers is this library's, not torch's: a torch run with the same seed draws different masks.            */
+int sais_rng_advance(unsigned long long* state /*{seed, offset}*/, void* stream);
+int sais_dropout_f32(const float* x, const float* resid /*optional*/, float* out, long n, float p,
+                     const unsigned long long* rng_state, unsigned site, void* stream);
+int sais_dropout_mask(unsigned char* mask, long n, float p, const unsigned long long* rng_state, unsigned site, void* stream);
 
 /* ---------------------------------------------------------------- head + SupCon / prototype loss
  * fullModel.forward Prototypes branch, prepare_model.py:215,220,381-416:

@@ -107,45 +107,53 @@ def temporal_prepare(sd, x):
     return torch.cat((cls, x), dim=2)                                                  # [B,ns,T+1,D]
 
 
-def temporal_layer(sd, pre, x, key_pad, heads=T_HEADS):
-    """torch-1.8 post-norm TransformerEncoderLayer in eval mode (dropout = identity) with the
-    README.md:43-48 edit that returns the head-averaged attention map.
-    x [Bn,S,D] (batch-first here; the reference feeds [S,Bn,D] — same math), key_pad bool [Bn,S]."""
+def temporal_layer(sd, pre, x, key_pad, heads=T_HEADS, drop=None, p=0.1):
+    """torch-1.8 post-norm TransformerEncoderLayer with the README.md:43-48 edit that returns the head-averaged
+    attention map.  x [Bn,S,D] (batch-first here; the reference feeds [S,Bn,D] — same math), key_pad bool [Bn,S].
+    drop = None: eval mode (dropout = identity).  drop = {attn [Bn,h,S,S], d1 [Bn,S,D], ff [Bn,S,FF], d2 [Bn,S,D]} keep
+    masks: train mode (model.train(), train.py:59) of the layer prepare_model.py:75 builds with torch's default
+    dropout p = 0.1 — nn.MultiheadAttention drops the softmaxed weights before P v and RETURNS the dropped weights
+    (F.multi_head_attention_forward), then src + dropout1(attn), linear2(dropout(relu(linear1))) and src + dropout2(ff).
+    The masks are inputs because the RNG stream is the framework's, not part of the algorithm."""
     Bn, S, D = x.shape
     hd = D // heads
+    dm = (lambda t, k: t * drop[k].to(t.dtype) / (1.0 - p)) if drop is not None else (lambda t, k: t)
     qkv = F.linear(x, sd[pre + "self_attn.in_proj_weight"], sd[pre + "self_attn.in_proj_bias"])
     q, k, v = qkv.reshape(Bn, S, 3, heads, hd).permute(2, 0, 3, 1, 4)                  # [Bn,h,S,hd]
     scores = (q * hd ** -0.5) @ k.transpose(-2, -1)
     scores = scores.masked_fill(key_pad.view(Bn, 1, 1, S), float("-inf"))
-    probs = scores.softmax(dim=-1)
+    probs = dm(scores.softmax(dim=-1), "attn")
     ctx = (probs @ v).transpose(1, 2).reshape(Bn, S, D)
     a = F.linear(ctx, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"])
-    x = F.layer_norm(x + a, (D,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
-    ff = F.linear(F.relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])),
+    x = F.layer_norm(x + dm(a, "d1"), (D,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
+    ff = F.linear(dm(F.relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])), "ff"),
                   sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
-    x = F.layer_norm(x + ff, (D,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
+    x = F.layer_norm(x + dm(ff, "d2"), (D,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
     return x, probs.mean(dim=1)
 
 
-def temporal_aggregate(sd, seq, pad, nlayers=4, trace=None):
+def temporal_aggregate(sd, seq, pad, nlayers=4, trace=None, drop=None, p=0.1):
     """aggregateInputs — prepare_model.py:197-221.  seq [B,ns,S,D], pad bool [B,ns,S].
-    Returns (full relu'd sequence [B,ns,S,D], CLS rows [B,ns,D], attn of LAST layer [B*ns,S,S])."""
+    Returns (full relu'd sequence [B,ns,S,D], CLS rows [B,ns,D], attn of LAST layer [B*ns,S,S]).
+    drop: per-layer keep masks (temporal_layer) for train mode."""
     B, ns, S, D = seq.shape
     x = seq.reshape(B * ns, S, D)
     kp = pad.reshape(B * ns, S)
     attn = None
     for l in range(nlayers):
-        x, attn = temporal_layer(sd, f"transEncoderFrame.layers.{l}.", x, kp)
+        x, attn = temporal_layer(sd, f"transEncoderFrame.layers.{l}.", x, kp, drop=None if drop is None else drop[l], p=p)
         if trace is not None:
             trace.append(x)
     full = F.relu(x).reshape(B, ns, S, D)
     return full, full[:, :, 0, :], attn
 
 
-def temporal_forward(sd, x, f, xpad, fpad, modalities="RGB-Flow", nlayers=4, importance=False, trace=None):
+def temporal_forward(sd, x, f, xpad, fpad, modalities="RGB-Flow", nlayers=4, importance=False, trace=None, drop=None,
+                     p=0.1):
     """fullModel.forward, data_type='reps', encoder 'ViT', task 'Prototypes', self_attention
     — prepare_model.py:246-448.  Tensor inputs -> (emb [B,256], attn [B*ns,S,S]); list inputs
-    (test-time augmentation, :331-346) -> (list of embs, attn of version 0)."""
+    (test-time augmentation, :331-346) -> (list of embs, attn of version 0).
+    drop = {"rgb": [per-layer masks], "flow": [...]}: train mode with these dropout keep masks (temporal_layer)."""
     if isinstance(x, (list, tuple)):
         embs, attn0 = [], None
         for v in range(len(x)):
@@ -156,10 +164,12 @@ def temporal_forward(sd, x, f, xpad, fpad, modalities="RGB-Flow", nlayers=4, imp
         return embs, attn0
     full = None
     if modalities in ("RGB", "RGB-Flow"):
-        full, rgb, attn = temporal_aggregate(sd, temporal_prepare(sd, x), xpad, nlayers, trace)
+        full, rgb, attn = temporal_aggregate(sd, temporal_prepare(sd, x), xpad, nlayers, trace,
+                                             drop=None if drop is None else drop.get("rgb"), p=p)
         rep = rgb.mean(dim=1)
     if modalities in ("Flow", "RGB-Flow"):
-        ffull, flow, fattn = temporal_aggregate(sd, temporal_prepare(sd, f), fpad, nlayers)
+        ffull, flow, fattn = temporal_aggregate(sd, temporal_prepare(sd, f), fpad, nlayers,
+                                                drop=None if drop is None else drop.get("flow"), p=p)
         if modalities == "Flow":
             rep, attn, full = flow.mean(dim=1), fattn, ffull
         else:

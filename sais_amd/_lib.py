@@ -78,8 +78,11 @@ SIGNATURES = {
                                   c_void_p],
     "sais_temporal_prepare_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_long, c_long, c_int, c_void_p,
                                   c_void_p, c_void_p],
-    "sais_temporal_attn_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
-    "sais_temporal_attn_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sais_temporal_attn_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
+    "sais_temporal_attn_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
+    "sais_rng_advance": [c_void_p, c_void_p],
+    "sais_dropout_f32": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p, ctypes.c_uint, c_void_p],
+    "sais_dropout_mask": [c_void_p, c_long, c_float, c_void_p, ctypes.c_uint, c_void_p],
     "sais_head_fwd": [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sais_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p,
                       c_void_p, c_void_p, c_void_p],

@@ -1,5 +1,6 @@
 // Small HBM-bound helpers of the SAIS hot path (gfx950): patch gather, CLS rows, SGD, weight shadows.
 #include "common.hpp"
+#include "philox.hpp"
 #include "../../include/sais_hip.h"
 
 namespace {
@@ -176,6 +177,27 @@ __global__ void scale_kernel(float* p, long n, float s) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= s;
 }
 
+// out = (resid ? resid : 0) + x * keep / (1 - p): nn.Dropout in train mode, optionally with the residual add that follows it
+// in the post-norm TransformerEncoderLayer (src + dropout1(src2)).  out may alias x.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* x, const float* resid, float* out, long n, float p,
+                                                      const unsigned long long* rng, unsigned sid) {
+    const unsigned thr = drop_threshold(p);
+    const float inv = 1.0f / (1.0f - p);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = philox_keep(rng, sid, (unsigned long long)i, thr) ? x[i] * inv : 0.f;
+        out[i] = resid ? resid[i] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned char* mask, long n, float p, const unsigned long long* rng,
+                                                           unsigned sid) {
+    const unsigned thr = drop_threshold(p);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        mask[i] = philox_keep(rng, sid, (unsigned long long)i, thr) ? 1 : 0;
+}
+
+__global__ void rng_advance_kernel(unsigned long long* state) { state[1] += 1; }
+
 int grid_for(long n, int per_block = 256) {
     long b = (n + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -273,5 +295,30 @@ extern "C" int sais_scale_f32(float* p, long n, float s, void* stream) {
     SAIS_ENTER();
     if (!p || n <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, n, s);
+    return sais_check_launch();
+}
+
+// ---- train-mode dropout (philox.hpp) ---------------------------------------------------------------------------
+extern "C" int sais_rng_advance(unsigned long long* state, void* stream) {
+    SAIS_ENTER();
+    if (!state) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    return sais_check_launch();
+}
+
+extern "C" int sais_dropout_f32(const float* x, const float* resid, float* out, long n, float p,
+                                const unsigned long long* rng_state, unsigned site, void* stream) {
+    SAIS_ENTER();
+    if (!x || !out || !rng_state || n <= 0 || p < 0.f || p >= 1.f) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, resid, out, n, p, rng_state,
+                       site);
+    return sais_check_launch();
+}
+
+extern "C" int sais_dropout_mask(unsigned char* mask, long n, float p, const unsigned long long* rng_state, unsigned site,
+                                 void* stream) {
+    SAIS_ENTER();
+    if (!mask || !rng_state || n <= 0 || p < 0.f || p >= 1.f) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p, rng_state, site);
     return sais_check_launch();
 }

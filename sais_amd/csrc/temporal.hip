@@ -10,6 +10,7 @@
 //   ReLU -> CLS row -> (+flow) -> ReLU -> Linear(384->256)   prepare_model.py:215,220,381-416 (sais_head_*)
 //   calcNCELoss / getProbs      prepare_miscellaneous.py:14-46,111-126   (sais_nce_*)
 #include "common.hpp"
+#include "philox.hpp"
 #include "../../include/sais_hip.h"
 
 namespace {
@@ -97,8 +98,12 @@ DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad
     __syncthreads();
 }
 
+// Train mode (p > 0): the attention weights are dropped AFTER the softmax and BEFORE P v, and the returned map is the
+// dropped one (torch-1.8 F.multi_head_attention_forward: softmax -> dropout -> bmm; the weights it returns are the
+// dropped ones).  Mask element index: ((b * 4 + h) * S + i) * S + j.
 __global__ __launch_bounds__(1024) void tattn_fwd_kernel(const float* qkv, const unsigned char* key_pad, int S, float* ctx,
-                                                        float* attn_avg) {
+                                                        float* attn_avg, float p_drop, const unsigned long long* rng,
+                                                        unsigned sid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = (float*)smem;
     float* sK = sQ + S * QS;
@@ -110,6 +115,16 @@ __global__ __launch_bounds__(1024) void tattn_fwd_kernel(const float* qkv, const
     load_head(qkv, b, h, S, 2, sV, tid, nt);
     __syncthreads();
     probs_lds(sQ, sK, key_pad + (size_t)b * S, S, 0.10206207261596577f /* 96^-0.5 */, sP, tid, nt);
+    if (p_drop > 0.f) {
+        const unsigned thr = drop_threshold(p_drop);
+        const float inv = 1.0f / (1.0f - p_drop);
+        const unsigned long long base = ((unsigned long long)b * TH + h) * S * S;
+        for (int idx = tid; idx < S * S; idx += nt) {
+            float& v = sP[(idx / S) * SP + idx % S];
+            v = philox_keep(rng, sid, base + idx, thr) ? v * inv : 0.f;
+        }
+        __syncthreads();
+    }
     if (attn_avg)
         for (int idx = tid; idx < S * S; idx += nt)
             atomicAdd(attn_avg + (size_t)b * S * S + idx, sP[(idx / S) * SP + idx % S] * (1.0f / TH));
@@ -121,8 +136,11 @@ __global__ __launch_bounds__(1024) void tattn_fwd_kernel(const float* qkv, const
     }
 }
 
+// With dropout: ctx = P' v, P' = P m / (1 - p).  dV = P'^T dctx; dP = (dctx v^T) m / (1 - p); dS = P (dP - rowsum(P dP)).
+// The mask is regenerated from (rng, sid) and kept in the SIGN BIT of the stored P (P >= 0): negative = dropped.
 __global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const unsigned char* key_pad, int S,
-                                                        const float* dctx, float* dqkv) {
+                                                        const float* dctx, float* dqkv, float p_drop,
+                                                        const unsigned long long* rng, unsigned sid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = (float*)smem;
     float* sK = sQ + S * QS;
@@ -143,28 +161,42 @@ __global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const
     }
     __syncthreads();
     probs_lds(sQ, sK, key_pad + (size_t)b * S, S, scale, sP, tid, nt);
-    // dV[j][d] = sum_i P[i][j] dctx[i][d]
+    const float inv = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    if (p_drop > 0.f) {
+        const unsigned thr = drop_threshold(p_drop);
+        const unsigned long long base = ((unsigned long long)b * TH + h) * S * S;
+        for (int idx = tid; idx < S * S; idx += nt) {
+            float& v = sP[(idx / S) * SP + idx % S];
+            if (!philox_keep(rng, sid, base + idx, thr)) v = -v;          // -0.0f for P == 0: the sign bit is the flag
+        }
+        __syncthreads();
+    }
+    auto kept = [](float pv) { return !__builtin_signbit(pv); };
+    // dV[j][d] = sum_i P'[i][j] dctx[i][d]
     for (int idx = tid; idx < S * THD; idx += nt) {
         int j = idx / THD, d = idx % THD;
         float a = 0.f;
-        for (int i = 0; i < S; ++i) a += sP[i * SP + j] * sG[i * QS + d];
+        for (int i = 0; i < S; ++i) {
+            const float pv = sP[i * SP + j];
+            a += (kept(pv) ? pv * inv : 0.f) * sG[i * QS + d];
+        }
         dqkv[((size_t)b * S + j) * (3 * D) + 2 * D + h * THD + d] = a;
     }
-    // dP[i][j] = dctx_i . v_j
+    // dP[i][j] = (dctx_i . v_j) m / (1 - p)
     for (int idx = tid; idx < S * S; idx += nt) {
         int i = idx / S, j = idx % S;
         float a = 0.f;
 #pragma unroll 8
         for (int d = 0; d < THD; ++d) a += sG[i * QS + d] * sV[j * QS + d];
-        sS[i * SP + j] = a;
+        sS[i * SP + j] = kept(sP[i * SP + j]) ? a * inv : 0.f;
     }
     __syncthreads();
     const int lane = tid & 63, w = tid >> 6;
     for (int i = w; i < S; i += nt >> 6) {
         float dot = 0.f;
-        for (int j = lane; j < S; j += 64) dot += sP[i * SP + j] * sS[i * SP + j];
+        for (int j = lane; j < S; j += 64) dot += fabsf(sP[i * SP + j]) * sS[i * SP + j];
         dot = wave_sum(dot);
-        for (int j = lane; j < S; j += 64) sS[i * SP + j] = sP[i * SP + j] * (sS[i * SP + j] - dot) * scale;
+        for (int j = lane; j < S; j += 64) sS[i * SP + j] = fabsf(sP[i * SP + j]) * (sS[i * SP + j] - dot) * scale;
     }
     __syncthreads();
     for (int idx = tid; idx < S * THD; idx += nt) {
@@ -424,25 +456,31 @@ extern "C" int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf1
 }
 
 extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key_pad, int B, int S, float* ctx,
-                                      float* attn_avg, void* stream) {
+                                      float* attn_avg, float p_drop, const unsigned long long* rng_state,
+                                      unsigned site, void* stream) {
     SAIS_ENTER();
     if (!qkv || !key_pad || !ctx || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_FWD) return SAIS_ERR_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !rng_state)) return SAIS_ERR_ARG;
     int lds = (3 * S * QS + S * (S + 1)) * 4;
     if (set_lds(tattn_fwd_kernel, lds)) return SAIS_ERR_LAUNCH;
     hipStream_t s = (hipStream_t)stream;
     if (attn_avg && hipMemsetAsync(attn_avg, 0, (size_t)B * S * S * 4, s) != hipSuccess) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(1024), lds, s, qkv, key_pad, S, ctx, attn_avg);
+    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(1024), lds, s, qkv, key_pad, S, ctx, attn_avg, p_drop, rng_state,
+                       site);
     return sais_check_launch();
 }
 
 extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B, int S,
-                                      const float* dctx, float* dqkv, void* stream) {
+                                      const float* dctx, float* dqkv, float p_drop,
+                                      const unsigned long long* rng_state, unsigned site, void* stream) {
     SAIS_ENTER();
     if (!qkv || !key_pad || !dctx || !dqkv || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_BWD)
         return SAIS_ERR_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !rng_state)) return SAIS_ERR_ARG;
     int lds = (4 * S * QS + 2 * S * (S + 1)) * 4;
     if (set_lds(tattn_bwd_kernel, lds)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(1024), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, dqkv);
+    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(1024), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, dqkv,
+                       p_drop, rng_state, site);
     return sais_check_launch();
 }
 

@@ -269,12 +269,38 @@ def temporal_prepare_bwd(dz32, dz16, B, T, dx, clip_stride, frame_stride, accumu
            1 if accumulate else 0, _p(dpos), _p(dcls), _stream())
 
 
-def temporal_attn_fwd(qkv, key_pad_u8, B, S, ctx, attn_avg=None):
-    L.call("sais_temporal_attn_fwd", _p(qkv), _p(key_pad_u8), B, S, _p(ctx), _p(attn_avg), _stream())
+def temporal_attn_fwd(qkv, key_pad_u8, B, S, ctx, attn_avg=None, p_drop=0.0, rng=None, site=0):
+    L.call("sais_temporal_attn_fwd", _p(qkv), _p(key_pad_u8), B, S, _p(ctx), _p(attn_avg), float(p_drop), _p(rng), site,
+           _stream())
 
 
-def temporal_attn_bwd(qkv, key_pad_u8, B, S, dctx, dqkv):
-    L.call("sais_temporal_attn_bwd", _p(qkv), _p(key_pad_u8), B, S, _p(dctx), _p(dqkv), _stream())
+def temporal_attn_bwd(qkv, key_pad_u8, B, S, dctx, dqkv, p_drop=0.0, rng=None, site=0):
+    L.call("sais_temporal_attn_bwd", _p(qkv), _p(key_pad_u8), B, S, _p(dctx), _p(dqkv), float(p_drop), _p(rng), site,
+           _stream())
+
+
+# ---- train-mode dropout: rng = int64 device tensor {seed, offset} (include/sais_hip.h)
+def rng_state(seed, device):
+    return torch.tensor([int(seed), 0], dtype=torch.int64, device=device)
+
+
+def rng_advance(rng):
+    L.call("sais_rng_advance", _p(rng), _stream())
+
+
+def dropout(x, p, rng, site, resid=None, out=None):
+    """out = (resid or 0) + x * keep / (1 - p); in place on x unless `out` is given.  Applying it to a gradient with the
+    same (rng, site) is its backward."""
+    _chk(x, F32, "x"); _chk(resid, F32, "resid")
+    out = x if out is None else out
+    L.call("sais_dropout_f32", _p(x), _p(resid), _p(out), x.numel(), float(p), _p(rng), site, _stream())
+    return out
+
+
+def dropout_mask(n, p, rng, site, device):
+    m = torch.empty(n, dtype=torch.uint8, device=device)
+    L.call("sais_dropout_mask", _p(m), n, float(p), _p(rng), site, _stream())
+    return m
 
 
 def head_fwd(z_rgb, z_flow, clip_stride, B, W, bias, rep, emb, clip_stride_flow=None, nsnippets=1):

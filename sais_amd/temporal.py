@@ -15,7 +15,8 @@ on the last layer) -> MFMA out_proj + residual -> LN -> MFMA linear1 + ReLU -> M
 The MFMA GEMMs here are the fp32-operand "bf16x3" variant (sais_gemm_nt_f32).
 
 Deliberate differences: inputs are never mutated (the reference does `x += pos` in place,
-:192, and `rgb += flow`, :412); dropout (p=0.1, train() only, RNG-dependent) is the identity;
+:192, and `rgb += flow`, :412); dropout (p=0.1, the nn.TransformerEncoderLayer default, train() only) is applied at its four sites per layer with
+Philox masks of this library's own stream (`dropout_p`, `dropout_seed`; `dropout_p = 0` switches it off);
 MIL / ClassificationHead / R3D / raw branches are out of scope and raise.  Inputs [B, nsnippets, T, 384]: every
 (clip, snippet) pair is one sequence of the encoder, the head averages the ReLU'd CLS rows over the snippets of a clip
 (:381-382) and the returned attention map is [B*nsnippets, T+1, T+1], as in the reference.
@@ -101,6 +102,13 @@ class fullModel(nn.Module):
         self._anchor = None
         self.grad_ready_hook = None
         self._touched_T = 0            # longest stream whose position rows received a gradient since the last exchange
+        # nn.TransformerEncoderLayer(d_model, nhead=4) keeps torch's default dropout = 0.1 (prepare_model.py:75); it acts
+        # under model.train() (train.py:59) at four sites per layer.  Masks: Philox in the kernels (sais_hip.h), the
+        # {seed, offset} state is a device tensor so graph replays draw fresh masks.
+        self.dropout_p = 0.1
+        self.dropout_seed = 0
+        self._rng = None
+        self.last_dropout_state = None
 
     # ------------------------------------------------------------------ engine plumbing
     @property
@@ -141,6 +149,17 @@ class fullModel(nn.Module):
     def sgd_step(self, lr, grad_scale=1.0):
         self.flat.sgd_step(lr, grad_scale, self._t_names())
         self._sig = self.flat.signature(self._sentinels())
+
+    def dropout_masks(self, state, Bn, S, stream=0):
+        """The keep masks a train-mode forward with RNG state `state` (= self.last_dropout_state) applied to stream 0 (RGB) /
+        1 (flow) of Bn sequences of S tokens: per layer {attn [Bn,4,S,S], d1 [Bn,S,384], ff [Bn,S,2048], d2 [Bn,S,384]},
+        bool.  For tests: the oracle applies the same masks."""
+        out, p, dev = [], float(self.dropout_p), state.device
+        for l in range(self.nlayers):
+            site = (stream * self.nlayers + l) * 4
+            m = lambda k, *sh: ops.dropout_mask(int(torch.tensor(sh).prod()), p, state, site + k, dev).view(*sh).bool()
+            out.append(dict(attn=m(0, Bn, TH, S, S), d1=m(1, Bn, S, D), ff=m(2, Bn, S, FF), d2=m(3, Bn, S, D)))
+        return out
 
     # ------------------------------------------------------------------ reference signature
     def forward(self, x, f, xlens, flens, task, xpad, fpad, domains=None):
@@ -201,7 +220,7 @@ class fullModel(nn.Module):
     # All temporal activations are fp32 in HBM (they are tiny: clips*(T+1) rows) and every nn.Linear runs
     # on sais_gemm_nt_f32 (bf16x3 split on the matrix cores): the cosine logits inherit ~fp32 accuracy
     # from this half of the path, leaving the whole 1e-3 budget to the bf16 ViT.
-    def _stream_fwd(self, x, pad, save, want_attn):
+    def _stream_fwd(self, x, pad, save, want_attn, drop=None, sidx=0):
         fl = self.flat
         dev = x.device
         x = x.reshape(x.shape[0] * x.shape[1], 1, x.shape[2], D)       # (clip, snippet) pairs are independent sequences
@@ -224,31 +243,52 @@ class fullModel(nn.Module):
                             bias=fl.w32(p + "self_attn.in_proj_bias"))
             if want_attn and last:
                 attn = e32(B, S, S)
-            ops.temporal_attn_fwd(qkv, pad, B, S, ctx, attn if last else None)
+            # train mode: dropout sites 0-3 of this layer (attention weights, dropout1, dropout, dropout2)
+            site = (sidx * self.nlayers + l) * 4
+            pd, rng = drop if drop is not None else (0.0, None)
+            ops.temporal_attn_fwd(qkv, pad, B, S, ctx, attn if last else None, p_drop=pd, rng=rng, site=site)
             y1 = e32(M, D)
-            ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_RESID_F32, y1,
-                            bias=fl.w32(p + "self_attn.out_proj.bias"), aux=z)
+            if drop is None:
+                ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_RESID_F32, y1,
+                                bias=fl.w32(p + "self_attn.out_proj.bias"), aux=z)
+            else:                                              # src + dropout1(out_proj(ctx))
+                ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_F32, y1,
+                                bias=fl.w32(p + "self_attn.out_proj.bias"))
+                ops.dropout(y1, pd, rng, site + 1, resid=z)
             z1, m1, r1 = e32(M, D), e32(M), e32(M)
             ops.layernorm_fwd(y1, M, D, fl.w32(p + "norm1.weight"), fl.w32(p + "norm1.bias"), 1e-5, y32=z1, mean=m1, rstd=r1)
             h = e32(M, FF)
             ops.gemm_nt_f32(z1, fl.w32(p + "linear1.weight"), L.EPI_BIAS_RELU_F32, h, bias=fl.w32(p + "linear1.bias"))
             y2 = e32(M, D)
-            ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_RESID_F32, y2, bias=fl.w32(p + "linear2.bias"),
-                            aux=z1)
+            if drop is None:
+                ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_RESID_F32, y2, bias=fl.w32(p + "linear2.bias"),
+                                aux=z1)
+            else:                                              # src + dropout2(linear2(dropout(relu(linear1(src)))))
+                ops.dropout(h, pd, rng, site + 2)
+                ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_F32, y2, bias=fl.w32(p + "linear2.bias"))
+                ops.dropout(y2, pd, rng, site + 3, resid=z1)
             zo, m2, r2 = e32(M, D), e32(M), e32(M)
             ops.layernorm_fwd(y2, M, D, fl.w32(p + "norm2.weight"), fl.w32(p + "norm2.bias"), 1e-5, y32=zo, mean=m2, rstd=r2)
             if save:
                 layers.append(dict(z=z, qkv=qkv, ctx=ctx, y1=y1, m1=m1, r1=r1, z1=z1, h=h, y2=y2, m2=m2, r2=r2))
             z = zo
-        return z, attn, dict(layers=layers, pad=pad, B=B, T=T, x=x) if save else None
+        return z, attn, dict(layers=layers, pad=pad, B=B, T=T, x=x, drop=drop, sidx=sidx) if save else None
 
     def _forward_kernels(self, x, f, xpad, fpad, save):
         fl = self.flat
         zr = zf = sr = sf = attn = None
+        drop = None
+        if self.training and self.dropout_p > 0:
+            dev = (x if x is not None else f).device
+            if self._rng is None or self._rng.device != dev:
+                self._rng = ops.rng_state(self.dropout_seed, dev)
+            ops.rng_advance(self._rng)                        # a graph node: every replay draws fresh masks
+            self.last_dropout_state = self._rng.clone()       # what this forward and its backward regenerate the masks from
+            drop = (float(self.dropout_p), self.last_dropout_state)
         if x is not None:
-            zr, attn, sr = self._stream_fwd(x, xpad, save, want_attn=True)
+            zr, attn, sr = self._stream_fwd(x, xpad, save, want_attn=True, drop=drop, sidx=0)
         if f is not None:
-            zf, fattn, sf = self._stream_fwd(f, fpad, save, want_attn=(x is None))
+            zf, fattn, sf = self._stream_fwd(f, fpad, save, want_attn=(x is None), drop=drop, sidx=1)
             if x is None:
                 attn = fattn
         ref = x if x is not None else f
@@ -283,24 +323,34 @@ class fullModel(nn.Module):
             dy2 = e32(M, D)
             ops.layernorm_bwd(a["y2"], D, a["m2"], a["r2"], fl.w32(p + "norm2.weight"), M, dy32=dz, dx32=dy2,
                               dgamma=fl.g(p + "norm2.weight"), dbeta=fl.g(p + "norm2.bias"))
+            # dropout backward = the same mask on the branch gradient (the residual path keeps the un-dropped one);
+            # a["h"] is the DROPPED relu output, so the drelu epilogue already zeroes the dropped units and the mask
+            # applied to dh afterwards only rescales the kept ones
+            drop = s.get("drop")
+            site = (s.get("sidx", 0) * self.nlayers + l) * 4
+            pd, rng = drop if drop is not None else (0.0, None)
+            dt2 = dy2 if drop is None else ops.dropout(dy2, pd, rng, site + 3, out=e32(M, D))
             dh = e32(M, FF)
-            ops.gemm_nt_f32(dy2, fl.wt16[p + "linear2.weight"], L.EPI_DRELU_F32, dh, aux=a["h"])
+            ops.gemm_nt_f32(dt2, fl.wt16[p + "linear2.weight"], L.EPI_DRELU_F32, dh, aux=a["h"])
+            if drop is not None:
+                ops.dropout(dh, pd, rng, site + 2)
             dz1 = e32(M, D)                                   # = dy2 (residual) + dh . W1
             ops.gemm_nt_f32(dh, fl.wt16[p + "linear1.weight"], L.EPI_BIAS_RESID_F32, dz1, aux=dy2)
             dy1 = e32(M, D)
             ops.layernorm_bwd(a["y1"], D, a["m1"], a["r1"], fl.w32(p + "norm1.weight"), M, dy32=dz1, dx32=dy1,
                               dgamma=fl.g(p + "norm1.weight"), dbeta=fl.g(p + "norm1.bias"))
+            dt1 = dy1 if drop is None else ops.dropout(dy1, pd, rng, site + 1, out=e32(M, D))
             dctx = e32(M, D)
-            ops.gemm_nt_f32(dy1, fl.wt16[p + "self_attn.out_proj.weight"], L.EPI_BIAS_F32, dctx)
+            ops.gemm_nt_f32(dt1, fl.wt16[p + "self_attn.out_proj.weight"], L.EPI_BIAS_F32, dctx)
             dqkv = e32(M, 3 * D)
-            ops.temporal_attn_bwd(a["qkv"], s["pad"], B, S, dctx, dqkv)
+            ops.temporal_attn_bwd(a["qkv"], s["pad"], B, S, dctx, dqkv, p_drop=pd, rng=rng, site=site)
             dz = e32(M, D)                                    # = dy1 (residual) + dqkv . Win
             ops.gemm_nt_f32(dqkv, fl.wt16[p + "self_attn.in_proj_weight"], L.EPI_BIAS_RESID_F32, dz, aux=dy1)
             # the four weight / bias gradients of the layer in one launch (M is a few hundred rows: launch-bound)
             ops.gemm_tn_grouped([
-                (dy2, a["h"], fl.g(p + "linear2.weight"), fl.g(p + "linear2.bias")),
+                (dt2, a["h"], fl.g(p + "linear2.weight"), fl.g(p + "linear2.bias")),
                 (dh, a["z1"], fl.g(p + "linear1.weight"), fl.g(p + "linear1.bias")),
-                (dy1, a["ctx"], fl.g(p + "self_attn.out_proj.weight"), fl.g(p + "self_attn.out_proj.bias")),
+                (dt1, a["ctx"], fl.g(p + "self_attn.out_proj.weight"), fl.g(p + "self_attn.out_proj.bias")),
                 (dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))], M, nsplit=2)
         x = s["x"]
         dx = torch.empty_like(x) if need_dx else None

@@ -480,9 +480,79 @@ def golden_outlier(vits, prepare_model, misc, out):
     print("outlier.npz: residual |x|max per block", [round(a, 1) for a in absmax], "sim", sim.numpy().round(4).tolist())
 
 
+DROPOUT_CASE = dict(lens=[9, 4, 7, 9], T=9, C=2, mask_seed=(900, 901), x_seed=(910, 911), label_seed=912, p=0.1)
+DROPOUT_GRADS = ("linear.weight", "frame_cls", "frame_pos_embeddings.0", "frame_pos_embeddings.8",
+                 "transEncoderFrame.layers.0.self_attn.in_proj_weight", "transEncoderFrame.layers.0.self_attn.in_proj_bias",
+                 "transEncoderFrame.layers.1.self_attn.out_proj.weight", "transEncoderFrame.layers.2.linear1.weight",
+                 "transEncoderFrame.layers.2.linear1.bias", "transEncoderFrame.layers.3.linear2.weight",
+                 "transEncoderFrame.layers.3.norm1.weight", "transEncoderFrame.layers.0.norm2.bias")
+
+
+def golden_dropout(prepare_model, misc, out):
+    """The reference's fullModel in TRAIN mode (train.py:59) with the dropout masks of synth.dropout_masks injected in
+    place of torch's RNG: torch.nn.functional.dropout is replaced by a function that pops the next mask, in the order
+    the layer calls it (attention weights [Bn*4,S,S], dropout1 [S,Bn,384], dropout [S,Bn,2048], dropout2 [S,Bn,384]; RGB
+    stream first, then flow).  Pins WHERE the oracle applies the masks and the 1/(1-p) scaling, forward and backward."""
+    import torch.nn.functional as Fn
+    c = DROPOUT_CASE
+    lens, T, C, p = c["lens"], c["T"], c["C"], c["p"]
+    B, S = len(lens), T + 1
+    m = build_full(prepare_model, C, "RGB-Flow")
+    m.train()
+    x, f = synth.reps(seed=c["x_seed"][0], B=B, T=T), synth.reps(seed=c["x_seed"][1], B=B, T=T)
+    for b, n in enumerate(lens):
+        x[b, :, n:] = 0
+        f[b, :, n:] = 0
+    pad = synth.padding_mask(lens)
+    queue = []
+    for sidx in range(2):
+        for lm in synth.dropout_masks(c["mask_seed"][sidx], B, S, p=p):
+            queue += [lm["attn"].reshape(B * 4, S, S), lm["d1"].transpose(0, 1), lm["ff"].transpose(0, 1), lm["d2"].transpose(0, 1)]
+    real = Fn.dropout
+
+    def fed(inp, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return inp
+        mask = queue.pop(0)
+        assert tuple(mask.shape) == tuple(inp.shape), (tuple(mask.shape), tuple(inp.shape))
+        assert abs(p - c["p"]) < 1e-12
+        return inp * mask.to(inp.dtype) / (1.0 - p)
+
+    Fn.dropout = fed
+    try:
+        protos = nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in synth.prototypes(2, C).items()})
+        lab = synth.labels(seed=c["label_seed"], B=B, nclasses=C)
+        emb, attn = m(x.clone(), f.clone(), lens, lens, 'Prototypes', pad.clone(), pad.clone(), None)
+        loss = misc.calcNCELoss(0, emb, lab, [f"v{b}" for b in range(B)], protos, None)
+        loss.backward()
+    finally:
+        Fn.dropout = real
+    assert not queue, len(queue)                                 # 2 streams x 4 layers x 4 sites, all consumed
+    g = {"emb": emb.detach().numpy(), "attn": attn.detach().numpy(), "loss": np.array(loss.item()),
+         "lens": np.array(lens), "labels": lab.numpy()}
+    P = dict(m.named_parameters())
+    for n in DROPOUT_GRADS:                                      # big matrices: every 97th element + the norm
+        gr = P[n].grad
+        g["grad/" + n] = (gr.flatten()[::97] if gr.numel() > 20000 else gr).numpy()
+        g["gnorm/" + n] = np.array(gr.norm().item())
+    for k, v in protos.items():
+        g["grad/proto" + k] = v.grad.numpy()
+    # eval-mode outputs of the same inputs: the masks must have changed something
+    m.eval()
+    with torch.no_grad():
+        e0, _ = m(x.clone(), f.clone(), lens, lens, 'Prototypes', pad.clone(), pad.clone(), None)
+    g["emb_eval"] = e0.numpy()
+    np.savez_compressed(os.path.join(out, "dropout.npz"), **g)
+    print("dropout.npz: loss", loss.item(), "|emb - emb_eval|max", float((emb.detach() - e0).abs().max()))
+
+
 def main():
     torch.set_num_threads(8)
     vits, prepare_model, misc = import_reference()
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        {"dropout": lambda: golden_dropout(prepare_model, misc, HERE)}[sys.argv[2]]()
+        return
+    golden_dropout(prepare_model, misc, HERE)
     golden_vit(vits, HERE)
     golden_temporal(prepare_model, misc, HERE)
     golden_collate(HERE)

@@ -173,3 +173,11 @@ def padding_mask(lens, maxT=None):
     for b, n in enumerate(lens):
         m[b, :, n + 1:] = True
     return m
+
+
+def dropout_masks(seed, Bn, S, nlayers=T_LAYERS, p=0.1):
+    """Per-layer Bernoulli(1-p) keep masks for the four dropout sites of a train-mode TransformerEncoderLayer, in the
+    oracle's batch-first layouts: attn [Bn,4,S,S], d1 [Bn,S,384], ff [Bn,S,2048], d2 [Bn,S,384]."""
+    g = _gen(seed)
+    k = lambda *sh: torch.rand(sh, generator=g) >= p
+    return [dict(attn=k(Bn, T_HEADS, S, S), d1=k(Bn, S, T_DIM), ff=k(Bn, S, T_FF), d2=k(Bn, S, T_DIM)) for _ in range(nlayers)]

@@ -27,6 +27,7 @@ def run():
     vit = vit.to(dev).train()
     m = fullModel('reps', C, 'in_vs_out', 384, 'ViT', modalities='RGB-Flow')
     m.load_state_dict(tsd, strict=True)
+    m.dropout_p = 0.0                      # the oracle comparison below is dropout-free
     m = m.to(dev).train()
     protos = torch.nn.ParameterDict({k: torch.nn.Parameter(v.clone().to(dev)) for k, v in synth.prototypes(2, C).items()})
     clips, fclips = synth.clips(seed=1, B=B, T=T), synth.clips(seed=2, B=B, T=T)

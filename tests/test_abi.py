@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib.sais_abi_version.restype = ctypes.c_int
-    assert lib.sais_abi_version() == 2
+    assert lib.sais_abi_version() == 3
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -32,6 +32,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_gemm_ln_fwd(None, None) == -1 and lib.sais_gemm_ln_bwd(ctypes.byref(_lib.SaisGemmLn()), None) == -1
     assert lib.sais_layernorm_fwd(None, 384, 4, 384, None, None, 1e-6, None, 384, None, 384, None, None, None) == -1
     assert lib.sais_vit_attn_fwd(None, 1152, 1, None, 384, None, None, None) == -1
-    assert lib.sais_temporal_attn_fwd(None, None, 1, 1000, None, None, None) == -1
+    assert lib.sais_temporal_attn_fwd(None, None, 1, 1000, None, None, 0.0, None, 0, None) == -1
+    assert lib.sais_dropout_f32(None, None, None, 10, 0.1, None, 0, None) == -1 and lib.sais_rng_advance(None, None) == -1
     assert lib.sais_preprocess_plan_create(0, 10, 0.8, 0.8, None, None, None) == -1
     assert lib.sais_preprocess_run(None, None, 1, None, None) == -1

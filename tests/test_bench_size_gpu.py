@@ -42,6 +42,7 @@ def _models():
     vit.load_state_dict(synth.vit_state_dict(seed=0), strict=True)
     m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB')
     m.load_state_dict(synth.temporal_state_dict(seed=1), strict=True)
+    m.dropout_p = 0.0
     protos = torch.nn.ParameterDict({k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in synth.prototypes(2, 2).items()})
     return vit.to(DEV).train(), m.to(DEV).train(), protos
 

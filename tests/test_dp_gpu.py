@@ -31,6 +31,7 @@ def _build(dev):
     vit.load_state_dict(synth.vit_state_dict(seed=0, depth=DEPTH), strict=True)
     m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB')
     m.load_state_dict(synth.temporal_state_dict(seed=1), strict=True)
+    m.dropout_p = 0.0                      # ranks would draw different masks than the single-process run
     protos = torch.nn.ParameterDict({k: torch.nn.Parameter(v.clone().to(dev)) for k, v in synth.prototypes(2, 2).items()})
     return vit.to(dev).train(), m.to(dev).train(), protos
 

@@ -51,6 +51,7 @@ def make_full(nclasses=2, modalities="RGB-Flow", nlayers=4):
         m.transEncoderFrame.layers = m.transEncoderFrame.layers[:nlayers]
         m.transEncoderClip.layers = m.transEncoderClip.layers[:nlayers]
     m.load_state_dict(synth.temporal_state_dict(seed=1, nlayers=nlayers), strict=True)
+    m.dropout_p = 0.0                      # the goldens of these tests are dropout-free; tests/test_dropout_gpu.py covers p > 0
     return m.to(DEV).eval()
 
 
@@ -221,6 +222,7 @@ def test_importance_head_vs_golden(gpu, golden, modal):
     key = modal + "/"
     m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities=modal, importance_loss=True)
     m.load_state_dict(synth.temporal_state_dict(seed=3, importance=True), strict=True)
+    m.dropout_p = 0.0
     m = m.to(DEV).train()
     lens = [int(v) for v in g[key + "lens"]]
     B, T = len(lens), 9

@@ -70,6 +70,7 @@ def test_train_three_epochs_and_reload(tmp_path):
                            modalities="RGB-Flow", inference=True)
     loaders, classes = T.load_dataloaders(root, "Custom_Gestures", 8, ["val"], "in_vs_out", "ViT_SelfSupervised_ImageNet")
     assert classes == ["in-view", "out-of-view"]
+    md["model"].eval()                # what trainModel does for every phase but 'train' (train.py:57-63): no dropout
     metrics, snippets, labels, names, attn, imp, logits = T.single_epoch(0, 1, loaders, md, None, dev, "val", 2,
                                                                          "Prototypes", False)
     # the reloaded best snapshot reproduces the embeddings it was saved with (bit for bit: same kernels, same weights)
