@@ -12,8 +12,10 @@ transposed LDS reads, recompute-from-LSE attention backward); parameter gradient
 by the kernels directly into the flat gradient buffer that p.grad views.
 
 Deliberate differences from the reference (documented in DESIGN.md): only the ViT-S/16 @224
-geometry is supported; DropPath (stochastic, train() only, never used by SAIS which runs the ViT in
-eval(): extract_representations.py:362) is the identity.
+geometry is supported; DropPath (stochastic depth, train() only: DINO pre-training; SAIS itself only ever runs the ViT
+in eval(), extract_representations.py:279,340,362) is not built: `drop_path_rate` is accepted, is the identity in eval()
+exactly as in the reference, and a train()-mode forward with `drop_path_rate > 0` RAISES instead of silently training a
+different model.
 """
 import torch
 import torch.nn as nn
@@ -88,7 +90,7 @@ class VisionTransformer(nn.Module):
             raise NotImplementedError("the MI355X kernels implement the ViT-S/16 @224 geometry only")
         self.num_features = self.embed_dim = embed_dim
         self.depth = depth
-        self.drop_path_rate = drop_path_rate        # accepted for signature parity; identity (see module doc)
+        self.drop_path_rate = drop_path_rate        # identity in eval(); train() with a rate > 0 raises (module doc)
         self.patch_embed = _PatchEmbed()
         self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
         self.pos_embed = nn.Parameter(torch.zeros(1, NTOK, D))
@@ -149,6 +151,9 @@ class VisionTransformer(nn.Module):
 
     # ------------------------------------------------------------------ public API (reference signatures)
     def forward(self, x):
+        if self.training and self.drop_path_rate > 0:
+            raise NotImplementedError("DropPath (vision_transformer.py:27-46) is not implemented on the MI355X path: "
+                                      "call .eval() (what SAIS does) or build the ViT with drop_path_rate=0 to train it")
         x = self._check_input(x)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in (self.cls_token, self.norm.weight))
         self._engine(x.device)
