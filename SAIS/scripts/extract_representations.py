@@ -18,11 +18,13 @@ from SAIS.scripts._features_io import save_reps  # noqa: E402
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # :148
 
 
-def frame_batches(folder, dev, chunk=256):
+def frame_batches(folder, dev, chunk=256, rank=0, world=1):
     """SurgDataset.__getitem__ (dino-main/main_dino.py:295-316) + the transform of :158-162, with the arithmetic on the
     GPU: JPEGs are decoded on the host (PIL), pushed as uint8 and turned into the float32 [n,3,224,224] ViT input by
     sais_amd.preprocess (CenterCrop(0.8 H, 0.8 W) -> Resize((224,224)) -> ToTensor -> Normalize, bit-identical to the
-    torchvision 0.9.0 / Pillow pipeline of the reference).  Yields device tensors of up to `chunk` frames."""
+    torchvision 0.9.0 / Pillow pipeline of the reference).  Yields device tensors of up to `chunk` frames.
+    world > 1: rank r decodes and embeds a contiguous range of the (sorted) frame files only."""
+    from sais_amd.parallel import shard_range
     from PIL import Image
     from sais_amd.preprocess import FramePreprocessor
     plans, buf, geom = {}, [], None
@@ -33,7 +35,9 @@ def frame_batches(folder, dev, chunk=256):
             plans[geom] = FramePreprocessor(h, w, 0.8, 0.8, MEAN, STD, device=dev)
         return plans[geom](torch.from_numpy(np.stack(buf)))
 
-    for p in sorted(glob.glob(os.path.join(folder, '*.jpg'))):
+    files = sorted(glob.glob(os.path.join(folder, '*.jpg')))
+    lo, hi = shard_range(len(files), rank, world)
+    for p in files[lo:hi]:
         with Image.open(p) as img:
             if img.mode != 'RGB':                    # the reference drops the result of img.convert('RGB') (:297)
                 raise SystemExit(f'{p}: mode {img.mode}; the pipeline expects RGB frames')
@@ -73,7 +77,9 @@ def main():
     t0 = time.time()
     from sais_amd.inference import FeatureExtractor
     from sais_amd.model_io import load_vit
-    dev = torch.device('cuda', args.local_rank)
+    from sais_amd.parallel import gather_in_rank_order, init_from_env, shard_range
+    rank, world, local = init_from_env()                 # torch.distributed.run: frames of a video are sharded over the ranks
+    dev = torch.device('cuda', local if world > 1 else args.local_rank)
     ckpt = args.checkpoint or os.path.join(args.data_path, 'scripts', 'dino-main', 'outputs', 'dino_deitsmall16_pretrain.pth')
     if not os.path.exists(ckpt):
         print(f'[extract] {ckpt} not found: using seeded random ViT-S/16 weights (no network in this environment)')
@@ -91,18 +97,24 @@ def main():
             n = max(1, args.synthetic_frames // 15) if flow else args.synthetic_frames     # flow maps: every 15th frame
             u8 = torch.randint(0, 256, (n, 3, 224, 224), generator=g, dtype=torch.uint8).float() / 255.0
             frames = (u8 - torch.tensor(MEAN).view(1, 3, 1, 1)) / torch.tensor(STD).view(1, 3, 1, 1)
+            lo, hi = shard_range(n, rank, world)
+            mine = fx(frames[lo:hi].to(dev)).cpu() if hi > lo else torch.empty(0, 384)
         else:
-            parts = [fx(b).cpu() for b in frame_batches(os.path.join(args.data_path, sub, v), dev)]
-            if not parts:
-                raise SystemExit(f'no frames under {os.path.join(args.data_path, sub, v)}')
-            reps[v] = torch.cat(parts).numpy()
-            print(f'[extract] {v}: {reps[v].shape[0]} frames -> {reps[v].shape}')
-            continue
-        reps[v] = fx(frames.to(dev)).cpu().numpy()
-        print(f'[extract] {v}: {reps[v].shape[0]} frames -> {reps[v].shape}')
+            parts = [fx(b).cpu() for b in frame_batches(os.path.join(args.data_path, sub, v), dev, rank=rank, world=world)]
+            mine = torch.cat(parts) if parts else torch.empty(0, 384)
+        full = torch.cat(gather_in_rank_order(mine, world))           # rank order = frame order
+        if full.shape[0] == 0:
+            raise SystemExit(f'no frames under {os.path.join(args.data_path, sub, v)}')
+        reps[v] = full.numpy()
+        if rank == 0:
+            print(f'[extract] {v}: {reps[v].shape[0]} frames -> {reps[v].shape}' + (f' ({world} ranks)' if world > 1 else ''))
     name = '%s_%sRepsAndLabels' % (args.model_type, 'Flow' if flow else '')
-    print('[extract] saved', save_reps(args.data_path, name, reps))
-    print('Time taken (s): %.3f' % (time.time() - t0))
+    if rank == 0:                                                     # rank 0 writes (train.py:98)
+        print('[extract] saved', save_reps(args.data_path, name, reps))
+        print('Time taken (s): %.3f' % (time.time() - t0))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -67,7 +67,13 @@ def main():
         raise SystemExit('--inference is built for -data Custom_Gestures (main.sh:27)')
     from sais_amd.inference import run_windows, save_inference_outputs, tta_probs
     from sais_amd.model_io import loadModel
+    from sais_amd.parallel import init_from_env
     from sais_amd.postprocess import read_frame_counts
+    # under torch.distributed.run the window batches of every video are sharded over the ranks and rank 0 writes the files
+    # (the reference pins world_size = 1, run_experiments.py:112)
+    rank, world, local = init_from_env()
+    if world > 1:
+        a.local_rank = local
     rgb = load_reps(a.path, '%s_RepsAndLabels' % a.encoder_params)
     flow = load_reps(a.path, 'ViT_SelfSupervised_ImageNet_FlowRepsAndLabels')
     for domain in a.domains:
@@ -90,17 +96,22 @@ def main():
                     x = torch.from_numpy(rgb[video]).float().to(dev)
                     f = torch.from_numpy(flow[video]).float().to(dev)
                     r, attn, imp = run_windows(md['model'], x, f, videoname=video, batch_size=a.batch_size,
-                                               total_frames=total_frames)
+                                               total_frames=total_frames, rank=rank, world_size=world)
                     for v in range(3):
                         all_reps["reps"][v].extend(r["reps"][v])
                     all_reps["labels"] += r["labels"]
                     all_reps["videonames"] += r["videonames"]
                     all_attn += attn
                     all_imp += imp
-                save_inference_outputs(savepath, phase, all_reps, all_attn, all_imp)
-                probs = tta_probs(all_reps, md['prototypes'])
-                print('[%s] %i windows; mean class probabilities %s' % (phase, probs.shape[0], probs.mean(0).tolist()))
-    print('Time taken (s): %.3f' % (time.time() - t0))
+                if rank == 0:
+                    save_inference_outputs(savepath, phase, all_reps, all_attn, all_imp)
+                    probs = tta_probs(all_reps, md['prototypes'])
+                    print('[%s] %i windows; mean class probabilities %s' % (phase, probs.shape[0], probs.mean(0).tolist()))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if rank == 0:
+        print('Time taken (s): %.3f' % (time.time() - t0))
 
 
 if __name__ == '__main__':

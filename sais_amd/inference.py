@@ -127,17 +127,22 @@ class FeatureExtractor:
 
 # --------------------------------------------------------------------------- windowed temporal inference
 @torch.no_grad()
-def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, total_frames=None):
+def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, total_frames=None, rank=0, world_size=1):
     """The `Custom_inference` phase of single_epoch (perform_training.py:71-185) over one video.
     Returns the dict train.py:116 saves as reps_and_labels_<phase>, the attention list (:117) and the importance list
     (:118; per-batch [B,1,T+1,1] tensors with `-il`, else empty).  `total_frames` = the video's row count in
     paths/Custom_Paths.csv, which is what sizes the windows in the reference (prepare_dataset.py:1705-1727); default:
-    the number of feature rows."""
+    the number of feature rows.
+    world_size > 1: the batches of `batch_size` windows are the reference's own (same composition, same
+    padding), rank r runs a contiguous range of them and every rank returns the lists merged in batch order."""
+    from .parallel import gather_in_rank_order, shard_range
     model.eval()
     wins = gesture_windows(rgb_reps.shape[0] if total_frames is None else total_frames)
     reps = ([], [], [])
     attention, labels, names, importance = [], [], [], []
-    for i in range(0, len(wins), batch_size):
+    starts = list(range(0, len(wins), batch_size))
+    lo, hi = shard_range(len(starts), rank, world_size)
+    for i in starts[lo:hi]:
         items = [sample_window(rgb_reps, flow_reps, s, e) for s, e in wins[i:i + batch_size]]
         c = pad_collate_tta(items)
         use_f = model.modalities in ("Flow", "RGB-Flow")
@@ -154,6 +159,13 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
         attention.append(attn.detach().cpu())
         labels += [torch.tensor(0, dtype=torch.long)] * len(items)          # placeholder label (:2637)
         names += [videoname] * len(items)
+    if world_size > 1:
+        parts = gather_in_rank_order((reps, attention, labels, names, importance), world_size)
+        reps = tuple([e for p in parts for e in p[0][v]] for v in range(3))
+        attention = [a for p in parts for a in p[1]]
+        labels = [l for p in parts for l in p[2]]
+        names = [n for p in parts for n in p[3]]
+        importance = [m for p in parts for m in p[4]]
     return {"reps": reps, "labels": labels, "videonames": names, "logits": []}, attention, importance
 
 

@@ -9,6 +9,7 @@ it overlaps the rest of backward.  `wait()` joins right before the SGD step, whi
 average through its `grad_scale` argument.  The reference's (disabled) DDP needed
 find_unused_parameters=True (prepare_model.py:549): here only the touched slices are exchanged.
 """
+import torch
 import torch.distributed as dist
 
 
@@ -79,3 +80,44 @@ class GradSync:
         self.pending = []
         n, self.bytes = self.bytes, 0
         return n
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Inference shards without an exchange step: frames of a video and the windows of a video are independent, so
+# every rank takes a contiguous range and the results are gathered in rank order; rank 0 writes the files (train.py:98).
+def shard_range(n, rank, world):
+    """Contiguous balanced split of range(n): the first n % world ranks get one more."""
+    q, r = divmod(int(n), int(world))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def init_from_env():
+    """(rank, world, local_rank) from the torch.distributed.run environment; starts the process group when world > 1
+    (backend nccl = RCCL on a GPU box, gloo otherwise).  World 1: nothing is initialised."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        backend = os.environ.get("SAIS_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:                            # gloo: host-side exchange; the ranks may share a GPU (tests on a 1-GPU box)
+            if torch.cuda.is_available():
+                local %= torch.cuda.device_count()
+                torch.cuda.set_device(local)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1 and torch.cuda.is_available():
+        local %= torch.cuda.device_count()
+    return rank, world, local
+
+
+def gather_in_rank_order(obj, world):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (host objects: CPU tensors, lists).  World 1: [obj]."""
+    if world == 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out

@@ -170,6 +170,58 @@ def test_data_parallel_gradient_exchange_gloo_world2(tmp_path):
     assert int(nbytes) > 4 * 3_000_000
 
 
+class _StubModel:
+    """Stands in for fullModel in the CPU test of the sharded window loop: deterministic host arithmetic on the batch."""
+    modalities, importance_loss = "RGB-Flow", False
+
+    def eval(self):
+        return self
+
+    def __call__(self, xs, fs, xlens, flens, task, xpads, fpads, domains):
+        embs = [x.sum(dim=(1, 2))[:, :256] + 0.5 * f.sum(dim=(1, 2))[:, :256] for x, f in zip(xs, fs)]
+        S = xs[0].shape[2] + 1
+        attn = xs[0][:, 0, :1, :1].expand(-1, S, S) + torch.arange(S * S).view(1, S, S)
+        return embs, attn
+
+
+def _win_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sais_amd.inference import run_windows
+    g = torch.Generator().manual_seed(5)
+    rgb, flow = torch.randn(200, 384, generator=g), torch.randn(14, 384, generator=g)
+    r, attn, imp = run_windows(_StubModel(), rgb, flow, videoname="v", batch_size=2, rank=rank, world_size=world)
+    if rank == world - 1:                                  # every rank returns the merged lists, not only rank 0
+        torch.save((r, attn, imp), out)
+    dist.destroy_process_group()
+
+
+def test_sharded_window_inference_merges_in_batch_order_gloo_world3(tmp_path):
+    """window batches sharded over ranks, gathered in rank order == the single-process lists."""
+    import torch.multiprocessing as mp
+    from sais_amd.inference import run_windows
+    from sais_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 13):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    out = str(tmp_path / "win.pt")
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    mp.spawn(_win_worker, args=(3, port, out), nprocs=3, join=True)
+    r3, attn3, imp3 = torch.load(out, weights_only=False)
+    g = torch.Generator().manual_seed(5)
+    rgb, flow = torch.randn(200, 384, generator=g), torch.randn(14, 384, generator=g)
+    r1, attn1, imp1 = run_windows(_StubModel(), rgb, flow, videoname="v", batch_size=2)
+    assert len(r1["labels"]) == 13 and len(attn1) == 7            # (200 - 15) // 15 + 1 windows, 7 batches of <= 2
+    assert r3["videonames"] == r1["videonames"] and len(r3["labels"]) == 13 and imp3 == imp1 == []
+    for v in range(3):
+        assert len(r3["reps"][v]) == 13 and all(torch.equal(a, b) for a, b in zip(r3["reps"][v], r1["reps"][v]))
+    assert len(attn3) == 7 and all(torch.equal(a, b) for a, b in zip(attn3, attn1))
+
+
 def test_window_sampler_and_tta_indices_follow_the_reference_quirks():
     from sais_amd.inference import flow_rows, gesture_windows, pad_collate_tta, sample_window, tta_indices
     wins = gesture_windows(512)

@@ -220,3 +220,51 @@ def test_main_sh_on_jpeg_frames_end_to_end(gpu, tmp_path):
     lines = open(root / "results" / "Custom_inference_gestures.csv").read().strip().split("\n")
     assert lines[0] == ",0,1,StartFrame,EndFrame,Entropy,pred,StartTime,EndTime,Gesture,Video,Path"
     assert len(lines) >= 2 and lines[1].endswith("vid_01,images/vid_01")
+
+
+def test_cli_inference_sharded_over_two_ranks_equals_single_process(gpu, tmp_path):
+    """SURVEY 8e, inference: frames (extract_representations.py) and window batches (run_experiments.py --inference) are
+    sharded over the ranks of `torch.distributed.run`, results gathered in rank order, rank 0 writes.  Two ranks sharing
+    this box's GPU (gloo) must write the same files, bit for bit, as one process."""
+    from sais_amd import model_io
+    from sais_amd.hdf5_min import read_h5
+    from sais_amd.temporal import fullModel
+    env = dict(os.environ, PYTHONPATH=ROOT, SAIS_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sc = lambda name: os.path.join(ROOT, "SAIS/scripts", name)
+    outs = {}
+    for world in (1, 2):
+        root = tmp_path / f"w{world}" / "SAIS"
+        fold = root / "params" / "Fold_0"
+        fold.mkdir(parents=True)
+        m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT')
+        m.load_state_dict(synth.temporal_state_dict(seed=1))
+        model_io.save_params_file(m, fold / "params.zip")
+        model_io.save_prototypes_file(synth.prototypes(2, 2), fold / "prototypes.zip")
+        launch = [sys.executable] if world == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+             "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300)]
+        subprocess.run([sys.executable, sc("generate_paths.py"), "-f", "vid_01", "-p", str(root) + "/", "--synthetic_frames",
+                        "100"], check=True, env=env, cwd=ROOT)
+        ex = launch + [sc("extract_representations.py"), "--arch", "vit_small", "--patch_size", "16", "--model_type",
+                       "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "64", "--data_path", str(root) + "/",
+                       "--data_list", "Custom", "--save_type", "h5", "--video", "vid_01", "--synthetic_frames", "100"]
+        subprocess.run(ex, check=True, env=env, cwd=ROOT)
+        subprocess.run(ex + ["--optical_flow_to_reps"], check=True, env=env, cwd=ROOT)
+        run = launch + [sc("run_experiments.py"), "-p", str(root) + "/", "-data", "Custom_Gestures", "-d", "Custom", "-m",
+                        "ViT", "-enc", "ViT_SelfSupervised_ImageNet", "-t", "Prototypes", "-mod", "RGB-Flow", "-dim", "384",
+                        "-bs", "2", "-lr", "1e-1", "-nc", "2", "-bc", "-sa", "-domains", "in_vs_out", "-ph",
+                        "Custom_inference", "-dt", "reps", "-e", "1", "-f", "1", "--inference"]
+        subprocess.run(run, check=True, env=env, cwd=ROOT)
+        outs[world] = (read_h5(str(root / "results" / "ViT_SelfSupervised_ImageNet_RepsAndLabels.h5"))["vid_01"],
+                       read_h5(str(root / "results" / "ViT_SelfSupervised_ImageNet_FlowRepsAndLabels.h5"))["vid_01"],
+                       torch.load(fold / "reps_and_labels_Custom_inference", weights_only=False),
+                       torch.load(fold / "attention_Custom_inference", weights_only=False))
+    (rgb1, fl1, r1, a1), (rgb2, fl2, r2, a2) = outs[1], outs[2]
+    assert rgb1.shape == (100, 384) and fl1.shape == (6, 384)
+    assert (rgb1 == rgb2).all() and (fl1 == fl2).all()                  # fixed-shape graph batches: same kernels either way
+    nwin = (100 - 15) // 15 + 1
+    assert r2["videonames"] == r1["videonames"] == ["vid_01"] * nwin
+    for v in range(3):
+        assert len(r2["reps"][v]) == nwin and all(torch.equal(x, y) for x, y in zip(r1["reps"][v], r2["reps"][v]))
+    # the head-averaged map is summed over the 4 heads with fp32 atomics: equal up to the order of those four additions
+    assert len(a1) == len(a2) == (nwin + 1) // 2 and all(float((x - y).abs().max()) <= 1e-7 for x, y in zip(a1, a2))
