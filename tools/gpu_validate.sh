@@ -1,0 +1,21 @@
+#!/bin/bash
+# End-of-round run on the GPU box: GPU tests, smoke, the bench line, rocprofv3 kernel stats of the same command and the
+# three PMC passes (own runs, program directly after `--`).  Usage (from the repo root on the box): tools/gpu_validate.sh <tag>
+tag=${1:-run}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$tag
+mkdir -p $O
+cd $R
+python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json | head -c 300; echo
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/stats.log 2>&1
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+          SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
+# keep the merge small: the per-dispatch traces are large, the stats and counter CSVs are what the reports read
+find $O -name "*kernel_trace.csv" -size +20M -delete
+du -sh $O

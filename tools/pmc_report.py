@@ -34,7 +34,7 @@ def timer_name(kernel):
     m = re.search(r"gemm_nt(?:_w8p)?_kernel<(\d+)>|gemm_nt(?:_w8p)?_kernelILi(\d+)E", kernel)
     if m:
         return "gemm_nt<%s>" % NT_NAMES[int(m.group(1) or m.group(2))]
-    for key, name in (("gemm_tn_wide_kernel", "gemm_tn_grouped"), ("gemm_tn_grouped_kernel", "gemm_tn_grouped"),
+    for key, name in (("gemm_tn_pp_kernel", "gemm_tn_grouped"), ("gemm_tn_wide_kernel", "gemm_tn_grouped"), ("gemm_tn_grouped_kernel", "gemm_tn_grouped"),
                       ("attn_fwd_kernel", "vit_attn_fwd"), ("attn_bwd_dq_kernel", "vit_attn_bwd_dq"),
                       ("attn_bwd_dkv_kernel", "vit_attn_bwd_dkv"), ("attn_bwd_kernel", "vit_attn_bwd"),
                       ("ln_fwd_kernel", "ln_fwd"), ("ln_bwd_kernel", "ln_bwd"), ("sgd_kernel", "sgd")):
