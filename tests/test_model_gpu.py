@@ -91,7 +91,7 @@ def test_vit_is_deterministic_and_batch_invariant(gpu):
 
 def test_vit_grads_vs_golden(gpu, golden):
     g = golden("vit")
-    vit = make_vit().train()
+    vit = make_vit()                       # eval(), as the reference ran for the goldens: DropPath 0.1 is the identity there
     x = synth.clips(seed=10, B=1, T=2)[0].to(DEV)
     rep = vit(x)
     (rep * torch.from_numpy(g["grad_wvec"]).to(DEV)).sum().backward()
@@ -282,7 +282,7 @@ def test_e2e_train_step_grads_vs_golden(gpu, golden):
     from oracle import sais_oracle as O
     from sais_amd.loss import calcNCELoss, cosine_logits_and_probs
     g = golden("e2e")
-    vit = make_vit().train()
+    vit = make_vit()                       # eval(), as the reference ran for the goldens: DropPath 0.1 is the identity there
     m = make_full(2, "RGB-Flow").train()
     B, T = 2, 4
     clips = synth.clips(seed=900 + T, B=B, T=T)
