@@ -252,6 +252,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
                        : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
     const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
 
+    // A-operand prefetch into L2 (K = 384, N >= 1024).  The ntn column tiles of a row tile run side by side on one XCD and
+    // all of them wait for the same first-touch fetch of the A rows; once the epilogues of the other CUs keep HBM busy
+    // with writes that fetch takes several microseconds, far more than the two K-steps of lead the LDS ring gives
+    // (measured: the GELU + GELU' GEMM takes 145 us, 123 us with an L2-resident A).  So while a workgroup is in the
+    // epilogue of tile i, wave 0 touches its 1/ntn share of the cache lines of tile i+1's A rows that the in-loop loads
+    // would only ask for later (k >= 128: lines 2-5 of every 768-B row; lines 0-1 are being fetched by A'(0), A'(1)):
+    // one global_load_dword, 44-60 active lanes, result never used.  It is the youngest load at the tile switch (one
+    // more allowed in that wait) and is retired by the counted wait of K-step 0.  fc1 + GELU' 129 -> 124 us, qkv 68.5 ->
+    // 66.5 us inside the step.  (Prefetching two tiles ahead is no better; the same trick on the bf16 aux tile of the
+    // MUL epilogue is WORSE, 128 vs 118 us: that operand is bandwidth, not latency.)
+    const bool do_pf = nk == 6 && ntn >= 8 && ntn <= 16 && wid == 0;
+    unsigned pf_keep = 0;
+    auto prefetch_a = [&](int pm0, int tcol) {
+        const int per = (BM + ntn - 1) / ntn;                      // rows per sharing workgroup
+        const int row = tcol * per + (lane >> 2);
+        if ((lane >> 2) < per && row < BM) {
+            int m = pm0 + row;
+            m = m < p.M ? m : p.M - 1;
+            const bf16* q = p.A + (size_t)m * p.lda + (2 + (lane & 3)) * 64;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pf_keep) : "v"(q) : "memory");
+        }
+    };
     int v = blockIdx.x, m0, n0;
     if (v >= ntiles) return;
     set_tile(v, m0, n0);
@@ -295,11 +317,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
         const int cm0 = m0, cn0 = n0;
         const int nv = v + gridDim.x;
         const bool more = nv < ntiles;
+        asm volatile("" ::"v"(pf_keep));                               // the previous prefetch has been retired by now
         if (more) {
             set_tile(nv, m0, n0);
             issue_a(0);
             issue_w(0);
             if (nk > 1) issue_a(1);
+            if (do_pf) prefetch_a(m0, xcd_remap(nv, ntiles) % ntn);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -315,10 +339,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
         if (!more) break;
         v = nv;
         // A'(0) and W'(0) must have landed; the two A'(1) pieces and this epilogue's stores may stay in flight
-        const int allow = (cm0 + BM <= p.M && nk > 1) ? nstores + 2 : 0;
+        const int allow = (cm0 + BM <= p.M && nk > 1) ? nstores + 2 + (do_pf ? 1 : 0) : 0;
         if (allow == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (allow == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else if (allow == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (allow == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
         else if (allow == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (allow == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
