@@ -270,6 +270,7 @@ def trainModel(rank, world_size, root_path, savepath, dataset_name, data_type, b
                                          task, fold, lr=lr, modalities=modalities,
                                          freeze_encoder_params=freeze_encoder_params, self_attention=self_attention,
                                          importance_loss=importance_loss, inference=inference)
+    model["model"].dropout_seed = 1000 * fold + rank       # train-mode dropout: every fold and rank its own mask stream
     if dataloader is None:
         dataloader, _ = load_dataloaders(root_path, dataset_name, batch_size, phases, domain, encoder_params, rank,
                                          world_size, seed=fold)
