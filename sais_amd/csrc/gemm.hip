@@ -754,133 +754,11 @@ struct TnWideGroup {
     int nitems, ntiles;
 };
 
-__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
-    extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = wg / gp.ntiles;
-    int t = wg - split * gp.ntiles, it0 = 0;
-    while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;
-    if (it0 > 0) t -= gp.tile_end[it0 - 1];
-    const TnParams& p = gp.item[it0];
-    const int nt2 = p.N2 / WQ;
-    const int n1_0 = (t / nt2) * 128, n2_0 = (t % nt2) * WQ;
-    const int mbeg = split * p.rows_per_split;
-    const int mend = min(p.M, mbeg + p.rows_per_split);
-    if (mbeg >= mend) return;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
-    // LDS-DMA: wave w fills half (w & 1) of block (w >> 1) of every stage: 8 pieces of 4 rows x 256 B
-    const int blk = wid >> 1;
-    const bf16* src0 = blk == 0 ? (const bf16*)p.P + n1_0 : (const bf16*)p.Q + n2_0 + (blk - 1) * 128;
-    const int ld = blk == 0 ? p.ldp : p.ldq;
-    // one per-lane base pointer; piece j and the step add a wave-uniform row offset
-    const bf16* pbase = src0 + (size_t)(mbeg + 32 * (wid & 1) + (lane >> 4)) * ld + (lane & 15) * 8;
-    const int nsteps = (mend - mbeg) / TK;                        // host guarantees whole 64-row steps
-    // global -> VGPR -> LDS staging: a plain vector load does not hold the wave the way an LDS-DMA issue does, so the
-    // MFMAs of the current step start at once and the next tile lands in registers underneath them
-    // two tiles are in flight in registers (the one written to LDS at the end of this step and the one after it): a
-    // first-touch row slab comes from HBM, and one step (~2 us) is not enough to cover that latency
-    u32x4 stg[2][8];
-    auto gload = [&](int step, u32x4 (&dst)[8]) {
-        step = step < nsteps ? step : nsteps - 1;                       // past the end: harmless reload
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = *(const u32x4*)(pbase + (size_t)(step * TK + 4 * j) * ld);
-    };
-    auto lwrite = [&](int stage, const u32x4 (&src)[8]) {
-        char* s = wsmem + stage * WSTAGE + blk * WBLK;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = 4 * (8 * (wid & 1) + j) + (lane >> 4), c = lane & 15;
-            *(u32x4*)(s + r * 256 + ((((c >> 1) ^ (r & 7)) << 5) | ((c & 1) << 4))) = src[j];
-        }
-    };
-    f32x4 acc[4][6];
-    f32x4 accb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        accb[i] = f32x4{0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
-    }
-    const bool do_bias = p.db != nullptr && n2_0 == 0 && wc == 0;
-    bf16x8 ones;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (bf16)1.0f;
-    const int q4 = li >> 2, p4 = li & 3;
-    // `mid` (the LDS write of the NEXT tile + the global loads of the one after) is issued right after the first k-step's
-    // fragment reads, so the LDS write path (~830 cycles per step for the 64 KiB of a stage) drains under the MFMAs of
-    // this step instead of after them: in the first version the loop was reads -> 48 MFMAs -> 8 ds_write_b128 -> barrier,
-    // every wave of the workgroup in the same phase at the same time.
-    auto compute = [&](int cur, auto&& mid) {
-        const char* sp = wsmem + cur * WSTAGE;
-        const char* sq = sp + WBLK;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fp[4], fq[3];
-            const int row = ks * 32 + 4 * g + q4;
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int cp = wr * 64 + tt * 16 + 4 * p4;
-                fp[tt] = cat4(lds_read_tr16(tr_addr(sp, row, cp)), lds_read_tr16(tr_addr(sp, row + 16, cp)));
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {                         // Q fragments in two halves: 12 live registers less
-#pragma unroll
-                for (int tt = 0; tt < 3; ++tt) {
-                    const int c = wc * 96 + (3 * h + tt) * 16;
-                    const char* qb = sq + (c >> 7) * WBLK;
-                    const int cq = (c & 127) + 4 * p4;
-                    fq[tt] = cat4(lds_read_tr16(tr_addr(qb, row, cq)), lds_read_tr16(tr_addr(qb, row + 16, cq)));
-                }
-                if (ks == 0 && h == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    mid();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc[i][3 * h + j] = mfma16(fp[i], fq[j], acc[i][3 * h + j]);
-            }
-            if (do_bias) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) accb[i] = mfma16(fp[i], ones, accb[i]);
-            }
-        }
-    };
-    gload(0, stg[0]);
-    gload(1, stg[1]);
-    lwrite(0, stg[0]);
-    gload(2, stg[0]);
-    __syncthreads();
-    // step st: stage st&1 holds tile st; stg[(st+1)&1] holds tile st+1 (written to LDS at the end of the step) and tile
-    // st+2 is on its way into stg[st&1]; unrolled by two so that the register sets are static
-    for (int st = 0; st < nsteps; st += 2) {
-        compute(0, [&] { lwrite(1, stg[1]); gload(st + 3, stg[1]); });
-        __syncthreads();
-        if (st + 1 < nsteps) {
-            compute(1, [&] { lwrite(0, stg[0]); gload(st + 4, stg[0]); });
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n1 = n1_0 + wr * 64 + i * 16 + 4 * g + r;
-            float* row = p.dW + (size_t)n1 * p.ldw + n2_0 + wc * 96 + li;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) atomicAdd(row + j * 16, acc[i][j][r]);
-            if (do_bias && li == 0) atomicAdd(p.db + n1, accb[i][r]);
-        }
-}
-
-
-// Ping-pong schedule of the wide dW kernel.  Same tile (128 x 384), same LDS image, same register staging; what changes
-// is WHEN each wave does what.  In gemm_tn_wide_kernel all eight waves read fragments together, run their 48 MFMAs
-// together and meet at one barrier per step, so the MFMA pipe of a SIMD idles while both of its waves are in the LDS
+// The wide dW kernel: 128 x 384 tile, 8 waves (2 x 4 of 64 x 96), global -> VGPR -> LDS staging (a plain vector load does
+// not hold the wave the way an LDS-DMA issue does) with two tiles in flight in registers (a first-touch row slab comes
+// from HBM, and one step is not enough to cover that latency), transposed fragment reads.
+// Ping-pong schedule.  Round 1's version had all eight waves read fragments together, run their 48 MFMAs
+// together and meet at one barrier per step, so the MFMA pipe of a SIMD idled while both of its waves were in the LDS
 // phase (PMC: MFMA busy 39 %).  Here a step is four barrier intervals per wave,
 //     R0: fragments of k-half 0 + first half of the next tile's LDS writes / global loads
 //     M0: 24 MFMAs          R1: fragments of k-half 1 + second half of the writes / loads          M1: 24 MFMAs
@@ -889,6 +767,9 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(TnWideGroup gp) {
 // Hazards (intervals numbered globally; group A's step s is 4s..4s+3, group B's 4s+1..4s+4): tile s+1 is written into
 // buffer (s+1)&1 during 4s..4s+3 and first read in 4s+4; the old contents (tile s-1) were last read in 4s-2 (A) and
 // 4s-1 (B), and every R interval ends with lgkmcnt(0) BEFORE its barrier, so those reads have returned.
+// (212 -> 197 us per block inside the step.  Measured and dropped on this kernel: one bias MFMA per wave instead of four
+// on the wc = 0 waves, hand-counted vmcnt(12) instead of the compiler's vmcnt(7..4): no change either way — the kernel
+// is paced by the global fill stream)
 __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
     extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -1189,11 +1070,7 @@ extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, 
         int wrows = ((M + wns - 1) / wns + TK - 1) / TK * TK;
         wns = (M + wrows - 1) / wrows;
         for (int i = 0; i < nitems; ++i) { wg.item[i] = gp.item[i]; wg.item[i].rows_per_split = wrows; }
-#ifdef SAIS_TN_WIDE_V1
-        auto* kern = gemm_tn_wide_kernel;
-#else
         auto* kern = gemm_tn_pp_kernel;
-#endif
         static thread_local bool lds_set = false;
         if (!lds_set) {
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE) != hipSuccess)
