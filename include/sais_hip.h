@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 3
+#define SAIS_ABI_VERSION 4
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -58,6 +58,8 @@ typedef struct SaisGemm {
     void* out2; int ldo2;
     const void* aux; int ldaux;
     int grp_in, grp_out, grp_off;  /* SAIS_EPI_PATCH_F32 only            */
+    const float* rowscale;         /* SAIS_EPI_BIAS_RESID_F32 only, optional: DropPath (vision_transformer.py:27-46,111,113)
+                                      out = aux + rowscale[m] * (acc + bias), rowscale[m] = keep / (1 - p) of row m's sample */
 } SaisGemm;
 
 int sais_gemm_nt(const SaisGemm* g, void* stream);
@@ -117,6 +119,9 @@ typedef struct SaisGemmLn {
     float* mean; float* rstd;      /* fwd: outputs [M] (optional); bwd: inputs                */
     const float* dres; int lddres; /* bwd: residual-stream gradient added to dx (optional)    */
     float* dgamma; float* dbeta;   /* bwd: f32 [384], accumulated (both or neither)           */
+    const float* rowscale;         /* fwd, optional (DropPath): x_out = resid + rowscale[m] * (A.W^T + bias)            */
+    const float* rowscale16;       /* bwd, optional (DropPath): out16 = bf16(rowscale16[m] * dx): the gradient that enters
+                                      the NEXT branch's backward GEMMs; out32 (the residual-stream gradient) is not scaled */
 } SaisGemmLn;
 int sais_gemm_ln_fwd(const SaisGemmLn* g, void* stream);
 int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream);
@@ -134,7 +139,8 @@ int sais_layernorm_fwd(const float* x, long ldx, int rows, int dim, const float*
 int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float* dy_f32, long lddy32, const float* x, long ldx,
                        const float* mean, const float* rstd, const float* gamma, const float* dres, long lddres,
                        int rows, int dim, float* dx_f32, long lddx32, void* dx_bf16, long lddx16, float* dgamma,
-                       float* dbeta, void* stream);
+                       float* dbeta, const float* rowscale16 /*optional: dx_bf16 = bf16(rowscale16[row] * dx), DropPath*/,
+                       void* stream);
 
 /* ---------------------------------------------------------------- ViT spatial attention (197 tokens, 6 heads x 64)
  * Attention.forward core, vision_transformer.py:83-90: softmax(q k^T / 8) v per (frame, head).
@@ -221,6 +227,15 @@ int sais_rng_advance(unsigned long long* state /*{seed, offset}*/, void* stream)
 int sais_dropout_f32(const float* x, const float* resid /*optional*/, float* out, long n, float p,
                      const unsigned long long* rng_state, unsigned site, void* stream);
 int sais_dropout_mask(unsigned char* mask, long n, float p, const unsigned long long* rng_state, unsigned site, void* stream);
+/* DropPath / stochastic depth of the ViT blocks in train mode (vision_transformer.py:27-46,105-113; rates
+ * linspace(0, drop_path_rate, depth), :150): x = x + keep_f / (1 - p) * branch(x), one Bernoulli(1 - p) draw per sample f.
+ * sais_droppath_scales fills the per-ROW scale arrays of `nbranch` branches in one launch (out f32 [nbranch][samples *
+ * rows_per_sample]; keep from the same Philox state as the dropout, site = site0 + branch, element = sample); they are
+ * the `rowscale` of SaisGemm (SAIS_EPI_BIAS_RESID_F32) / SaisGemmLn forward and the `rowscale16` of the LayerNorm backward
+ * entry points.  sais_cast_bf16_rows: dst = bf16(rowscale[row] * src) (the first branch gradient of the backward pass). */
+int sais_droppath_scales(float* out, const float* rates_dev /*[nbranch]*/, int nbranch, int samples, int rows_per_sample,
+                         const unsigned long long* rng_state, unsigned site0, void* stream);
+int sais_cast_bf16_rows(const float* src, const float* rowscale, void* dst_bf16, long rows, int dim, void* stream);
 
 /* ---------------------------------------------------------------- head + SupCon / prototype loss
  * fullModel.forward Prototypes branch, prepare_model.py:215,220,381-416:

@@ -51,31 +51,35 @@ def vit_attention(sd, pre, xn, heads=VIT_HEADS, want_probs=False):
     return out, probs, qkv, ctx
 
 
-def vit_block(sd, i, x, trace=None):
-    """Block.forward — vision_transformer.py:95-113 in eval mode (DropPath = identity),
-    LayerNorm eps 1e-6 (vit_small :243-247), exact-erf GELU (Mlp :49-65)."""
+def vit_block(sd, i, x, trace=None, dp=None):
+    """Block.forward — vision_transformer.py:95-113, LayerNorm eps 1e-6 (vit_small :243-247), exact-erf GELU (Mlp
+    :49-65).  dp = None: eval mode (DropPath = identity).  dp = (s_attn [F], s_mlp [F]): train mode, the per-sample
+    DropPath factors keep / (1 - p) of the two residual branches (drop_path :27-46: x.div(keep_prob) * floor(keep_prob +
+    rand), one draw per sample) — inputs, because the RNG stream is the framework's, not part of the algorithm."""
     pre = f"blocks.{i}."
     D = x.shape[-1]
     xn = F.layer_norm(x, (D,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-6)
     a, probs, qkv, ctx = vit_attention(sd, pre, xn)
-    mid = x + a
+    mid = x + (a if dp is None else a * dp[0].view(-1, 1, 1))
     xn2 = F.layer_norm(mid, (D,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-6)
     u = F.linear(xn2, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
     h = F.gelu(u)
-    out = mid + F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    y = F.linear(h, sd[pre + "mlp.fc2.weight"], sd[pre + "mlp.fc2.bias"])
+    out = mid + (y if dp is None else y * dp[1].view(-1, 1, 1))
     if trace is not None:
         trace.update(norm1=xn, qkv=qkv, attn_ctx=ctx, proj=a, mid=mid, norm2=xn2, fc1=u, gelu=h, probs=probs)
     return out
 
 
-def vit_forward(sd, x, depth=12, trace=None):
-    """VisionTransformer.forward — vision_transformer.py:209-214: CLS row of the final LN."""
+def vit_forward(sd, x, depth=12, trace=None, droppath=None):
+    """VisionTransformer.forward — vision_transformer.py:209-214: CLS row of the final LN.
+    droppath: f32 [2 * depth, F] per-sample branch factors (row 2i = attention of block i, 2i + 1 = its MLP) for train mode."""
     t = vit_prepare_tokens(sd, x)
     if trace is not None:
         trace["tokens"] = t
     for i in range(depth):
         bt = {} if (trace is not None and i == 0) else None
-        t = vit_block(sd, i, t, bt)
+        t = vit_block(sd, i, t, bt, dp=None if droppath is None else (droppath[2 * i], droppath[2 * i + 1]))
         if trace is not None:
             trace[f"block{i}"] = t
             if bt:

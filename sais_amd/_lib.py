@@ -20,7 +20,7 @@ class SaisGemm(ctypes.Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("epilogue", c_int),
                 ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int),
                 ("out2", c_void_p), ("ldo2", c_int), ("aux", c_void_p), ("ldaux", c_int),
-                ("grp_in", c_int), ("grp_out", c_int), ("grp_off", c_int)]
+                ("grp_in", c_int), ("grp_out", c_int), ("grp_off", c_int), ("rowscale", c_void_p)]
 
 
 class SaisTnItem(ctypes.Structure):
@@ -33,7 +33,7 @@ class SaisGemmLn(ctypes.Structure):
                 ("bias", c_void_p), ("resid", c_void_p), ("ldr", c_int), ("out32", c_void_p), ("ldo32", c_int),
                 ("out16", c_void_p), ("ldo16", c_int), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
                 ("mean", c_void_p), ("rstd", c_void_p), ("dres", c_void_p), ("lddres", c_int),
-                ("dgamma", c_void_p), ("dbeta", c_void_p)]
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("rowscale", c_void_p), ("rowscale16", c_void_p)]
 
 
 EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
@@ -57,7 +57,7 @@ SIGNATURES = {
                            c_long, c_void_p, c_void_p, c_void_p],
     "sais_layernorm_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
-                           c_void_p],
+                           c_void_p, c_void_p],
     "sais_vit_attn_fwd": [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
     "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p,
                           c_long, c_void_p],
@@ -81,6 +81,8 @@ SIGNATURES = {
     "sais_temporal_attn_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
     "sais_temporal_attn_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
     "sais_rng_advance": [c_void_p, c_void_p],
+    "sais_droppath_scales": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_uint, c_void_p],
+    "sais_cast_bf16_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "sais_dropout_f32": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p, ctypes.c_uint, c_void_p],
     "sais_dropout_mask": [c_void_p, c_long, c_float, c_void_p, ctypes.c_uint, c_void_p],
     "sais_head_fwd": [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

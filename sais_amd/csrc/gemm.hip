@@ -91,6 +91,13 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16], cons
     } else if constexpr (EPI == SAIS_EPI_BIAS_F32) {
         store_f32(p.out, p.ldo, m, y);
     } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_PATCH_F32) {
+        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
+            if (p.rowscale) {                                   // DropPath: residual + s_m (acc + bias)
+                const float sc = p.rowscale[m];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) y[i] *= sc;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) y[i] += a.r[mt][i >> 2][i & 3];
         size_t orow = m;
@@ -924,7 +931,8 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
          g->epilogue == SAIS_EPI_BIAS_RESID_F32) && !g->aux)
         return SAIS_ERR_ARG;
     NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
-               g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off};
+               g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, g->grp_in, g->grp_out, g->grp_off, g->rowscale};
+    if (g->rowscale && g->epilogue != SAIS_EPI_BIAS_RESID_F32) return SAIS_ERR_ARG;
     dim3 grid((g->N / BN) * ((g->M + BM - 1) / BM));
     // Two kernels, chosen by M alone: the four-wave 128x128 kernel for small M (inference batches, tests, the
     // patch-embed epilogue) and the persistent eight-wave A-ring kernel for the ViT GEMMs of a training step
@@ -934,6 +942,7 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // the plain N = 384 GEMMs of a training step (dX of proj, the last block's fc2): balanced row tiles of gemm_row.hip
     if (big && g->N == 384 && (g->epilogue == SAIS_EPI_BIAS_BF16 || (g->epilogue == SAIS_EPI_BIAS_RESID_F32 && !g->out2)))
         return sais_gemm_nt_row_(g, stream);
+    if (big && g->rowscale) return SAIS_ERR_ARG;               // the eight-wave kernel has no row-scale epilogue
     switch (g->epilogue) {
         LAUNCH_NT(SAIS_EPI_BIAS_BF16)
         LAUNCH_NT(SAIS_EPI_BIAS_RELU_BF16)

@@ -14,6 +14,7 @@ struct NtParams {
     void* out2; int ldo2;
     const void* aux; int ldaux;
     int grp_in, grp_out, grp_off;
+    const float* rowscale;          // SAIS_EPI_BIAS_RESID_F32, small-M kernel only (DropPath)
 };
 
 // Eight-wave tile: the 128x128x64 tile and LDS image of gemm_nt_kernel, but 512 threads (2 x 4 waves of

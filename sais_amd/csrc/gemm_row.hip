@@ -54,13 +54,17 @@ struct RowParams {
     float* mean; float* rstd;       // LN_FWD: out (nullable) | LN_BWD: in
     const float* dres; int lddres;  // LN_BWD: residual-stream gradient added to dx (may alias out)
     float* dgamma; float* dbeta;    // LN_BWD: +=
+    // DropPath (stochastic depth, train mode; kernels instantiated with DP = true): per-row scale s[m] = keep / (1 - p) of
+    // the sample the row belongs to.  RESID / LN_FWD: x_out = residual + s (acc + bias).  LN_BWD: the bf16 copy of dx that
+    // feeds the NEXT branch's backward GEMMs is s dx (the fp32 residual-stream gradient is not scaled).
+    const float* rowscale;
 };
 
 // weight-row permutation inside a 32-column wave slice of a chunk: LDS row 16 t + 4 a + b <- slice column 8 a + 4 t + b,
 // so that lane group a = lane>>4 ends up with 8 CONTIGUOUS output columns (t = MFMA tile 0/1, b = accumulator register)
 DEVINL int perm32(int r) { return (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3); }
 
-template <int EPI>
+template <int EPI, bool DP>
 __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -239,6 +243,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                     }
 #pragma unroll
                     for (int i = 0; i < 12; ++i) v[i] += bs[i];
+                    if constexpr (DP) {
+                        const float sc = p.rowscale[clampm(m)];
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) v[i] *= sc;
+                    }
                     if (m < mend) {
                         if constexpr (EPI == ROW_BIAS_BF16) {
                             st12_bf16((bf16*)p.out + (size_t)m * p.ldo + n0, v);
@@ -278,8 +287,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                     if (it + 1 < NIT)                                // next row's residual: issued before this row's stores
                         ld12((const float*)p.aux + (size_t)clampm(m0 + trow(it + 1)) * p.ldaux, rnext);
                     float sum = 0.f;
+                    if constexpr (DP) {
+                        const float sc = p.rowscale[clampm(m)];
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) { v[i] += bs[i] + rcur[i]; sum += v[i]; }
+                        for (int i = 0; i < 12; ++i) { v[i] = (v[i] + bs[i]) * sc + rcur[i]; sum += v[i]; }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) { v[i] += bs[i] + rcur[i]; sum += v[i]; }
+                    }
                     const float mu = half_sum(sum) * (1.0f / RBN);
                     float sq = 0.f;
 #pragma unroll
@@ -349,6 +364,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                     for (int i = 0; i < 12; ++i) dy[i] = rs * (dy[i] - c1 - xv[i] * c2) + dr[i];
                     if (live) {
                         if (p.out) st12((float*)p.out + (size_t)m * p.ldo, dy);
+                        if constexpr (DP) {
+                            const float sc = p.rowscale[m];
+#pragma unroll
+                            for (int i = 0; i < 12; ++i) dy[i] *= sc;
+                        }
                         if (p.out2) st12_bf16((bf16*)p.out2 + (size_t)m * p.ldo2, dy);
                     }
                 }
@@ -385,11 +405,22 @@ int rows_per_tile(int M) {
     return rows;
 }
 
+template <int EPI, bool DP>
+int launch_row_dp(RowParams& p, void* stream);
+
 template <int EPI>
 int launch_row(RowParams& p, void* stream) {
+    if constexpr (EPI != ROW_BIAS_BF16) {
+        if (p.rowscale) return launch_row_dp<EPI, true>(p, stream);
+    }
+    return launch_row_dp<EPI, false>(p, stream);
+}
+
+template <int EPI, bool DP>
+int launch_row_dp(RowParams& p, void* stream) {
     static thread_local bool set = false;
     if (!set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_row_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gemm_nt_row_kernel<EPI, DP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ROW_LDS) != hipSuccess)
             return SAIS_ERR_LAUNCH;
         set = true;
@@ -398,7 +429,7 @@ int launch_row(RowParams& p, void* stream) {
     if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAIS_ERR_ARG;
     p.rows_per_tile = rows_per_tile(p.M);
     const int grid = (p.N / RBN) * ((p.M + p.rows_per_tile - 1) / p.rows_per_tile);
-    hipLaunchKernelGGL(gemm_nt_row_kernel<EPI>, dim3(grid), dim3(256), ROW_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_nt_row_kernel<EPI, DP>), dim3(grid), dim3(256), ROW_LDS, (hipStream_t)stream, p);
     return sais_check_launch();
 }
 
@@ -411,6 +442,7 @@ extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream) {
     p.A = (const bf16*)g->A; p.W = (const bf16*)g->B; p.lda = g->lda; p.ldw = g->ldb;
     p.M = g->M; p.N = g->N; p.K = g->K; p.bias = g->bias;
     p.out = g->out; p.ldo = g->ldo; p.out2 = g->out2; p.ldo2 = g->ldo2; p.aux = g->aux; p.ldaux = g->ldaux;
+    p.rowscale = g->rowscale;
     switch (g->epilogue) {
         case SAIS_EPI_BIAS_BF16: return launch_row<ROW_BIAS_BF16>(p, stream);
         case SAIS_EPI_BIAS_RESID_F32: return g->out2 ? SAIS_ERR_ARG : launch_row<ROW_RESID_F32>(p, stream);
@@ -432,6 +464,7 @@ extern "C" int sais_gemm_ln_fwd(const SaisGemmLn* g, void* stream) {
     p.M = g->M; p.N = RBN; p.K = g->K; p.bias = g->bias;
     p.out = g->out32; p.ldo = g->ldo32; p.out2 = g->out16; p.ldo2 = g->ldo16; p.aux = g->resid; p.ldaux = g->ldr;
     p.gamma = g->gamma; p.beta = g->beta; p.eps = g->eps; p.mean = g->mean; p.rstd = g->rstd;
+    p.rowscale = g->rowscale;
     return launch_row<ROW_LN_FWD>(p, stream);
 }
 
@@ -445,5 +478,6 @@ extern "C" int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream) {
     p.out = g->out32; p.ldo = g->ldo32; p.out2 = g->out16; p.ldo2 = g->ldo16; p.aux = g->resid; p.ldaux = g->ldr;
     p.gamma = g->gamma; p.mean = g->mean; p.rstd = g->rstd;
     p.dres = g->dres; p.lddres = g->lddres; p.dgamma = g->dgamma; p.dbeta = g->dbeta;
+    p.rowscale = g->rowscale16;
     return launch_row<ROW_LN_BWD>(p, stream);
 }

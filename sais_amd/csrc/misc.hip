@@ -129,6 +129,30 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* 
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (bf16)src[i];
 }
 
+// dst[m, :] = bf16(rowscale[m] * src[m, :]) over rows of `dim` elements (DropPath: the branch gradient)
+__global__ __launch_bounds__(256) void cast_bf16_rows_kernel(const float* src, const float* rowscale, bf16* dst, long rows,
+                                                            int dim) {
+    const long n = rows * dim;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = (bf16)(src[i] * rowscale[i / dim]);
+}
+
+// DropPath (vision_transformer.py:27-46): per sample a Bernoulli(1 - p) keep, output scaled by 1 / (1 - p).  One launch
+// fills the per-ROW scale arrays of all branches: out[j][f * rows_per_sample + t] = keep(j, f) / (1 - rate[j]),
+// keep from Philox (site = site0 + j, element = sample f).  rate[j] = 0 -> 1.0.
+__global__ __launch_bounds__(256) void droppath_scales_kernel(float* out, const float* rates, int nbranch, int samples,
+                                                             int rows_per_sample, const unsigned long long* rng,
+                                                             unsigned site0) {
+    const long per = (long)samples * rows_per_sample, n = per * nbranch;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int j = (int)(i / per);
+        const int f = (int)((i - (long)j * per) / rows_per_sample);
+        const float p = rates[j];
+        float sc = 1.0f;
+        if (p > 0.f) sc = philox_keep(rng, site0 + j, (unsigned long long)f, drop_threshold(p)) ? 1.0f / (1.0f - p) : 0.f;
+        out[i] = sc;
+    }
+}
+
 // dst[C,R] = src[R,C]^T (f32 in, bf16 or f32 out); 32x32 tiles through LDS
 template <typename TO>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* src, TO* dst, int R, int C) {
@@ -320,5 +344,22 @@ extern "C" int sais_dropout_mask(unsigned char* mask, long n, float p, const uns
     SAIS_ENTER();
     if (!mask || !rng_state || n <= 0 || p < 0.f || p >= 1.f) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p, rng_state, site);
+    return sais_check_launch();
+}
+
+extern "C" int sais_cast_bf16_rows(const float* src, const float* rowscale, void* dst_bf16, long rows, int dim, void* stream) {
+    SAIS_ENTER();
+    if (!src || !rowscale || !dst_bf16 || rows <= 0 || dim <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(cast_bf16_rows_kernel, dim3(grid_for(rows * dim)), dim3(256), 0, (hipStream_t)stream, src, rowscale,
+                       (bf16*)dst_bf16, rows, dim);
+    return sais_check_launch();
+}
+
+extern "C" int sais_droppath_scales(float* out, const float* rates_dev, int nbranch, int samples, int rows_per_sample,
+                                    const unsigned long long* rng_state, unsigned site0, void* stream) {
+    SAIS_ENTER();
+    if (!out || !rates_dev || !rng_state || nbranch <= 0 || samples <= 0 || rows_per_sample <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(droppath_scales_kernel, dim3(grid_for((long)nbranch * samples * rows_per_sample)), dim3(256), 0,
+                       (hipStream_t)stream, out, rates_dev, nbranch, samples, rows_per_sample, rng_state, site0);
     return sais_check_launch();
 }

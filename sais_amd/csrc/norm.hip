@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy16, long lddy
                                                      const float* x, long ldx, const float* mean, const float* rstd,
                                                      const float* gamma, const float* dres, long lddres, int rows,
                                                      float* dx32, long lddx32, bf16* dx16, long lddx16,
-                                                     float* dgamma, float* dbeta) {
+                                                     float* dgamma, float* dbeta, const float* rowscale16) {
     __shared__ float red[2][8][D];
     const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
     float gm[12], ag[12], ab[12];
@@ -119,7 +119,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy16, long lddy
             for (int i = 0; i < 12; ++i) dy[i] += t[i];
         }
         if (dx32) store_f32(dx32 + (size_t)row * lddx32, l32, dy);
-        if (dx16) store_bf16(dx16 + (size_t)row * lddx16, l32, dy);
+        if (dx16) {
+            if (rowscale16) {                                      // DropPath: the next branch's backward sees s dx
+                const float sc = rowscale16[row];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) dy[i] *= sc;
+            }
+            store_bf16(dx16 + (size_t)row * lddx16, l32, dy);
+        }
     }
     if (dgamma) {
 #pragma unroll
@@ -154,7 +161,8 @@ extern "C" int sais_layernorm_fwd(const float* x, long ldx, int rows, int dim, c
 extern "C" int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float* dy_f32, long lddy32, const float* x,
                                   long ldx, const float* mean, const float* rstd, const float* gamma,
                                   const float* dres, long lddres, int rows, int dim, float* dx_f32, long lddx32,
-                                  void* dx_bf16, long lddx16, float* dgamma, float* dbeta, void* stream) {
+                                  void* dx_bf16, long lddx16, float* dgamma, float* dbeta, const float* rowscale16,
+                                  void* stream) {
     SAIS_ENTER();
     if (!x || !mean || !rstd || !gamma || dim != D || rows <= 0 || (!dy_bf16 && !dy_f32)) return SAIS_ERR_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SAIS_ERR_ARG;
@@ -162,6 +170,6 @@ extern "C" int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float*
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy_bf16, lddy16,
                        dy_f32, lddy32, x, ldx, mean, rstd, gamma, dres, lddres, rows, dx_f32, lddx32, (bf16*)dx_bf16,
-                       lddx16, dgamma, dbeta);
+                       lddx16, dgamma, dbeta, rowscale16);
     return sais_check_launch();
 }

@@ -68,14 +68,15 @@ def _chk(t, dtype, name):
         raise L.SaisHipError(f"{name}: innermost dimension must be contiguous")
 
 
-def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0, 0, 0)):
-    """out[M,N] = a[M,K] . w[N,K]^T (+epilogue).  a, w bf16 2-D (row stride free)."""
-    _chk(a, BF16, "A"); _chk(w, BF16, "B"); _chk(bias, F32, "bias")
+def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0, 0, 0), rowscale=None):
+    """out[M,N] = a[M,K] . w[N,K]^T (+epilogue).  a, w bf16 2-D (row stride free).  rowscale f32 [M] (EPI_BIAS_RESID_F32
+    only): out = aux + rowscale[m] * (acc + bias), the DropPath form of the residual add."""
+    _chk(a, BF16, "A"); _chk(w, BF16, "B"); _chk(bias, F32, "bias"); _chk(rowscale, F32, "rowscale")
     M = a.shape[0] if M is None else M
     N, K = w.shape
     g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
                    _p(out), out.stride(-2), _p(out2), 0 if out2 is None else out2.stride(-2),
-                   _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2])
+                   _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2], _p(rowscale))
     nbytes = 2 * (M * K + N * K) + out.element_size() * M * N
     _timed(f"gemm_nt<{_NT_NAMES[epilogue]}>[N{N},K{K}]", 2.0 * M * N * K, nbytes,
            lambda: L.call("sais_gemm_nt", ctypes.byref(g), _stream()))
@@ -89,7 +90,7 @@ def _ld(t):
     return 0 if t is None else t.stride(-2)
 
 
-def gemm_ln_fwd(a, w, bias, resid, x_out, xn_out, gamma, beta, eps, mean=None, rstd=None):
+def gemm_ln_fwd(a, w, bias, resid, x_out, xn_out, gamma, beta, eps, mean=None, rstd=None, rowscale=None):
     """x_out f32[M,384] = a[M,K] . w[384,K]^T + bias + resid ;  xn_out bf16 = LayerNorm(x_out) ; mean/rstd saved.
     One launch (LayerNorm in the GEMM epilogue); resid and x_out may be the same tensor."""
     _chk(a, BF16, "A"); _chk(w, BF16, "W"); _chk(bias, F32, "bias"); _chk(resid, F32, "resid")
@@ -99,13 +100,13 @@ def gemm_ln_fwd(a, w, bias, resid, x_out, xn_out, gamma, beta, eps, mean=None, r
         raise L.SaisHipError(f"gemm_ln_fwd: W must be [384,{K}], got {tuple(w.shape)}")
     g = L.SaisGemmLn(_p(a), a.stride(0), _p(w), w.stride(0), M, K, _p(bias), _p(resid), _ld(resid), _p(x_out),
                      _ld(x_out), _p(xn_out), _ld(xn_out), _p(gamma), _p(beta), eps, _p(mean), _p(rstd), None, 0,
-                     None, None)
+                     None, None, _p(rowscale), None)
     nbytes = 2 * (M * K + 384 * K) + M * 384 * (4 + 4 + 2)
     _timed(f"gemm_ln_fwd[N384,K{K}]", 2.0 * M * 384 * K, nbytes,
            lambda: L.call("sais_gemm_ln_fwd", ctypes.byref(g), _stream()))
 
 
-def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dgamma=None, dbeta=None):
+def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dgamma=None, dbeta=None, rowscale16=None):
     """dy = a[M,K] . w[384,K]^T, then LayerNorm backward at the saved input x / mean / rstd:
     dx = dres + dLN(dy) -> dx32 (f32) and/or dx16 (bf16); dgamma / dbeta accumulated.  dres may alias dx32."""
     _chk(a, BF16, "A"); _chk(w, BF16, "W"); _chk(x, F32, "x"); _chk(dres, F32, "dres"); _chk(dx32, F32, "dx32")
@@ -115,7 +116,7 @@ def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dga
         raise L.SaisHipError(f"gemm_ln_bwd: W must be [384,{K}], got {tuple(w.shape)}")
     g = L.SaisGemmLn(_p(a), a.stride(0), _p(w), w.stride(0), M, K, None, _p(x), _ld(x), _p(dx32), _ld(dx32),
                      _p(dx16), _ld(dx16), _p(gamma), None, 0.0, _p(mean), _p(rstd), _p(dres), _ld(dres),
-                     _p(dgamma), _p(dbeta))
+                     _p(dgamma), _p(dbeta), None, _p(rowscale16))
     nbytes = 2 * (M * K + 384 * K) + M * 384 * (4 + 4 + 4 + 2)
     _timed(f"gemm_ln_bwd[N384,K{K}]", 2.0 * M * 384 * K, nbytes,
            lambda: L.call("sais_gemm_ln_bwd", ctypes.byref(g), _stream()))
@@ -185,10 +186,11 @@ def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None,
 
 
 def layernorm_bwd(x, ldx, mean, rstd, gamma, rows, dy16=None, dy32=None, dres=None, dx32=None, dx16=None,
-                  dgamma=None, dbeta=None, lddy16=384, lddy32=384, lddres=384, lddx32=384, lddx16=384):
+                  dgamma=None, dbeta=None, lddy16=384, lddy32=384, lddres=384, lddx32=384, lddx16=384, rowscale16=None):
     _chk(dy16, BF16, "dy16"); _chk(dy32, F32, "dy32"); _chk(dx16, BF16, "dx16"); _chk(dx32, F32, "dx32")
     L.call("sais_layernorm_bwd", _p(dy16), lddy16, _p(dy32), lddy32, _p(x), ldx, _p(mean), _p(rstd), _p(gamma),
-           _p(dres), lddres, rows, 384, _p(dx32), lddx32, _p(dx16), lddx16, _p(dgamma), _p(dbeta), _stream())
+           _p(dres), lddres, rows, 384, _p(dx32), lddx32, _p(dx16), lddx16, _p(dgamma), _p(dbeta), _p(rowscale16),
+           _stream())
 
 
 def vit_attn_fwd(qkv, frames, out, lse=None, probs=None):
@@ -295,6 +297,19 @@ def dropout(x, p, rng, site, resid=None, out=None):
     out = x if out is None else out
     L.call("sais_dropout_f32", _p(x), _p(resid), _p(out), x.numel(), float(p), _p(rng), site, _stream())
     return out
+
+
+def droppath_scales(rates_dev, samples, rows_per_sample, rng, site0=0):
+    """f32 [nbranch, samples * rows_per_sample]: per-row keep / (1 - rate) of every DropPath branch (one draw per sample)."""
+    nb = rates_dev.numel()
+    out = torch.empty(nb, samples * rows_per_sample, dtype=F32, device=rates_dev.device)
+    L.call("sais_droppath_scales", _p(out), _p(rates_dev), nb, samples, rows_per_sample, _p(rng), site0, _stream())
+    return out
+
+
+def cast_bf16_rows(src, rowscale, dst):
+    _chk(src, F32, "src"); _chk(rowscale, F32, "rowscale"); _chk(dst, BF16, "dst")
+    L.call("sais_cast_bf16_rows", _p(src), _p(rowscale), _p(dst), src.shape[0], src.shape[1], _stream())
 
 
 def dropout_mask(n, p, rng, site, device):

@@ -12,10 +12,10 @@ transposed LDS reads, recompute-from-LSE attention backward); parameter gradient
 by the kernels directly into the flat gradient buffer that p.grad views.
 
 Deliberate differences from the reference (documented in DESIGN.md): only the ViT-S/16 @224
-geometry is supported; DropPath (stochastic depth, train() only: DINO pre-training; SAIS itself only ever runs the ViT
-in eval(), extract_representations.py:279,340,362) is not built: `drop_path_rate` is accepted, is the identity in eval()
-exactly as in the reference, and a train()-mode forward with `drop_path_rate > 0` RAISES instead of silently training a
-different model.
+geometry is supported.  DropPath (stochastic depth, vision_transformer.py:27-46: train() only, per-sample keep with
+rates linspace(0, drop_path_rate, depth); SAIS itself only ever runs the ViT in eval(), extract_representations.py:
+279,340,362) is applied in the epilogues of the residual GEMMs as a per-row scale; the keep draws come from Philox
+(`drop_path_seed`, this library's stream, not torch's): `last_droppath_scales` holds what a forward used.
 """
 import torch
 import torch.nn as nn
@@ -90,7 +90,10 @@ class VisionTransformer(nn.Module):
             raise NotImplementedError("the MI355X kernels implement the ViT-S/16 @224 geometry only")
         self.num_features = self.embed_dim = embed_dim
         self.depth = depth
-        self.drop_path_rate = drop_path_rate        # identity in eval(); train() with a rate > 0 raises (module doc)
+        self.drop_path_rate = drop_path_rate        # identity in eval(); per-sample stochastic depth in train()
+        self.drop_path_seed = 0
+        self._rng = None
+        self.last_droppath_scales = None
         self.patch_embed = _PatchEmbed()
         self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
         self.pos_embed = nn.Parameter(torch.zeros(1, NTOK, D))
@@ -151,9 +154,6 @@ class VisionTransformer(nn.Module):
 
     # ------------------------------------------------------------------ public API (reference signatures)
     def forward(self, x):
-        if self.training and self.drop_path_rate > 0:
-            raise NotImplementedError("DropPath (vision_transformer.py:27-46) is not implemented on the MI355X path: "
-                                      "call .eval() (what SAIS does) or build the ViT with drop_path_rate=0 to train it")
         x = self._check_input(x)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in (self.cls_token, self.norm.weight))
         self._engine(x.device)
@@ -193,6 +193,19 @@ class VisionTransformer(nn.Module):
         # FOLLOWING LayerNorm in their epilogue (sais_gemm_ln_fwd): proj -> norm2, fc2 -> the next block's norm1.
         # Only block 0's norm1 and the final norm remain stand-alone launches.
         fused = M >= ops.ROW_GEMM_MIN_M
+        # DropPath (train mode): row scales keep_f / (1 - p_i) for the 2 x depth residual branches, one Philox draw per
+        # frame and branch; branch 2i = attention of block i, 2i + 1 = its MLP.  None in eval() / rate 0.
+        dp = None
+        if self.training and self.drop_path_rate > 0 and not want_last_attn:
+            if self._rng is None or self._rng.device != dev:
+                self._rng = ops.rng_state(self.drop_path_seed, dev)
+                rates = torch.linspace(0, self.drop_path_rate, self.depth).repeat_interleave(2)      # :150
+                self._dp_rates = rates.to(dev, torch.float32)
+            ops.rng_advance(self._rng)
+            dp = ops.droppath_scales(self._dp_rates, Fr, NTOK, self._rng)
+            self.last_droppath_scales = dp
+        if saved is not None:
+            saved["dp"] = dp
         xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
         xn2 = e16(M, D)
         mean1 = rstd1 = None
@@ -217,12 +230,14 @@ class VisionTransformer(nn.Module):
                 xn2 = e16(M, D)
             mean2 = e32(M) if save else None
             rstd2 = e32(M) if save else None
+            rs_attn = None if dp is None else dp[2 * i]
+            rs_mlp = None if dp is None else dp[2 * i + 1]
             if fused:
                 ops.gemm_ln_fwd(ao, f.w(p + "attn.proj.weight"), f.w32(p + "attn.proj.bias"), x, x_mid, xn2,
-                                f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, mean2, rstd2)
+                                f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, mean2, rstd2, rowscale=rs_attn)
             else:
                 ops.gemm_nt(ao, f.w(p + "attn.proj.weight"), L.EPI_BIAS_RESID_F32, x_mid,
-                            bias=f.w32(p + "attn.proj.bias"), aux=x)
+                            bias=f.w32(p + "attn.proj.bias"), aux=x, rowscale=rs_attn)
                 ops.layernorm_fwd(x_mid, M, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2,
                                   mean=mean2, rstd=rstd2)
             u = e16(M, HID) if save else None
@@ -236,10 +251,10 @@ class VisionTransformer(nn.Module):
                 if save:
                     xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
                 ops.gemm_ln_fwd(h, f.w(p + "mlp.fc2.weight"), f.w32(p + "mlp.fc2.bias"), x_mid, x_out, xn,
-                                f.w32(q + "norm1.weight"), f.w32(q + "norm1.bias"), 1e-6, mean1, rstd1)
+                                f.w32(q + "norm1.weight"), f.w32(q + "norm1.bias"), 1e-6, mean1, rstd1, rowscale=rs_mlp)
             else:
                 ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"),
-                            aux=x_mid)
+                            aux=x_mid, rowscale=rs_mlp)
             if save:
                 saved["blocks"].append(blk)
             x = x_out
@@ -264,7 +279,13 @@ class VisionTransformer(nn.Module):
         dxa, dxb = e16(M, D), e16(M, D)            # bf16 copies of the residual-stream gradient (block input / mid)
         ops.layernorm_bwd(saved["x_final"], NTOK * D, saved["meanN"], saved["rstdN"], f.w32("norm.weight"), Fr,
                           dy32=dreps, dx32=dx, lddx32=NTOK * D, dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
-        ops.cast_bf16(dx, dxa)
+        dp = saved.get("dp")
+        # with DropPath the gradient that enters a branch is s dx (the residual stream keeps dx): the bf16 copies carry the
+        # NEXT branch's scale — dxa feeds an MLP branch (2i + 1), dxb an attention branch (2i)
+        if dp is None:
+            ops.cast_bf16(dx, dxa)
+        else:
+            ops.cast_bf16_rows(dx, dp[2 * (self.depth - 1) + 1], dxa)
         fused = M >= ops.ROW_GEMM_MIN_M
         dxn, dao, du, dqkv = (None if fused else e16(M, D)), e16(M, D), e16(M, HID), e16(M, 3 * D)
         delta = torch.empty(Fr, HEADS, NTOK, dtype=torch.float32, device=dev)
@@ -273,16 +294,19 @@ class VisionTransformer(nn.Module):
         for i in reversed(range(self.depth)):
             p = f"blocks.{i}."
             s = saved["blocks"][i]
+            rs_attn = None if dp is None else dp[2 * i]                        # this block's attention branch
+            rs_prev = None if dp is None or i == 0 else dp[2 * (i - 1) + 1]     # the MLP branch of block i - 1
             # MLP branch
             ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
             if fused:         # dX of fc1 with norm2's backward (+ residual gradient) in its epilogue
                 ops.gemm_ln_bwd(du, f.wt16[p + "mlp.fc1.weight"], s["x_mid"], s["mean2"], s["rstd2"],
                                 f.w32(p + "norm2.weight"), dres=dx, dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"),
-                                dbeta=f.g(p + "norm2.bias"))
+                                dbeta=f.g(p + "norm2.bias"), rowscale16=rs_attn)
             else:
                 ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
                 ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
-                                  dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"))
+                                  dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"),
+                                  rowscale16=rs_attn)
             # attention branch
             ops.gemm_nt(dxb, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
             ops.vit_attn_bwd(s["qkv"], dao, s["ao"], s["lse"], delta, Fr, dqkv)
@@ -296,11 +320,12 @@ class VisionTransformer(nn.Module):
             if fused:         # dX of qkv with norm1's backward in its epilogue
                 ops.gemm_ln_bwd(dqkv, f.wt16[p + "attn.qkv.weight"], s["x_in"], s["mean1"], s["rstd1"],
                                 f.w32(p + "norm1.weight"), dres=dx, dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"),
-                                dbeta=f.g(p + "norm1.bias"))
+                                dbeta=f.g(p + "norm1.bias"), rowscale16=rs_prev)
             else:
                 ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn)
                 ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,
-                                  dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"))
+                                  dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"),
+                                  rowscale16=rs_prev)
             saved["blocks"][i] = None
             if self.grad_ready_hook:                  # the block's gradient slice is final: DP all-reduce may start
                 self.grad_ready_hook(*self.block_grad_range(i))

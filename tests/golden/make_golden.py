@@ -546,13 +546,68 @@ def golden_dropout(prepare_model, misc, out):
     print("dropout.npz: loss", loss.item(), "|emb - emb_eval|max", float((emb.detach() - e0).abs().max()))
 
 
+DROPPATH_CASE = dict(frames=6, depth=4, rate=0.3, mask_seed=930, x_seed=931)
+DROPPATH_GRADS = ("cls_token", "patch_embed.proj.bias", "blocks.0.attn.qkv.bias", "blocks.1.norm1.weight",
+                  "blocks.1.attn.proj.weight", "blocks.2.mlp.fc1.bias", "blocks.2.norm2.bias", "blocks.3.mlp.fc2.weight",
+                  "blocks.3.attn.qkv.weight", "norm.weight")
+
+
+def golden_droppath(vits, out):
+    """The reference ViT in TRAIN mode with DropPath (vision_transformer.py:27-46) fed from synth.droppath_factors: the
+    module-level drop_path() is replaced by a function that pops the next per-sample factor vector, in call order
+    (block 1 attention, block 1 MLP, block 2 ...: block 0 has rate 0 and an nn.Identity).  A 4-block ViT with rate 0.3 so
+    that several frames are actually dropped; loss = sum(features * fixed weights)."""
+    c = DROPPATH_CASE
+    Fn, depth, rate = c["frames"], c["depth"], c["rate"]
+    from functools import partial
+    # vit_small (:243-247) with fewer blocks: its own constructor call pins depth = 12
+    model = vits.VisionTransformer(patch_size=16, embed_dim=384, depth=depth, num_heads=6, mlp_ratio=4, qkv_bias=True,
+                                   norm_layer=partial(nn.LayerNorm, eps=1e-6), drop_path_rate=rate)
+    model.load_state_dict(synth.vit_state_dict(seed=0, depth=depth), strict=True)
+    model.train()
+    fac = synth.droppath_factors(c["mask_seed"], Fn, depth, rate)
+    queue = [fac[j] for j in range(2, 2 * depth)]                   # rows 0, 1 belong to block 0 (Identity)
+    real = vits.drop_path
+
+    def fed(x, drop_prob=0., training=False):
+        if drop_prob == 0. or not training:
+            return x
+        f = queue.pop(0)
+        assert set((f * (1 - drop_prob)).round().tolist()) <= {0.0, 1.0}
+        return x * f.view(-1, *([1] * (x.ndim - 1)))
+
+    vits.drop_path = fed
+    try:
+        x = synth.clips(seed=c["x_seed"], B=1, T=Fn)[0]
+        w = synth.reps(seed=c["x_seed"] + 1, B=1, T=Fn)[0, 0]        # [Fn, 384] fixed loss weights
+        feat = model(x)
+        (feat * w).sum().backward()
+    finally:
+        vits.drop_path = real
+    assert not queue
+    g = {"feat": feat.detach().numpy(), "factors": fac.numpy()}
+    P = dict(model.named_parameters())
+    for n in DROPPATH_GRADS:
+        gr = P[n].grad
+        g["grad/" + n] = (gr.flatten()[::97] if gr.numel() > 20000 else gr).numpy()
+        g["gnorm/" + n] = np.array(gr.norm().item())
+    model.eval()
+    with torch.no_grad():
+        g["feat_eval"] = model(x).numpy()
+    np.savez_compressed(os.path.join(out, "droppath.npz"), **g)
+    print("droppath.npz: dropped", int((fac == 0).sum()), "of", fac.numel(), " |feat - feat_eval|max",
+          float(np.abs(g["feat"] - g["feat_eval"]).max()))
+
+
 def main():
     torch.set_num_threads(8)
     vits, prepare_model, misc = import_reference()
     if len(sys.argv) > 2 and sys.argv[1] == "--only":
-        {"dropout": lambda: golden_dropout(prepare_model, misc, HERE)}[sys.argv[2]]()
+        {"dropout": lambda: golden_dropout(prepare_model, misc, HERE),
+         "droppath": lambda: golden_droppath(vits, HERE)}[sys.argv[2]]()
         return
     golden_dropout(prepare_model, misc, HERE)
+    golden_droppath(vits, HERE)
     golden_vit(vits, HERE)
     golden_temporal(prepare_model, misc, HERE)
     golden_collate(HERE)

@@ -181,3 +181,12 @@ def dropout_masks(seed, Bn, S, nlayers=T_LAYERS, p=0.1):
     g = _gen(seed)
     k = lambda *sh: torch.rand(sh, generator=g) >= p
     return [dict(attn=k(Bn, T_HEADS, S, S), d1=k(Bn, S, T_DIM), ff=k(Bn, S, T_FF), d2=k(Bn, S, T_DIM)) for _ in range(nlayers)]
+
+
+def droppath_factors(seed, frames, depth=VIT_DEPTH, rate=0.1):
+    """[2 * depth, frames] DropPath factors keep / (1 - p_i) (p_i = linspace(0, rate, depth)[i], vision_transformer.py:150):
+    row 2i = attention branch of block i, 2i + 1 = its MLP branch.  Block 0 has p = 0 (always 1)."""
+    g = _gen(seed)
+    rates = torch.linspace(0, rate, depth).repeat_interleave(2)
+    keep = torch.rand((2 * depth, frames), generator=g) >= rates.view(-1, 1)
+    return keep.float() / (1.0 - rates).view(-1, 1)

@@ -180,3 +180,64 @@ def test_graph_replays_draw_fresh_masks_and_match_eager(ops):
     le = float(step())
     assert le == l2
     assert rel_l2(m.flat.grad, g_graph) <= 1e-5
+
+
+# ------------------------------------------------------------------ DropPath (stochastic depth) of the ViT blocks
+def _vit(depth, rate):
+    from sais_amd.vit import vit_small
+    v = vit_small(patch_size=16, drop_path_rate=rate, depth=depth)
+    v.load_state_dict(synth.vit_state_dict(seed=0, depth=depth), strict=True)
+    return v.to(DEV)
+
+
+@pytest.mark.parametrize("frames,depth", [(6, 4), (48, 2)])          # M = 1182: stand-alone kernels; M = 9456: LN-fused row GEMMs
+def test_droppath_train_mode_vs_oracle_with_the_same_draws(ops, frames, depth):
+    """vision_transformer.py:27-46,105-113 in train(): per-sample keep / (1 - p_i) on both residual branches, forward and
+    backward.  The draws are this library's (Philox): the per-row scales a forward used are exported, reduced to per-sample
+    factors and handed to the oracle, whose DropPath arithmetic is pinned against the reference (droppath.npz)."""
+    from oracle import sais_oracle as O
+    rate = 0.3
+    vit = _vit(depth, rate).train()
+    vit.drop_path_seed = 11
+    x = synth.clips(seed=931, B=1, T=frames)[0]
+    w = synth.reps(seed=932, B=1, T=frames)[0, 0]
+    feat = vit(x.to(DEV))
+    (feat * w.to(DEV)).sum().backward()
+    sc = vit.last_droppath_scales                                       # [2 * depth, frames * 197]
+    assert tuple(sc.shape) == (2 * depth, frames * 197)
+    per = sc.view(2 * depth, frames, 197)
+    assert bool((per == per[:, :, :1]).all())                           # one draw per sample, shared by its 197 rows
+    fac = per[:, :, 0].cpu()
+    rates = torch.linspace(0, rate, depth).repeat_interleave(2)
+    for j in range(2 * depth):
+        vals = set(round(float(v), 5) for v in fac[j].unique())
+        assert vals <= {0.0, round(1.0 / (1.0 - float(rates[j])), 5)}, (j, vals)
+    assert bool((fac[:2] == 1).all()) and float((fac == 0).sum()) >= 1  # block 0: p = 0; something was dropped
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0, depth=depth).items()}
+    ref = O.vit_forward(sd, x, depth=depth, droppath=fac)
+    (ref * w).sum().backward()
+    assert (feat.detach().cpu() - ref.detach()).abs().max().item() <= 3e-2 * ref.detach().abs().max().item()
+    bad = {n: rel_l2(q.grad, sd[n].grad) for n, q in vit.named_parameters()}
+    bad = {k: v for k, v in bad.items() if v > 6e-2}
+    assert not bad, bad
+    # a dropped branch sends nothing into its parameters' gradients from that sample: with every sample dropped on one
+    # branch the branch's weights get exactly zero — checked through the scales themselves: all-zero rows exist only by
+    # chance, so check the forward instead: eval() ignores the rate
+    with torch.no_grad():
+        e1 = vit.eval()(x.to(DEV))
+        e0 = _vit(depth, 0.0).eval()(x.to(DEV))
+    assert torch.equal(e1, e0) and (feat.detach() - e1).abs().max().item() > 0.05
+
+
+def test_droppath_draws_are_fresh_per_forward_and_bernoulli(ops):
+    from sais_amd.vit import vit_small
+    rates = torch.tensor([0.0, 0.0, 0.25, 0.25, 0.5, 0.5], device=DEV)
+    st = ops.rng_state(5, DEV)
+    a = ops.droppath_scales(rates, 4096, 3, st)
+    assert tuple(a.shape) == (6, 4096 * 3)
+    keep = (a.view(6, 4096, 3)[:, :, 0] > 0).float().mean(1).cpu()
+    for j, p in enumerate([0.0, 0.0, 0.25, 0.25, 0.5, 0.5]):
+        assert abs(float(keep[j]) - (1 - p)) < 4 * math.sqrt(max(p * (1 - p), 1e-9) / 4096) + 1e-9, (j, float(keep[j]))
+    assert not torch.equal(a[2], a[3])                                  # branches are independent draws
+    ops.rng_advance(st)
+    assert not torch.equal(a, ops.droppath_scales(rates, 4096, 3, st))

@@ -58,3 +58,31 @@ def test_oracle_train_mode_dropout_matches_reference():
         e1, _ = O.temporal_forward(sd, x, f, pad, pad, "RGB-Flow", drop=ones, p=0.0)
         e0, _ = O.temporal_forward(sd, x, f, pad, pad, "RGB-Flow")
     assert torch.equal(e0, e1) and np.abs(e0.numpy() - g["emb_eval"]).max() < 2e-5
+
+
+def test_oracle_train_mode_droppath_matches_reference():
+    """droppath.npz: the reference ViT (4 blocks, rate 0.3) in train() with synth.droppath_factors injected into its
+    drop_path(): features and parameter gradients."""
+    g = np.load(os.path.join(HERE, "golden", "droppath.npz"))
+    Fn, depth, rate = 6, 4, 0.3
+    fac = synth.droppath_factors(930, Fn, depth, rate)
+    assert np.array_equal(fac.numpy(), g["factors"]) and float((fac == 0).sum()) >= 5 and bool((fac[:2] == 1).all())
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0, depth=depth).items()}
+    x = synth.clips(seed=931, B=1, T=Fn)[0]
+    w = synth.reps(seed=932, B=1, T=Fn)[0, 0]
+    feat = O.vit_forward(sd, x, depth=depth, droppath=fac)
+    (feat * w).sum().backward()
+    assert np.abs(feat.detach().numpy() - g["feat"]).max() < 2e-4
+    assert np.abs(g["feat"] - g["feat_eval"]).max() > 0.5
+    for k in g.files:
+        if not k.startswith("grad/"):
+            continue
+        n = k[5:]
+        got, want = sd[n].grad, g[k]
+        if got.numel() != want.size:
+            assert abs(got.norm().item() - float(g["gnorm/" + n])) <= 1e-3 * max(1.0, float(g["gnorm/" + n])), n
+            got = got.flatten()[::97]
+        err = np.abs(got.numpy().reshape(want.shape) - want).max()
+        assert err <= 1e-3 * max(1.0, np.abs(want).max()), (n, err)
+    with torch.no_grad():
+        assert np.abs(O.vit_forward(sd, x, depth=depth).numpy() - g["feat_eval"]).max() < 2e-4
