@@ -216,10 +216,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # SAIS_BENCH_BACKEND=gloo (tests only): the ranks exchange through the host and may share a GPU, so the whole N > 1
+    # control flow of this file (every rank's collectives in the same order, rank 0's JSON line) runs on a 1-GPU box
+    backend = os.environ.get("SAIS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         world = dist.get_world_size()                    # what RCCL actually formed
 
     import synth
@@ -297,13 +305,17 @@ def main():
             raise SystemExit(f"bench.py: hipGraph replay loss {lg!r} != eager loss {le!r} from the same weights")
 
     # instrumented pass (outside the timed region): HIP events around every MFMA kernel launch
+    # With N > 1 a step contains collectives (gradient all-reduces from the backward hooks), so EVERY rank runs these
+    # passes; only rank 0 brackets its kernels with events.
     roof = None
+    NPASS = 3
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
-        NPASS = 3
+    if rank == 0 or dist_on:
         for _ in range(NPASS):
             eager_step()
         torch.cuda.synchronize()
+    if rank == 0:
         summ = ops.TIMER.summary()
         ops.TIMER = None
         fam = {}

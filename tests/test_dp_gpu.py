@@ -162,3 +162,23 @@ def test_bench_distributed_branch_with_world_size_one():
     assert line["n_gpus"] == 1 and line["config"]["launch"] == "eager"
     assert 100e6 < line["comm"]["allreduce_bytes_per_step"] < 140e6       # 30.45 M touched params x 4 B
     assert line["comm"]["exposed_comm_ms_per_step"] >= 0
+
+
+def test_bench_two_ranks_complete_and_print_one_line(tmp_path):
+    """The N > 1 control flow of bench.py end to end on this 1-GPU box: two ranks under torch.distributed.run, exchanging
+    through gloo (SAIS_BENCH_BACKEND, tests only) and sharing the GPU — every rank must issue the same collectives in the
+    same order (a rank-0-only eager pass with all-reduces in it would hang here), rank 0 prints the one JSON line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    env = dict(os.environ, SAIS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "2", "--frames", "8"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["comm"]["allreduce_bytes_per_step"] > 80e6 and d["value"] > 0 and d["roofline"]["all_kernels"]
