@@ -63,8 +63,12 @@ class GradSync:
             return
         model, T = self._temporal
         self._temporal = None
-        Tmax = max(T or 0, getattr(model, "_touched_T", 0))
+        touched = getattr(model, "_touched_T", 0)
         model._touched_T = 0
+        # every rank must hand all_reduce the SAME slices: a caller that knows the (common) stream length passes T; without
+        # it, or if a longer stream turned up on this rank, all 2000 position rows go (3 MB) rather than a rank-dependent
+        # count
+        Tmax = T if (T is not None and touched <= T) else 2000
         for a, b in self.temporal_ranges(model, Tmax):
             self._reduce(model.flat.grad[a:b])
 

@@ -140,7 +140,10 @@ def load_dataloaders(root_path, dataset_name, batch_size, phases, domain, encode
         rows = by_phase[phase]
         train = phase in ("train", "train+val")
         if train and world_size > 1:
-            rows = rows[rank::world_size]                      # data parallel: a strided shard of the windows per rank
+            # data parallel: a strided shard of the windows per rank, padded by wrapping around (DistributedSampler's
+            # rule) so that every rank runs the same number of batches — the gradient all-reduces are collective
+            total = -(-len(rows) // world_size) * world_size
+            rows = (rows + rows[:total - len(rows)])[rank::world_size]
         ds = GestureWindows(rows, rgb, flow, classes, phase, domain)
         g = torch.Generator().manual_seed(seed)
         loaders[phase] = torch.utils.data.DataLoader(ds, batch_size=batch_size, shuffle=train, drop_last=False,
@@ -243,7 +246,7 @@ def single_epoch(rank, world_size, dataloader, model_dict, optimizer, device, ph
             xl = xlens[0] if is_list else xlens
             importance_list.append([imp[:, 1:n + 1, :].squeeze() for imp, n in zip(output_importances.detach(), xl)])
         bsz = snippets[0].shape[0] if is_list else snippets.shape[0]
-        running_loss += float(loss) * bsz
+        running_loss += float(loss.detach()) * bsz
         nitems += bsz
     ave_loss = running_loss / max(len(dataloader[phase].dataset), 1)
     snip_sequence_list = lists if is_list else lists[0]

@@ -127,7 +127,7 @@ def _dp_worker(rank, world, port, out):
     # (the temporal hook fires once per backward CALL — three times with TTA list inputs — but the slices must be
     # exchanged ONCE, over the longest stream seen: a second all-reduce would double-count the remote gradients)
     m._touched_T = T
-    th = sync.temporal_hook(m)
+    th = sync.temporal_hook(m, T)
     th(0, m.flat.numel)
     th(0, m.flat.numel)
     hook = sync.vit_hook(vit)

@@ -93,3 +93,48 @@ def test_run_experiments_cli_trains(tmp_path):
                        capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "All Info Saved!" in r.stdout and os.path.exists(os.path.join(root, "params", "Fold_0", "params"))
+
+
+def _dp_train_worker(rank, world, port, root, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sais_amd import train as T
+    # both ranks share cuda:0 here, so the device index trainModel derives from its `rank` argument is 0 for both; the data
+    # shard is the true rank's (passed in as a ready dataloader) and each rank writes into its own directory
+    loaders, _ = T.load_dataloaders(root, "Custom_Gestures", 4, ["train", "val"], "in_vs_out", "ViT_SelfSupervised_ImageNet",
+                                    rank, world, seed=0)
+    savepath = os.path.join(root, "params", f"Fold_0_r{rank}")
+    torch.manual_seed(0)
+    hist = T.trainModel(0, world, root, savepath, "Custom_Gestures", "reps", 4, 2, "in_vs_out", ["train", "val"], 0.1,
+                        "RGB-Flow", False, False, "Prototypes", True, False, False, "None", True, False, "ViT",
+                        "ViT_SelfSupervised_ImageNet", 5, 1, 0, 384, 2, 0, 1, dataloader=loaders)
+    torch.save(dict(hist=hist, ntrain=len(loaders["train"])), out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_completes_with_replicas_in_step(tmp_path):
+    """trainModel with world_size 2 (two ranks on this GPU, gloo): an ODD number of training windows (the shards are padded to
+    equal length, every rank runs the same number of collective steps), averaged gradients — the job must finish and both
+    ranks must see the same validation losses (= the same weights after every epoch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    root = str(tmp_path / "SAIS")
+    _project(root, nvid=4, nframes=330)
+    ann = os.path.join(root, "paths", "Custom_Gestures_Annotations.csv")
+    lines = open(ann).read().strip().split("\n")
+    train_rows = [i for i, l in enumerate(lines) if l.endswith(",train")]
+    if len(train_rows) % 2 == 0:
+        del lines[train_rows[-1]]
+    open(ann, "w").write("\n".join(lines) + "\n")
+    assert sum(1 for l in lines if l.endswith(",train")) % 2 == 1
+    out = str(tmp_path / "hist.pt")
+    mp.spawn(_dp_train_worker, args=(2, 29800 + os.getpid() % 100, root, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    assert r0["ntrain"] == r1["ntrain"]                          # same number of batches = same number of collectives
+    h0, h1 = r0["hist"], r1["hist"]
+    assert len(h0["loss"]) == 2 and all(np.isfinite(v) for v in h0["loss"])
+    assert np.allclose(h0["loss"], h1["loss"], rtol=0, atol=1e-6), (h0["loss"], h1["loss"])
