@@ -9,6 +9,9 @@ cd $R
 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json | head -c 300; echo
+# the distributed branch of bench.py over RCCL with a world of one (RCCL init, hook all-reduces, barriers, max-over-ranks)
+SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline > $O/force_dist_world1.log 2>&1; tail -c 400 $O/force_dist_world1.log | head -c 200; echo
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/stats.log 2>&1
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph"
