@@ -3,6 +3,7 @@ C ABI) against a plain fp32 torch reference of the same op on the same seeded in
 bf16 operands are generated in bf16 first, so the only differences are accumulation order
 (fp32 in both) and the final bf16 rounding where the output is bf16."""
 import math
+import os
 
 import pytest
 import torch
@@ -476,3 +477,21 @@ def test_gemm_ln_bwd(ops, M, K):
     dx_only = torch.empty(M, 384, device=DEV)
     ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dx32=dx_only)
     assert_close(dx_only, xr.grad, atol=2e-4 * scale, rtol=1e-4, name="dx (no dres)")
+
+
+def test_integration_md_ctypes_stub_runs_as_written(ops):
+    """The ctypes binding shown in INTEGRATION.md (what a SAIS maintainer would paste) is executed verbatim: the struct
+    layout in the document must match include/sais_hip.h, and the call must give fc1 + GELU."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch.*?)```", md, re.S).group(1)
+    code = code.replace('ctypes.CDLL("sais_amd/libsais_hip.so")', f'ctypes.CDLL("{os.path.join(root, "sais_amd", "libsais_hip.so")}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    x = rnd(300, 384, seed=1, dtype=torch.bfloat16)
+    w = rnd(1536, 384, seed=2, scale=0.05, dtype=torch.bfloat16)
+    b = rnd(1536, seed=3, scale=0.1)
+    out = ns["linear_gelu"](x, w, b)
+    ref = F.gelu(x.float() @ w.float().t() + b)
+    assert_close(out.float(), ref, atol=2e-2, rtol=2e-2)
