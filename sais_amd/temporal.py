@@ -346,12 +346,13 @@ class fullModel(nn.Module):
             ops.temporal_attn_bwd(a["qkv"], s["pad"], B, S, dctx, dqkv, p_drop=pd, rng=rng, site=site)
             dz = e32(M, D)                                    # = dy1 (residual) + dqkv . Win
             ops.gemm_nt_f32(dqkv, fl.wt16[p + "self_attn.in_proj_weight"], L.EPI_BIAS_RESID_F32, dz, aux=dy1)
-            # the four weight / bias gradients of the layer in one launch (M is a few hundred rows: launch-bound)
+            # the four weight / bias gradients of the layer in one launch (M is a few hundred rows: launch-bound); one M-split:
+            # every workgroup owns its output tile and accumulates without atomics
             ops.gemm_tn_grouped([
                 (dt2, a["h"], fl.g(p + "linear2.weight"), fl.g(p + "linear2.bias")),
                 (dh, a["z1"], fl.g(p + "linear1.weight"), fl.g(p + "linear1.bias")),
                 (dt1, a["ctx"], fl.g(p + "self_attn.out_proj.weight"), fl.g(p + "self_attn.out_proj.bias")),
-                (dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))], M, nsplit=2)
+                (dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))], M, nsplit=1)
         x = s["x"]
         dx = torch.empty_like(x) if need_dx else None
         self._touched_T = max(self._touched_T, T)

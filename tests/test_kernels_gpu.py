@@ -495,3 +495,21 @@ def test_integration_md_ctypes_stub_runs_as_written(ops):
     out = ns["linear_gelu"](x, w, b)
     ref = F.gelu(x.float() @ w.float().t() + b)
     assert_close(out.float(), ref, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("nsplit", [1, 2])
+def test_gemm_tn_grouped_f32_accumulates_owned_or_atomic(ops, nsplit):
+    """The temporal encoder's dW launch (fp32 operands, M = a few hundred rows): one M-split = every workgroup owns its
+    tile (plain read-add-write), more = atomics; both must ADD to what dW / db already hold."""
+    M = 264
+    shapes = [(384, 2048), (2048, 384), (384, 384), (1152, 384)]
+    items, refs = [], []
+    for i, (n1, n2) in enumerate(shapes):
+        p, q = rnd(M, n1, seed=300 + i), rnd(M, n2, seed=310 + i)
+        dW, db = rnd(n1, n2, seed=320 + i), rnd(n1, seed=330 + i)
+        refs.append((dW.clone() + p.bfloat16().float().t() @ q.bfloat16().float(), db.clone() + p.bfloat16().float().sum(0)))
+        items.append((p, q, dW, db))
+    ops.gemm_tn_grouped(items, M, nsplit=nsplit)
+    for (p, q, dW, db), (rw, rb) in zip(items, refs):
+        assert_close(dW, rw, atol=2e-3 * math.sqrt(M), rtol=1e-4)
+        assert_close(db, rb, atol=1e-3 * math.sqrt(M))
