@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 4
+#define SAIS_ABI_VERSION 5
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -60,6 +60,11 @@ typedef struct SaisGemm {
     int grp_in, grp_out, grp_off;  /* SAIS_EPI_PATCH_F32 only            */
     const float* rowscale;         /* SAIS_EPI_BIAS_RESID_F32 only, optional: DropPath (vision_transformer.py:27-46,111,113)
                                       out = aux + rowscale[m] * (acc + bias), rowscale[m] = keep / (1 - p) of row m's sample */
+    /* sais_gemm_nt_f32 only: train-mode dropout of the temporal encoder layer fused into the epilogue (p_drop = 0: none);
+     * mask element = m * N + n of site `site` (see sais_dropout_f32):  _BIAS_RESID_F32: out = aux + drop(acc + bias)
+     * (dropout1 / dropout2);  _BIAS_RELU_F32: out = drop(relu(acc + bias)) (the FFN dropout);  _DRELU_F32: out =
+     * drop(acc) where aux > 0 (its backward, same site).                                                          */
+    float p_drop; const unsigned long long* rng_state; unsigned site;
 } SaisGemm;
 
 int sais_gemm_nt(const SaisGemm* g, void* stream);
@@ -140,7 +145,9 @@ int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float* dy_f32, lo
                        const float* mean, const float* rstd, const float* gamma, const float* dres, long lddres,
                        int rows, int dim, float* dx_f32, long lddx32, void* dx_bf16, long lddx16, float* dgamma,
                        float* dbeta, const float* rowscale16 /*optional: dx_bf16 = bf16(rowscale16[row] * dx), DropPath*/,
-                       void* stream);
+                       float* dx_f32_drop /*optional, ld = lddx32: dropout(dx) with mask element row * 384 + col of `site`:
+                       the gradient that enters a dropped branch of the temporal encoder layer*/,
+                       float p_drop, const unsigned long long* rng_state, unsigned site, void* stream);
 
 /* ---------------------------------------------------------------- ViT spatial attention (197 tokens, 6 heads x 64)
  * Attention.forward core, vision_transformer.py:83-90: softmax(q k^T / 8) v per (frame, head).

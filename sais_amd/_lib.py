@@ -20,7 +20,8 @@ class SaisGemm(ctypes.Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("epilogue", c_int),
                 ("bias", c_void_p), ("out", c_void_p), ("ldo", c_int),
                 ("out2", c_void_p), ("ldo2", c_int), ("aux", c_void_p), ("ldaux", c_int),
-                ("grp_in", c_int), ("grp_out", c_int), ("grp_off", c_int), ("rowscale", c_void_p)]
+                ("grp_in", c_int), ("grp_out", c_int), ("grp_off", c_int), ("rowscale", c_void_p),
+                ("p_drop", c_float), ("rng_state", c_void_p), ("site", ctypes.c_uint)]
 
 
 class SaisTnItem(ctypes.Structure):
@@ -57,7 +58,7 @@ SIGNATURES = {
                            c_long, c_void_p, c_void_p, c_void_p],
     "sais_layernorm_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
-                           c_void_p, c_void_p],
+                           c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
     "sais_vit_attn_fwd": [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
     "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p,
                           c_long, c_void_p],

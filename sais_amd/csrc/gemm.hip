@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "../../include/sais_hip.h"
 #include "gemm_nt_epi.hpp"
+#include "philox.hpp"
 
 namespace {
 
@@ -367,7 +368,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 // 16-contiguous-columns-per-lane epilogue as the bf16 kernel.
 template <int EPI>
 DEVINL void epilogue_f32(const NtParams& p, int m, int n, const float (&v)[16]) {
-    float y[16];
     if (p.grp_in > 1) {
         // split-K: raw partial sums go to the workspace slab of this split; splitk_reduce_kernel applies the epilogue
         float* o = (float*)p.out2 + ((size_t)blockIdx.z * p.M + m) * p.N + n;
@@ -375,23 +375,40 @@ DEVINL void epilogue_f32(const NtParams& p, int m, int n, const float (&v)[16]) 
         for (int i = 0; i < 4; ++i) *(f32x4*)(o + 4 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
         return;
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) y[i] = v[i] + (p.bias ? p.bias[n + i] : 0.f);
-    if constexpr (EPI == SAIS_EPI_BIAS_RELU_F32) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) y[i] = fmaxf(y[i], 0.f);
-    } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
-        const float* r = (const float*)p.aux + (size_t)m * p.ldaux + n;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) y[i] += r[i];
-    } else if constexpr (EPI == SAIS_EPI_DRELU_F32) {
-        const float* u = (const float*)p.aux + (size_t)m * p.ldaux + n;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) y[i] = u[i] > 0.f ? y[i] : 0.f;
-    }
+    // four columns at a time (the dropout draws would otherwise push the 64-accumulator kernel into scratch).
+    // Train-mode dropout of the encoder layer, fused: relu -> dropout (FFN), dropout -> + residual (dropout1 / dropout2),
+    // and in the backward drelu -> the same FFN mask.
+    const bool dropping = p.p_drop > 0.f;
+    const unsigned thr = drop_threshold(p.p_drop);
+    const float inv = dropping ? 1.0f / (1.0f - p.p_drop) : 1.0f;
     float* o = (float*)p.out + (size_t)m * p.ldo + n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(f32x4*)(o + 4 * i) = f32x4{y[4 * i], y[4 * i + 1], y[4 * i + 2], y[4 * i + 3]};
+    for (int q = 0; q < 4; ++q) {
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * q + j;
+            t[j] = v[i] + (p.bias ? p.bias[n + i] : 0.f);
+        }
+        f32x4 keep = {1.f, 1.f, 1.f, 1.f};
+        if (dropping) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                keep[j] = philox_keep(p.rng, p.site, (unsigned long long)m * p.N + n + 4 * q + j, thr) ? inv : 0.f;
+        }
+        if constexpr (EPI == SAIS_EPI_BIAS_RELU_F32) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = fmaxf(t[j], 0.f) * keep[j];
+        } else if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
+            const f32x4 r = *(const f32x4*)((const float*)p.aux + (size_t)m * p.ldaux + n + 4 * q);
+            t = t * keep + r;
+        } else if constexpr (EPI == SAIS_EPI_DRELU_F32) {
+            const f32x4 u = *(const f32x4*)((const float*)p.aux + (size_t)m * p.ldaux + n + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = u[j] > 0.f ? t[j] * keep[j] : 0.f;
+        }
+        *(f32x4*)(o + 4 * q) = t;
+    }
 }
 
 DEVINL void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
@@ -971,22 +988,30 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
 // out[m][n] = epilogue( sum_z ws[z][m][n] + bias[n] , aux[m][n] )  — second half of the split-K fp32 GEMM
 template <int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int ks, int M, int N, const float* bias,
-                                                            const float* aux, int ldaux, float* out, int ldo) {
+                                                            const float* aux, int ldaux, float* out, int ldo, float p_drop,
+                                                            const unsigned long long* rng, unsigned site) {
     const int n4 = N >> 2;
+    const unsigned thr = drop_threshold(p_drop);
+    const float inv = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)M * n4; i += (long)gridDim.x * 256) {
         const int m = i / n4, n = (i - (long)m * n4) * 4;
         f32x4 y = *(const f32x4*)(ws + (size_t)m * N + n);
         for (int z = 1; z < ks; ++z) y += *(const f32x4*)(ws + ((size_t)z * M + m) * N + n);
         if (bias) y += *(const f32x4*)(bias + n);
-        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) y += *(const f32x4*)(aux + (size_t)m * ldaux + n);
+        f32x4 keep = {1.f, 1.f, 1.f, 1.f};
+        if (p_drop > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep[j] = philox_keep(rng, site, (unsigned long long)m * N + n + j, thr) ? inv : 0.f;
+        }
+        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) y = y * keep + *(const f32x4*)(aux + (size_t)m * ldaux + n);
         if constexpr (EPI == SAIS_EPI_BIAS_RELU_F32) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+            for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f) * keep[j];
         }
         if constexpr (EPI == SAIS_EPI_DRELU_F32) {
             const f32x4 u = *(const f32x4*)(aux + (size_t)m * ldaux + n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = u[j] > 0.f ? y[j] : 0.f;
+            for (int j = 0; j < 4; ++j) y[j] = u[j] > 0.f ? y[j] * keep[j] : 0.f;
         }
         *(f32x4*)(out + (size_t)m * ldo + n) = y;
     }
@@ -996,7 +1021,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
     case E:                                                                                                       \
         hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3(rgrid), dim3(256), 0, (hipStream_t)stream,              \
                            (const float*)g->out2, ks, g->M, g->N, g->bias, (const float*)g->aux, g->ldaux,        \
-                           (float*)g->out, g->ldo);                                                               \
+                           (float*)g->out, g->ldo, g->p_drop, g->rng_state, g->site);                             \
         break;
 
 #define LAUNCH_NT32(E)                                                                            \
@@ -1009,7 +1034,9 @@ extern "C" int sais_gemm_nt_f32(const SaisGemm* g, void* stream) {
     if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
     if (g->M <= 0 || g->N % BN || g->K % BK || g->lda % 4 || g->ldb % 4 || g->ldo % 4) return SAIS_ERR_ARG;
     NtParams p{(const bf16*)g->A, (const bf16*)g->B, g->lda, g->ldb, g->M, g->N, g->K, g->bias,
-               g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, 1, 0, 0};
+               g->out, g->ldo, g->out2, g->ldo2, g->aux, g->ldaux, 1, 0, 0, nullptr, g->p_drop, g->rng_state, g->site};
+    if (g->p_drop < 0.f || g->p_drop >= 1.f || (g->p_drop > 0.f && (!g->rng_state || g->epilogue == SAIS_EPI_BIAS_F32)))
+        return SAIS_ERR_ARG;
     dim3 grid(g->N / BN, (g->M + BM - 1) / BM);
     // Few output tiles (M = clips*(T+1) rows): split K over gridDim.z into the caller's workspace (out2 = f32
     // [ldo2][M][N], ldo2 = number of splits) and finish with a tiny reduce+epilogue kernel, so that dozens of CUs

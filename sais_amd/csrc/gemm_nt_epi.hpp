@@ -15,6 +15,8 @@ struct NtParams {
     const void* aux; int ldaux;
     int grp_in, grp_out, grp_off;
     const float* rowscale;          // SAIS_EPI_BIAS_RESID_F32, small-M kernel only (DropPath)
+    // fp32 GEMM (temporal encoder) only: train-mode dropout fused into the epilogue, mask element = m * N + n
+    float p_drop; const unsigned long long* rng; unsigned site;
 };
 
 // Eight-wave tile: the 128x128x64 tile and LDS image of gemm_nt_kernel, but 512 threads (2 x 4 waves of

@@ -5,6 +5,7 @@
 //             (prepare_model.py:74-81; eps 1e-5).
 //   backward: autograd of the same.
 #include "common.hpp"
+#include "philox.hpp"
 #include "../../include/sais_hip.h"
 
 namespace {
@@ -18,6 +19,7 @@ DEVINL float half_sum(float v) {          // reduce over the 32 lanes of a half-
     return v;
 }
 
+DEVINL int col_of(int l32, int i) { return 128 * (i >> 2) + 4 * l32 + (i & 3); }      // column of register i of lane l32
 DEVINL void load_f32(const float* p, int l32, float (&v)[12]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy16, long lddy
                                                      const float* x, long ldx, const float* mean, const float* rstd,
                                                      const float* gamma, const float* dres, long lddres, int rows,
                                                      float* dx32, long lddx32, bf16* dx16, long lddx16,
-                                                     float* dgamma, float* dbeta, const float* rowscale16) {
+                                                     float* dgamma, float* dbeta, const float* rowscale16, float* dx32_drop,
+                                                     float p_drop, const unsigned long long* rng, unsigned site) {
     __shared__ float red[2][8][D];
     const int l32 = threadIdx.x & 31, hw = threadIdx.x >> 5;
     float gm[12], ag[12], ab[12];
@@ -119,6 +122,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* dy16, long lddy
             for (int i = 0; i < 12; ++i) dy[i] += t[i];
         }
         if (dx32) store_f32(dx32 + (size_t)row * lddx32, l32, dy);
+        if (dx32_drop) {                                           // dropout backward of the branch this gradient enters
+            const unsigned thr = drop_threshold(p_drop);
+            const float inv = 1.0f / (1.0f - p_drop);
+            float t[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                t[i] = philox_keep(rng, site, (unsigned long long)row * D + col_of(l32, i), thr) ? dy[i] * inv : 0.f;
+            store_f32(dx32_drop + (size_t)row * lddx32, l32, t);
+        }
         if (dx16) {
             if (rowscale16) {                                      // DropPath: the next branch's backward sees s dx
                 const float sc = rowscale16[row];
@@ -162,14 +174,16 @@ extern "C" int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float*
                                   long ldx, const float* mean, const float* rstd, const float* gamma,
                                   const float* dres, long lddres, int rows, int dim, float* dx_f32, long lddx32,
                                   void* dx_bf16, long lddx16, float* dgamma, float* dbeta, const float* rowscale16,
+                                  float* dx_f32_drop, float p_drop, const unsigned long long* rng_state, unsigned site,
                                   void* stream) {
     SAIS_ENTER();
     if (!x || !mean || !rstd || !gamma || dim != D || rows <= 0 || (!dy_bf16 && !dy_f32)) return SAIS_ERR_ARG;
     if ((dgamma == nullptr) != (dbeta == nullptr)) return SAIS_ERR_ARG;
+    if (dx_f32_drop && (!rng_state || p_drop <= 0.f || p_drop >= 1.f)) return SAIS_ERR_ARG;
     int grid = (rows + 7) / 8;
     if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy_bf16, lddy16,
                        dy_f32, lddy32, x, ldx, mean, rstd, gamma, dres, lddres, rows, dx_f32, lddx32, (bf16*)dx_bf16,
-                       lddx16, dgamma, dbeta, rowscale16);
+                       lddx16, dgamma, dbeta, rowscale16, dx_f32_drop, p_drop, rng_state, site);
     return sais_check_launch();
 }

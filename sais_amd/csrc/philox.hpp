@@ -22,7 +22,8 @@ DEVINL unsigned philox_u32(const unsigned long long* state, unsigned sid, unsign
         philox_round(c, k0, k1);
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return c[idx & 3];
+    const unsigned k = (unsigned)idx & 3u;                        // (a dynamic index would put c[] into scratch memory)
+    return k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3];
 }
 
 // p in [0, 1): threshold on the raw 32-bit draw; p = 0 keeps everything

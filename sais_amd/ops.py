@@ -76,7 +76,7 @@ def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0,
     N, K = w.shape
     g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
                    _p(out), out.stride(-2), _p(out2), 0 if out2 is None else out2.stride(-2),
-                   _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2], _p(rowscale))
+                   _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2], _p(rowscale), 0.0, None, 0)
     nbytes = 2 * (M * K + N * K) + out.element_size() * M * N
     _timed(f"gemm_nt<{_NT_NAMES[epilogue]}>[N{N},K{K}]", 2.0 * M * N * K, nbytes,
            lambda: L.call("sais_gemm_nt", ctypes.byref(g), _stream()))
@@ -122,8 +122,9 @@ def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dga
            lambda: L.call("sais_gemm_ln_bwd", ctypes.byref(g), _stream()))
 
 
-def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None):
-    """fp32-operand variant (bf16x3 split on the matrix cores): out f32[M,N] = a f32[M,K] . w f32[N,K]^T."""
+def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None, drop=None):
+    """fp32-operand variant (bf16x3 split on the matrix cores): out f32[M,N] = a f32[M,K] . w f32[N,K]^T.
+    drop = (p, rng_state, site): train-mode dropout fused into the epilogue (include/sais_hip.h, SaisGemm.p_drop)."""
     _chk(a, F32, "A"); _chk(w, F32, "B"); _chk(bias, F32, "bias"); _chk(out, F32, "out"); _chk(aux, F32, "aux")
     M = a.shape[0] if M is None else M
     N, K = w.shape
@@ -138,7 +139,9 @@ def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None):
         ws = torch.empty(ks, M, N, dtype=F32, device=a.device)
     g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
                    _p(out), out.stride(-2), _p(ws), ks if ws is not None else 0, _p(aux),
-                   0 if aux is None else aux.stride(-2), 0, 0, 0)
+                   0 if aux is None else aux.stride(-2), 0, 0, 0, None,
+                   0.0 if drop is None else float(drop[0]), None if drop is None else _p(drop[1]),
+                   0 if drop is None else int(drop[2]))
     _timed(f"gemm_nt_f32x3<{_NT_NAMES[epilogue]}>", 2.0 * M * N * K, 4 * (M * K + N * K + M * N),
            lambda: L.call("sais_gemm_nt_f32", ctypes.byref(g), _stream()))
     return out
@@ -186,11 +189,15 @@ def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None,
 
 
 def layernorm_bwd(x, ldx, mean, rstd, gamma, rows, dy16=None, dy32=None, dres=None, dx32=None, dx16=None,
-                  dgamma=None, dbeta=None, lddy16=384, lddy32=384, lddres=384, lddx32=384, lddx16=384, rowscale16=None):
+                  dgamma=None, dbeta=None, lddy16=384, lddy32=384, lddres=384, lddx32=384, lddx16=384, rowscale16=None,
+                  dx32_drop=None, drop=None):
+    """dx32_drop (with drop = (p, rng_state, site)): a second fp32 output dropout(dx), same row stride as dx32."""
     _chk(dy16, BF16, "dy16"); _chk(dy32, F32, "dy32"); _chk(dx16, BF16, "dx16"); _chk(dx32, F32, "dx32")
+    _chk(dx32_drop, F32, "dx32_drop")
     L.call("sais_layernorm_bwd", _p(dy16), lddy16, _p(dy32), lddy32, _p(x), ldx, _p(mean), _p(rstd), _p(gamma),
            _p(dres), lddres, rows, 384, _p(dx32), lddx32, _p(dx16), lddx16, _p(dgamma), _p(dbeta), _p(rowscale16),
-           _stream())
+           _p(dx32_drop), 0.0 if drop is None else float(drop[0]), None if drop is None else _p(drop[1]),
+           0 if drop is None else int(drop[2]), _stream())
 
 
 def vit_attn_fwd(qkv, frames, out, lse=None, probs=None):

@@ -248,25 +248,18 @@ class fullModel(nn.Module):
             pd, rng = drop if drop is not None else (0.0, None)
             ops.temporal_attn_fwd(qkv, pad, B, S, ctx, attn if last else None, p_drop=pd, rng=rng, site=site)
             y1 = e32(M, D)
-            if drop is None:
-                ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_RESID_F32, y1,
-                                bias=fl.w32(p + "self_attn.out_proj.bias"), aux=z)
-            else:                                              # src + dropout1(out_proj(ctx))
-                ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_F32, y1,
-                                bias=fl.w32(p + "self_attn.out_proj.bias"))
-                ops.dropout(y1, pd, rng, site + 1, resid=z)
+            dsite = (lambda k: None if drop is None else (pd, rng, site + k))      # dropout fused into the GEMM epilogues
+            ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_RESID_F32, y1,
+                            bias=fl.w32(p + "self_attn.out_proj.bias"), aux=z, drop=dsite(1))   # src + dropout1(out_proj(ctx))
             z1, m1, r1 = e32(M, D), e32(M), e32(M)
             ops.layernorm_fwd(y1, M, D, fl.w32(p + "norm1.weight"), fl.w32(p + "norm1.bias"), 1e-5, y32=z1, mean=m1, rstd=r1)
             h = e32(M, FF)
-            ops.gemm_nt_f32(z1, fl.w32(p + "linear1.weight"), L.EPI_BIAS_RELU_F32, h, bias=fl.w32(p + "linear1.bias"))
+            # src + dropout2(linear2(dropout(relu(linear1(src)))))
+            ops.gemm_nt_f32(z1, fl.w32(p + "linear1.weight"), L.EPI_BIAS_RELU_F32, h, bias=fl.w32(p + "linear1.bias"),
+                            drop=dsite(2))
             y2 = e32(M, D)
-            if drop is None:
-                ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_RESID_F32, y2, bias=fl.w32(p + "linear2.bias"),
-                                aux=z1)
-            else:                                              # src + dropout2(linear2(dropout(relu(linear1(src)))))
-                ops.dropout(h, pd, rng, site + 2)
-                ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_F32, y2, bias=fl.w32(p + "linear2.bias"))
-                ops.dropout(y2, pd, rng, site + 3, resid=z1)
+            ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_RESID_F32, y2, bias=fl.w32(p + "linear2.bias"),
+                            aux=z1, drop=dsite(3))
             zo, m2, r2 = e32(M, D), e32(M), e32(M)
             ops.layernorm_fwd(y2, M, D, fl.w32(p + "norm2.weight"), fl.w32(p + "norm2.bias"), 1e-5, y32=zo, mean=m2, rstd=r2)
             if save:
@@ -320,26 +313,27 @@ class fullModel(nn.Module):
         for l in reversed(range(self.nlayers)):
             p = self._lnames(l)
             a = s["layers"][l]
-            dy2 = e32(M, D)
-            ops.layernorm_bwd(a["y2"], D, a["m2"], a["r2"], fl.w32(p + "norm2.weight"), M, dy32=dz, dx32=dy2,
-                              dgamma=fl.g(p + "norm2.weight"), dbeta=fl.g(p + "norm2.bias"))
-            # dropout backward = the same mask on the branch gradient (the residual path keeps the un-dropped one);
-            # a["h"] is the DROPPED relu output, so the drelu epilogue already zeroes the dropped units and the mask
-            # applied to dh afterwards only rescales the kept ones
+            # dropout backward = the same mask on the branch gradient (the residual path keeps the un-dropped one), fused:
+            # the LayerNorm backward emits dropout(dx) as a second output, and the drelu epilogue applies the FFN mask
+            # (a["h"] is the DROPPED relu output, so dropped units are already zero there: the mask rescales the kept ones)
             drop = s.get("drop")
             site = (s.get("sidx", 0) * self.nlayers + l) * 4
             pd, rng = drop if drop is not None else (0.0, None)
-            dt2 = dy2 if drop is None else ops.dropout(dy2, pd, rng, site + 3, out=e32(M, D))
+            dsite = (lambda k: None if drop is None else (pd, rng, site + k))
+            dy2 = e32(M, D)
+            dt2 = dy2 if drop is None else e32(M, D)
+            ops.layernorm_bwd(a["y2"], D, a["m2"], a["r2"], fl.w32(p + "norm2.weight"), M, dy32=dz, dx32=dy2,
+                              dgamma=fl.g(p + "norm2.weight"), dbeta=fl.g(p + "norm2.bias"),
+                              dx32_drop=None if drop is None else dt2, drop=dsite(3))
             dh = e32(M, FF)
-            ops.gemm_nt_f32(dt2, fl.wt16[p + "linear2.weight"], L.EPI_DRELU_F32, dh, aux=a["h"])
-            if drop is not None:
-                ops.dropout(dh, pd, rng, site + 2)
+            ops.gemm_nt_f32(dt2, fl.wt16[p + "linear2.weight"], L.EPI_DRELU_F32, dh, aux=a["h"], drop=dsite(2))
             dz1 = e32(M, D)                                   # = dy2 (residual) + dh . W1
             ops.gemm_nt_f32(dh, fl.wt16[p + "linear1.weight"], L.EPI_BIAS_RESID_F32, dz1, aux=dy2)
             dy1 = e32(M, D)
+            dt1 = dy1 if drop is None else e32(M, D)
             ops.layernorm_bwd(a["y1"], D, a["m1"], a["r1"], fl.w32(p + "norm1.weight"), M, dy32=dz1, dx32=dy1,
-                              dgamma=fl.g(p + "norm1.weight"), dbeta=fl.g(p + "norm1.bias"))
-            dt1 = dy1 if drop is None else ops.dropout(dy1, pd, rng, site + 1, out=e32(M, D))
+                              dgamma=fl.g(p + "norm1.weight"), dbeta=fl.g(p + "norm1.bias"),
+                              dx32_drop=None if drop is None else dt1, drop=dsite(1))
             dctx = e32(M, D)
             ops.gemm_nt_f32(dt1, fl.wt16[p + "self_attn.out_proj.weight"], L.EPI_BIAS_F32, dctx)
             dqkv = e32(M, 3 * D)
