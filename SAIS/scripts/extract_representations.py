@@ -18,6 +18,10 @@ from SAIS.scripts._features_io import save_reps  # noqa: E402
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # :148
 
 
+class FrameError(Exception):
+    """A frame this rank's shard cannot use.  Raised locally, reported collectively (every rank leaves together)."""
+
+
 def frame_batches(folder, dev, chunk=256, rank=0, world=1):
     """SurgDataset.__getitem__ (dino-main/main_dino.py:295-316) + the transform of :158-162, with the arithmetic on the
     GPU: JPEGs are decoded on the host (PIL), pushed as uint8 and turned into the float32 [n,3,224,224] ViT input by
@@ -40,7 +44,7 @@ def frame_batches(folder, dev, chunk=256, rank=0, world=1):
     for p in files[lo:hi]:
         with Image.open(p) as img:
             if img.mode != 'RGB':                    # the reference drops the result of img.convert('RGB') (:297)
-                raise SystemExit(f'{p}: mode {img.mode}; the pipeline expects RGB frames')
+                raise FrameError(f'{p}: mode {img.mode}; the pipeline expects RGB frames')
             a = np.asarray(img)
         if buf and (a.shape[:2] != geom or len(buf) == chunk):
             yield flush()
@@ -92,6 +96,7 @@ def main():
     fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 256), use_graph=True)
     reps = {}
     for v in videos:
+        err = None
         if args.synthetic_frames:
             g = torch.Generator().manual_seed(1 if flow else 0)
             n = max(1, args.synthetic_frames // 15) if flow else args.synthetic_frames     # flow maps: every 15th frame
@@ -100,9 +105,18 @@ def main():
             lo, hi = shard_range(n, rank, world)
             mine = fx(frames[lo:hi].to(dev)).cpu() if hi > lo else torch.empty(0, 384)
         else:
-            parts = [fx(b).cpu() for b in frame_batches(os.path.join(args.data_path, sub, v), dev, rank=rank, world=world)]
-            mine = torch.cat(parts) if parts else torch.empty(0, 384)
-        full = torch.cat(gather_in_rank_order(mine, world))           # rank order = frame order
+            try:
+                parts = [fx(b).cpu() for b in frame_batches(os.path.join(args.data_path, sub, v), dev, rank=rank, world=world)]
+                mine = torch.cat(parts) if parts else torch.empty(0, 384)
+            except FrameError as e:          # a rank-local failure: the other ranks are about to enter the gather below
+                err, mine = str(e), torch.empty(0, 384)
+        # the error flag travels WITH the payload, so that one rank's bad frame ends the job on every rank at once instead of
+        # leaving the others in all_gather_object until the process-group timeout
+        gathered = gather_in_rank_order((err, mine), world)
+        errs = [e for e, _ in gathered if e]
+        if errs:
+            raise SystemExit(errs[0])
+        full = torch.cat([m for _, m in gathered])                    # rank order = frame order
         if full.shape[0] == 0:
             raise SystemExit(f'no frames under {os.path.join(args.data_path, sub, v)}')
         reps[v] = full.numpy()

@@ -51,16 +51,25 @@ def main():
     if a.model != 'ViT' or a.task != 'Prototypes' or a.data_type != 'reps':
         raise SystemExit('this build covers -m ViT -t Prototypes -dt reps only (SURVEY.md §8)')
     if not a.inference:
+        from sais_amd.parallel import init_from_env
         from sais_amd.train import trainModel
+        # the reference pins world_size = 1 here (run_experiments.py:112, its DDP is commented out); under
+        # torch.distributed.run this CLI trains data-parallel: every rank a shard of the training windows, gradients
+        # exchanged by sais_amd.parallel.GradSync, rank 0 writes the files
+        rank, world, local = init_from_env()
         for domain in a.domains:
             for fold in range(a.nfolds):
                 savepath = os.path.join(a.path, 'params/Fold_%i' % fold)             # getSavepath :82-83
                 print('***** \n Savepath: %s \n *****' % savepath)
-                trainModel(a.local_rank, 1, a.path, savepath, a.dataset_name, a.data_type, a.batch_size, a.nclasses,
+                trainModel(local if world > 1 else a.local_rank, world, a.path, savepath, a.dataset_name, a.data_type,
+                           a.batch_size, a.nclasses,
                            domain, a.phases, a.learning_rate, a.modalities, a.freeze_encoder, False, a.task,
                            a.balance_classes, a.balance_groups, a.single_group, 'None', a.self_attention,
                            a.importance_loss, a.model, a.encoder_params, 5, 1, 0, a.rep_dim, a.nepochs, fold,
                            a.training_fraction)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         print('Time taken (s): %.3f' % (time.time() - t0))
         return
     if a.dataset_name != 'Custom_Gestures':
@@ -93,8 +102,9 @@ def main():
                     if video not in rgb or video not in flow:
                         raise SystemExit('no features for video %r in the reps files: run extract_representations.py '
                                          'for it first' % video)
-                    x = torch.from_numpy(rgb[video]).float().to(dev)
-                    f = torch.from_numpy(flow[video]).float().to(dev)
+                    # the feature files are memory-mapped (read-only views): one video at a time is copied to the GPU
+                    x = torch.tensor(rgb[video], dtype=torch.float32).to(dev)
+                    f = torch.tensor(flow[video], dtype=torch.float32).to(dev)
                     r, attn, imp = run_windows(md['model'], x, f, videoname=video, batch_size=a.batch_size,
                                                total_frames=total_frames, rank=rank, world_size=world)
                     for v in range(3):

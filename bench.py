@@ -47,7 +47,16 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="issue the launches of a step eagerly instead of "
-                                                              "replaying the captured hipGraph (N=1 only)")
+                                                              "replaying the captured hipGraph")
+    ap.add_argument("--two-stream", action="store_true",
+                    help="BASELINE config 4: RGB + optical-flow frames, 2 x clips x frames through the ViT, the temporal "
+                         "encoder once per stream, streams fused by add (modalities='RGB-Flow', prepare_model.py:412)")
+    ap.add_argument("--vit-drop-path", type=float, default=0.1,
+                    help="stochastic-depth rate of the ViT in train mode (the reference constructs it with 0.1: "
+                         "extract_representations.py:201, main_dino.py:57)")
+    ap.add_argument("--sustain-seconds", type=float, default=20.0,
+                    help="after the timed region, keep replaying the step for this long and report the settled rate "
+                         "(clock under sustained MFMA load); 0 = skip")
     return ap.parse_args()
 
 
@@ -68,15 +77,16 @@ def spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def build(dev, B, T, C, lr):
+def build(dev, B, T, C, lr, two_stream=False, drop_path=0.1):
     import torch
     from sais_amd.optim import SGD
     from sais_amd.temporal import fullModel
     from sais_amd.vit import vit_small
     torch.manual_seed(0)                                  # identical initial weights on every rank
-    vit = vit_small(patch_size=16, drop_path_rate=0.0)    # constructor init (trunc-normal .02), seed 0
+    vit = vit_small(patch_size=16, drop_path_rate=drop_path)   # constructor init (trunc-normal .02), seed 0
     vit = vit.to(dev).train()
-    model = fullModel('reps', C, 'in_vs_out', 384, 'ViT', modalities='RGB').to(dev).train()
+    vit.drop_path_seed = 7919 + int(os.environ.get("RANK", "0"))
+    model = fullModel('reps', C, 'in_vs_out', 384, 'ViT', modalities='RGB-Flow' if two_stream else 'RGB').to(dev).train()
     # train mode = the reference's: dropout 0.1 in the temporal encoder (prepare_model.py:75, train.py:59); every rank its
     # own mask stream
     model.dropout_seed = int(os.environ.get("RANK", "0"))
@@ -85,7 +95,8 @@ def build(dev, B, T, C, lr):
     return vit, model, protos, opt
 
 
-def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on=False, comm_events=None):
+def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on=False, comm_events=None,
+              two_stream=False):
     import torch
     from sais_amd.loss import calcNCELoss
     from sais_amd.loss import label_columns
@@ -95,23 +106,35 @@ def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, d
 
     def step():
         opt.zero_grad()
-        reps = vit(frames).view(B, 1, T, 384)
-        emb, attn = model(reps, None, lens, None, 'Prototypes', pad, None, None)
+        if two_stream:       # frames = [RGB clips | flow clips]: one ViT pass over 2 B T frames, one encoder pass per stream
+            reps = vit(frames).view(2, B, 1, T, 384)
+            emb, attn = model(reps[0], reps[1], lens, lens, 'Prototypes', pad, pad, None)
+        else:
+            reps = vit(frames).view(B, 1, T, 384)
+            emb, attn = model(reps, None, lens, None, 'Prototypes', pad, None, None)
         loss = calcNCELoss(0, emb, labels, names, protos, None)
         loss.backward()
         if dist_on:
             sync.reduce_params(protos.values())
-            if comm_events is not None:       # how long the compute stream stalls for the collectives = exposed comm time
+            if comm_events is not None and comm_events.enabled:   # compute-stream stall for the collectives = exposed comm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+                nlaunch = len(sync.pending)
                 nbytes = sync.wait()
                 e1.record()
-                comm_events.append((e0, e1, nbytes))
+                comm_events.recs.append((e0, e1, nbytes, nlaunch))
             else:
                 sync.wait()
         opt.step(grad_scale=1.0 / world)
         return loss
     return step
+
+
+class CommEvents:
+    """HIP-event brackets around the gradient-exchange join; only armed in the eager instrumented passes."""
+
+    def __init__(self):
+        self.enabled, self.recs = False, []
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -233,24 +256,30 @@ def main():
     import synth
     from sais_amd import ops
     B, T, C = args.clips, args.frames, 2
-    vit, model, protos, opt = build(dev, B, T, C, lr=0.1)
+    two = args.two_stream
+    vit, model, protos, opt = build(dev, B, T, C, lr=0.1, two_stream=two, drop_path=args.vit_drop_path)
     frames = synth.clips(seed=rank, B=B, T=T).view(B * T, 3, 224, 224).to(dev)     # resident in HBM
+    if two:      # the flow stream: seeded synthetic frames of the same shape (RAFT renders flow as RGB images, :62-67)
+        frames = torch.cat([frames, synth.clips(seed=1000 + rank, B=B, T=T).view(B * T, 3, 224, 224).to(dev)])
     pad = synth.padding_mask([T] * B).to(dev)
     labels = synth.labels(seed=rank, B=B, nclasses=C)
     from sais_amd.parallel import GradSync
     sync = GradSync(world, active=dist_on)
-    comm_events = [] if dist_on else None
-    step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on, comm_events)
+    comm_events = CommEvents() if dist_on else None
+    step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on, comm_events, two_stream=two)
     vit(frames[:2])                                          # builds the flat buffers
     model._engine(dev)
     vit.grad_ready_hook = sync.vit_hook(vit)
     model.grad_ready_hook = sync.temporal_hook(model, T)
 
     eager_step = step
-    use_graph = not dist_on and not args.no_graph
-    if use_graph:                                            # DP runs eagerly (RCCL collectives from hooks)
+    # ONE launch path for every N: the whole step — kernels AND, with N > 1, the per-block RCCL all-reduces that the
+    # backward hooks issue on ProcessGroupNCCL's stream (forked / joined with events, which the capture records as graph
+    # edges) — is captured into one hipGraph.  gloo (tests on a 1-GPU box) exchanges through the host: not capturable.
+    use_graph = not args.no_graph and (not dist_on or backend == "nccl")
+    if use_graph:
         from sais_amd.graph import GraphedStep
-        step = GraphedStep(eager_step, warmup=2)
+        step = GraphedStep(eager_step, warmup=2, capture_error_mode="thread_local" if dist_on else "global")
     for _ in range(args.warmup):
         loss = step()
 
@@ -261,8 +290,6 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    if comm_events is not None:
-        comm_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -272,30 +299,28 @@ def main():
         tmax = torch.tensor([dt], device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
-    comm = None
-    if comm_events:
-        comm = dict(allreduce_bytes_per_step=int(comm_events[-1][2]),
-                    exposed_comm_ms_per_step=round(sum(a.elapsed_time(b) for a, b, _ in comm_events) / len(comm_events), 3),
-                    payload="fp32 flat gradient slices, one all-reduce per ViT block issued from the backward hooks")
     timed_loss = float(loss.detach())
 
     # parity of the measured code path: one hipGraph replay and one eager step from the SAME weights and the same dropout
     # RNG state must give the same loss (the forward has no atomics, so this is exact up to nothing)
     graph_check = None
-    if use_graph and rank == 0:
-        snap = [vit.flat.flat.clone(), model.flat.flat.clone()] + [p.detach().clone() for p in protos.values()]
-        rng_snap = None if model._rng is None else model._rng.clone()       # train-mode dropout: same masks for both runs
+    snap = [vit.flat.flat.clone(), model.flat.flat.clone()] + [p.detach().clone() for p in protos.values()]
+    rng_snap = None if model._rng is None else model._rng.clone()       # train-mode dropout: same masks for both runs
+    dp_snap = None if vit._rng is None else vit._rng.clone()            # ... and the same DropPath draws
 
-        def restore():
-            with torch.no_grad():
-                if rng_snap is not None:
-                    model._rng.copy_(rng_snap)
-                vit.flat.flat.copy_(snap[0])
-                model.flat.flat.copy_(snap[1])
-                for p, s in zip(protos.values(), snap[2:]):
-                    p.copy_(s)
-            vit.flat.refresh_shadows(vit._t_names)
-            model.flat.refresh_shadows(model._t_names())
+    def restore():
+        with torch.no_grad():
+            if rng_snap is not None:
+                model._rng.copy_(rng_snap)
+            if dp_snap is not None:
+                vit._rng.copy_(dp_snap)
+            vit.flat.flat.copy_(snap[0])
+            model.flat.flat.copy_(snap[1])
+            for p, s in zip(protos.values(), snap[2:]):
+                p.copy_(s)
+        vit.flat.refresh_shadows(vit._t_names)
+        model.flat.refresh_shadows(model._t_names())
+    if use_graph and (rank == 0 or dist_on):      # N > 1: a step contains collectives, so every rank runs the check
         lg = float(step().detach())
         restore()
         le = float(eager_step().detach())
@@ -311,10 +336,22 @@ def main():
     NPASS = 3
     if rank == 0:
         ops.TIMER = ops.KernelTimer()
+    if comm_events is not None:
+        comm_events.enabled = True
     if rank == 0 or dist_on:
         for _ in range(NPASS):
             eager_step()
         torch.cuda.synchronize()
+    comm = None
+    if comm_events is not None and comm_events.recs:
+        r = comm_events.recs
+        comm = dict(allreduce_bytes_per_step=int(r[-1][2]), allreduce_launches_per_step=int(r[-1][3]),
+                    exposed_comm_ms_per_step=round(sum(a.elapsed_time(b) for a, b, _, _ in r) / len(r), 3),
+                    exposed_comm_measured_in="eager instrumented passes after the timed region (HIP events around the "
+                                             "join; events cannot be timed inside a captured graph)",
+                    payload_dtype="fp32",
+                    payload="flat gradient slices, one all-reduce per ViT block issued from the backward hooks, "
+                            "captured into the step's hipGraph" + ("" if use_graph else " (eager launch path)"))
     if rank == 0:
         summ = ops.TIMER.summary()
         ops.TIMER = None
@@ -345,28 +382,70 @@ def main():
                                          avg_us=round(v["avg_ms"] * 1e3, 1),
                                          tflops=round(v["flops"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
                                          gbps=round(v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9, 1)) for n, v in summ.items()})
+    # sustained rate (outside the metric): the timed region is a fraction of a second, so keep running the same step
+    # for >= --sustain-seconds and report what the chip settles at under sustained MFMA load.  The weights are put back to
+    # the snapshot before every chunk (untimed): a thousand SGD steps on random labels would otherwise drift to values
+    # whose arithmetic no longer costs what real data costs.
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_chunk = max(args.steps, 10)
+        ts0 = time.perf_counter()
+        last_dt, total = 0.0, 0
+        while True:
+            restore()
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            for _ in range(n_chunk):
+                step()
+            torch.cuda.synchronize()
+            last_dt = time.perf_counter() - tc
+            total += n_chunk
+            left = torch.tensor([args.sustain_seconds - (time.perf_counter() - ts0)], device=dev)
+            if dist_on:                                       # every rank leaves the loop in the same iteration
+                dist.all_reduce(left, op=dist.ReduceOp.MIN)
+            if left.item() <= 0:
+                break
+        tl = torch.tensor([last_dt], device=dev)
+        if dist_on:
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        sustained = dict(seconds=round(time.perf_counter() - ts0, 1), steps=total,
+                         frames_per_s=round(world * B * T * n_chunk / tl.item(), 1),
+                         note="rate of the LAST %d steps of a >= %.0f s back-to-back run of the same step" %
+                              (n_chunk, args.sustain_seconds))
     if dist_on:
         dist.barrier()
 
     if rank == 0:
         fps = world * B * T * args.steps / dt
-        step_flops = B * T * FLOP_PER_FRAME_FWD_BWD + B * FLOP_TEMPORAL_PER_CLIP
+        nstream = 2 if two else 1
+        step_flops = nstream * (B * T * FLOP_PER_FRAME_FWD_BWD + B * FLOP_TEMPORAL_PER_CLIP)
         if roof is not None:
-            roof["hbm_frac"] = round(B * T * HBM_BYTES_PER_FRAME * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)
-            roof["hbm_frac_note"] = "whole step: 133 MB/frame fused-plan algorithmic bytes / step time / 8 TB/s"
+            roof["hbm_frac"] = round(nstream * B * T * HBM_BYTES_PER_FRAME * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)
+            roof["hbm_frac_note"] = "MODEL-based: 133 MB/frame fused-plan algorithmic bytes / step time / 8 TB/s"
+            step_pmc = (load_pmc("pmc_traffic.json") or {}).get("_step", {}).get("step_hbm_bytes")
+            if step_pmc and not two and (B, T) == (8, 32):
+                roof["hbm_frac_counters"] = round(step_pmc * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)
+                roof["hbm_frac_counters_note"] = ("COUNTER-based: sum over kernel families of launches x PMC bytes per "
+                                                  "launch (profiles/pmc_traffic.json, collected offline on this config) "
+                                                  "/ this run's step time / 8 TB/s")
         out = {
             "metric": "frames/sec ViT-S/16 fwd+bwd, 224x224 32-frame clips",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: ViT-S/16 + 4-layer temporal encoder + SupCon prototype loss, "
-                                   f"fwd+bwd+SGD, {B} clips x {T} frames x 224x224 per GPU (global {world * B} clips), "
-                                   f"random-init weights, RGB stream", "clips_per_gpu": B, "frames_per_clip": T,
+            "config": {"workload": (f"BASELINE config 4 (two-stream): RGB + optical-flow frames, 2 x {B} x {T} frames through "
+                                    f"ViT-S/16, 4-layer temporal encoder per stream, fused by add, SupCon prototype loss, "
+                                    f"fwd+bwd+SGD; value counts the {B * T} RGB frames per step" if two else
+                                    f"BASELINE config 2: ViT-S/16 + 4-layer temporal encoder + SupCon prototype loss, "
+                                    f"fwd+bwd+SGD, {B} clips x {T} frames x 224x224 per GPU (global {world * B} clips), "
+                                    f"random-init weights, RGB stream"), "clips_per_gpu": B, "frames_per_clip": T,
+                       "streams": nstream, "vit_frames_per_step_per_gpu": nstream * B * T,
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
-                       "temporal_dropout": model.dropout_p},
+                       "temporal_dropout": model.dropout_p, "vit_drop_path": vit.drop_path_rate},
             "step_tflops": round(step_flops * world * args.steps / dt / 1e12, 1),
             "frac_of_mfma_roofline": round(step_flops * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "loss": round(timed_loss, 6),
+            "sustained": None if sustained is None else dict(sustained, ratio_to_value=round(sustained["frames_per_s"] / fps, 4)),
             "graph_vs_eager": graph_check,
             "comm": comm,
             "roofline": roof,

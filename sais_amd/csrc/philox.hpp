@@ -27,7 +27,8 @@ DEVINL unsigned philox_u32(const unsigned long long* state, unsigned sid, unsign
 }
 
 // p in [0, 1): threshold on the raw 32-bit draw; p = 0 keeps everything
-DEVINL unsigned drop_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967295.0f); }
+// (4294967040 = 2^32 - 256 is the largest fp32 below 2^32: the clamp keeps the float -> unsigned conversion defined)
+DEVINL unsigned drop_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967040.0f); }
 DEVINL bool philox_keep(const unsigned long long* state, unsigned sid, unsigned long long idx, unsigned thr) {
     return philox_u32(state, sid, idx) >= thr;
 }

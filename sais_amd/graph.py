@@ -9,8 +9,10 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, fn, warmup=3):
-        """fn() -> tensor (e.g. the loss); must read its inputs from tensors that outlive the graph."""
+    def __init__(self, fn, warmup=3, capture_error_mode="global"):
+        """fn() -> tensor (e.g. the loss); must read its inputs from tensors that outlive the graph.
+        capture_error_mode "thread_local": for steps that contain RCCL collectives (ProcessGroupNCCL's watchdog thread
+        makes HIP calls of its own while this thread captures)."""
         self.fn = fn
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -19,7 +21,7 @@ class GraphedStep:
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=capture_error_mode):
             self.out = fn()
 
     def __call__(self):

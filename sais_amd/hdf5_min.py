@@ -16,6 +16,7 @@ Pinned by tests/test_hdf5.py against a fixture written by libhdf5 1.10.6 itself 
 tests/golden/make_golden_h5.py) and, where libhdf5 is installed, by reading this writer's files back through it.
 Host-side I/O only: nothing here touches the GPU.
 """
+import os
 import struct
 
 import numpy as np
@@ -135,8 +136,13 @@ def write_h5(path, datasets):
 # ------------------------------------------------------------------------------------------------- reader
 class _File:
     def __init__(self, path):
+        # the file is MAPPED, not read: datasets come back as views of the mapping, so the resident footprint is the pages
+        # actually touched (the reference opens its feature files lazily too: h5py .get per item, prepare_dataset.py:1702)
+        import mmap
         with open(path, "rb") as fh:
-            self.b = fh.read()
+            if os.fstat(fh.fileno()).st_size == 0:
+                raise Hdf5FormatError(f"{path}: empty file")
+            self.b = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
         b = self.b
         base = -1
         off = 0
@@ -254,6 +260,14 @@ class _File:
             return np.dtype(order + ("i" if signed else "u") + str(size))
         raise Hdf5FormatError(f"unsupported datatype class {cls}")
 
+    def _view(self, pos, dt, n, dims):
+        """Contiguous dataset at file position `pos`: a read-only view of the mapping when the file's byte order is the
+        host's (no copy), a converted copy otherwise."""
+        if pos + n * dt.itemsize > len(self.b):
+            raise Hdf5FormatError("dataset extends past the end of the file")
+        a = np.frombuffer(self.b, dt, n, pos).reshape(dims)
+        return a if dt.isnative else a.astype(dt.newbyteorder("="))
+
     def dataset(self, haddr):
         msgs = self.messages(haddr)
         by = {}
@@ -271,7 +285,9 @@ class _File:
         if lay[0] == 3:
             if lay[1] == 1:
                 addr, size = struct.unpack_from("<QQ", lay, 2)
-                raw = b"" if addr == UNDEF else self.b[self.at(addr):self.at(addr) + n * dt.itemsize]
+                if addr != UNDEF:
+                    return self._view(self.at(addr), dt, n, dims)
+                raw = b""
             elif lay[1] == 0:
                 size, = struct.unpack_from("<H", lay, 2)
                 raw = lay[4:4 + size]
@@ -282,7 +298,7 @@ class _File:
             if cls != 1:
                 raise Hdf5FormatError("only contiguous version-1/2 layouts are supported")
             addr, = struct.unpack_from("<Q", lay, 8)
-            raw = self.b[self.at(addr):self.at(addr) + n * dt.itemsize]
+            return self._view(self.at(addr), dt, n, dims)
         else:
             raise Hdf5FormatError(f"layout message version {lay[0]} is not supported")
         if len(raw) < n * dt.itemsize:

@@ -65,10 +65,14 @@ class GradSync:
         self._temporal = None
         touched = getattr(model, "_touched_T", 0)
         model._touched_T = 0
-        # every rank must hand all_reduce the SAME slices: a caller that knows the (common) stream length passes T; without
-        # it, or if a longer stream turned up on this rank, all 2000 position rows go (3 MB) rather than a rank-dependent
-        # count
-        Tmax = T if (T is not None and touched <= T) else 2000
+        # every rank must hand all_reduce the SAME slices.  A caller that knows the stream length common to ALL ranks
+        # passes T (bench.py; trainModel agrees on it with one MAX all-reduce before the first epoch); without it all 2000
+        # position rows go (3 MB).  A longer stream than promised on this rank alone would make the collective sizes
+        # rank-dependent (a hang or corruption under RCCL), so it is an error, not a silent switch.
+        if T is not None and touched > T:
+            raise RuntimeError(f"GradSync: a stream of {touched} frames received gradients but the exchange was set up "
+                               f"for at most {T} (every rank must all-reduce identical slices)")
+        Tmax = T if T is not None else 2000
         for a, b in self.temporal_ranges(model, Tmax):
             self._reduce(model.flat.grad[a:b])
 
@@ -76,6 +80,30 @@ class GradSync:
         for p in params:
             if p.grad is not None:
                 self._reduce(p.grad)
+
+    def broadcast_initial_state(self, tensors, src=0):
+        """Replicas must START from the same weights: only gradients are exchanged afterwards.  Broadcasts every tensor
+        (flat parameter buffers, prototypes) from rank `src`; the caller refreshes its bf16 / transposed shadows."""
+        if not self.active:
+            return
+        for t in tensors:
+            dist.broadcast(t, src=src)
+
+    def agree_max(self, value, device):
+        """MAX of a host integer over the ranks (stream lengths, stop flags)."""
+        if not self.active:
+            return int(value)
+        t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
+
+    def mean_scalar(self, value, device):
+        """Mean of a host float over the ranks (the validation loss every rank bases its stop decision on)."""
+        if not self.active:
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        dist.all_reduce(t)
+        return float(t.item()) / self.world
 
     def wait(self):
         self.flush_temporal()

@@ -26,7 +26,6 @@ from collections import defaultdict
 
 import numpy as np
 import torch
-from torch.nn.utils.rnn import pad_sequence
 
 from . import _lib as L
 from .loss import calcImportanceLoss, calcNCELoss, cosine_logits_and_probs
@@ -37,52 +36,45 @@ TTA_OFFSETS = (0, 3, 6)
 
 
 # ------------------------------------------------------------------------------------------ collate (host)
+def pad_stream(seqs):
+    """Zero-pad a list of [nsnippets, T_b, ...] tensors along T to the batch maximum.
+    Returns (padded [B, nsnippets, Tmax, ...], key_padding_mask bool [B, nsnippets, Tmax + 1], lens).  Mask slot 0 is the
+    CLS token the temporal encoder prepends, slots lens[b] + 1 .. are the padding keys (True = masked): the contract of
+    the reference's createPaddingMask (prepare_dataset.py:2798-2806)."""
+    lens = [int(t.shape[1]) for t in seqs]
+    ns, tmax = max(int(t.shape[0]) for t in seqs), max(lens)
+    padded = seqs[0].new_zeros((len(seqs), ns, tmax) + tuple(seqs[0].shape[2:]))
+    mask = torch.arange(tmax + 1).expand(len(seqs), ns, tmax + 1) > torch.tensor(lens).view(-1, 1, 1)
+    for b, t in enumerate(seqs):
+        padded[b, :, :lens[b]] = t            # a clip with another snippet count than the batch's raises here
+    return padded, mask, lens
+
+
 def createPaddingMask(x, lens):
-    """prepare_dataset.py:2798-2806.  x: list of [nframes, nsnippets, dim]; True = masked key; slot 0 is the CLS token."""
-    nsnippets = max(el.shape[1] for el in x)
-    key_padding_mask = torch.zeros(len(x), nsnippets, max(lens) + 1).type(torch.bool)
-    for row, xlen in zip(range(key_padding_mask.shape[0]), lens):
-        key_padding_mask[row, :, xlen + 1:] = True
-    return key_padding_mask
+    """Reference signature (prepare_dataset.py:2798): x = list of [nframes, nsnippets, dim] tensors."""
+    ns = max(int(t.shape[1]) for t in x)
+    return torch.arange(max(lens) + 1).expand(len(x), ns, max(lens) + 1) > torch.tensor(list(lens)).view(-1, 1, 1)
 
 
 def pad_collate(batch):
-    """pad_collate, Prototypes branch (:2839-2899).  batch items: (videoname, snippets, flows, label, frames_importance,
-    domain) with snippets / flows either tensors [nsnippets, nframes, dim] (training) or tuples of 3 such tensors (TTA).
-    Returns the reference's 11-tuple: videoname, snippets_padded, flows_padded, frames_importance_padded, label,
-    snippets_lens, flows_lens, snippets_mask, flows_mask, frames_importance_mask, domains (dicts keyed 0/1/2 under TTA)."""
-    videoname, snippets, flows, label, frames_importance, domains = zip(*batch)
-    if isinstance(snippets[0], tuple):
-        snippets_lens, snippets_padded, snippets_mask = {}, {}, {}
-        flows_lens, flows_padded, flows_mask = {}, {}, {}
-        nbatch, nversions = len(snippets), len(snippets[0])
-        for i in range(nversions):
-            for src, lens_d, pad_d, mask_d in ((snippets, snippets_lens, snippets_padded, snippets_mask),
-                                               (flows, flows_lens, flows_padded, flows_mask)):
-                seq = [src[n][i] for n in range(nbatch)]
-                lens = [s.shape[1] for s in seq]
-                seq = [s.permute(1, 0, 2) for s in seq]                  # nframes x nsnippets x dim
-                mask_d[i] = createPaddingMask(seq, lens)
-                pad_d[i] = pad_sequence(seq, batch_first=True, padding_value=0).permute(0, 2, 1, 3)
-                lens_d[i] = lens
-        frames_importance_padded = torch.zeros(1, 1)                     # placeholders (:2873-2874)
-        frames_importance_mask = torch.zeros(1, 1)
+    """Collate of the Prototypes path (contract: prepare_dataset.py:2839-2899).  Items are (videoname, snippets, flows,
+    label, frames_importance, domain); snippets / flows are [nsnippets, T, dim] tensors (training) or tuples with one
+    such tensor per test-time-augmentation version.  Returns the 11-tuple the epoch loop unpacks: names, RGB batch, flow
+    batch, importance targets, labels, RGB lens, flow lens, RGB mask, flow mask, importance mask, domains — under TTA the
+    batch / lens / mask entries are dicts keyed by the version number and the importance entries are placeholders."""
+    names, rgb, flow, labels, importance, domains = zip(*batch)
+    if isinstance(rgb[0], tuple):
+        cols = {k: {} for k in ("xp", "xm", "xl", "fp", "fm", "fl")}
+        for v in range(len(rgb[0])):
+            cols["xp"][v], cols["xm"][v], cols["xl"][v] = pad_stream([item[v] for item in rgb])
+            cols["fp"][v], cols["fm"][v], cols["fl"][v] = pad_stream([item[v] for item in flow])
+        xp, xm, xl, fp, fm, fl = (cols[k] for k in ("xp", "xm", "xl", "fp", "fm", "fl"))
+        ip, im = torch.zeros(1, 1), torch.zeros(1, 1)
     else:
-        snippets_lens = [s.shape[1] for s in snippets]
-        flows_lens = [f.shape[1] for f in flows]
-        frames_importance = [i.permute(1, 0) for i in frames_importance]        # nframes x 1
-        snippets = [s.permute(1, 0, 2) for s in snippets]
-        flows = [f.permute(1, 0, 2) for f in flows]
-        snippets_mask = createPaddingMask(snippets, snippets_lens)
-        flows_mask = createPaddingMask(flows, flows_lens)
-        frames_importance_mask = createPaddingMask(frames_importance, snippets_lens)
-        snippets_padded = pad_sequence(snippets, batch_first=True, padding_value=0).permute(0, 2, 1, 3)
-        flows_padded = pad_sequence(flows, batch_first=True, padding_value=0).permute(0, 2, 1, 3)
-        frames_importance_padded = pad_sequence(frames_importance, batch_first=True, padding_value=0).permute(0, 2, 1)
-    videoname = [v for v in videoname]
-    label = torch.stack([l for l in label])
-    return (videoname, snippets_padded, flows_padded, frames_importance_padded, label, snippets_lens, flows_lens,
-            snippets_mask, flows_mask, frames_importance_mask, domains)
+        xp, xm, xl = pad_stream(list(rgb))
+        fp, fm, fl = pad_stream(list(flow))
+        ip, im, _ = pad_stream(list(importance))          # targets [1, T] per clip -> [B, 1, Tmax], mask [B, 1, Tmax + 1]
+    return list(names), xp, fp, ip, torch.stack(list(labels)), xl, fl, xm, fm, im, domains
 
 
 # ------------------------------------------------------------------------------------------ dataset (host)
@@ -280,8 +272,17 @@ def trainModel(rank, world_size, root_path, savepath, dataset_name, data_type, b
     sync = None
     if world_size > 1 and dist.is_initialized():
         sync = GradSync(world_size)
-        model["model"]._engine(device)
-        model["model"].grad_ready_hook = sync.temporal_hook(model["model"])
+        tm = model["model"]
+        tm._engine(device)
+        # loadModel draws the initial weights and prototypes from every process's own RNG (prepare_model.py:556-560 runs in
+        # one process): replicas must start from rank 0's, or the averaged gradients are applied to different parameters
+        with torch.no_grad():
+            sync.broadcast_initial_state([tm.flat.flat] + [p.data for p in model["prototypes"].values()])
+        tm._sig = None                                        # the bf16 / transposed shadows follow at the next forward
+        # longest window of any rank's shard: the position rows 0 .. T-1 are the only ones that receive gradients
+        tmax = max((_longest_window(dataloader[ph].dataset) for ph in phases if ph in ("train", "train+val")), default=0)
+        tmax = sync.agree_max(tmax, device)
+        tm.grad_ready_hook = sync.temporal_hook(tm, tmax if tmax > 0 else None)
     best_params_dict, best_prototypes_dict, reps_and_labels_dict = {}, {}, {}
     attention_dict, importance_dict = [], []
     metrics_dict = defaultdict(list)
@@ -300,6 +301,8 @@ def trainModel(rank, world_size, root_path, savepath, dataset_name, data_type, b
             if not inference:
                 if phase == "val":
                     loss = metrics["loss"]
+                    if sync is not None:                                   # one stop decision for all ranks
+                        loss = metrics["loss"] = sync.mean_scalar(loss, device)
                     metrics_dict = trackMetrics(metrics, metrics_dict)
                     if loss < min_loss:
                         min_loss, patience_count = loss, 1
@@ -332,6 +335,17 @@ def trainModel(rank, world_size, root_path, savepath, dataset_name, data_type, b
             torch.save(attention_dict, os.path.join(savepath, "attention_%s" % phases[0]))
             torch.save(importance_dict, os.path.join(savepath, "importance_%s" % phases[0]))
     return dict(metrics_dict)
+
+
+def _longest_window(dataset):
+    """Frames in the longest training window of a GestureWindows dataset (0 = unknown dataset type)."""
+    if not isinstance(dataset, GestureWindows):
+        return 0
+    best = 0
+    for r in dataset.rows:
+        start, end = int(r["StartFrame"]) - 1, int(r["EndFrame"]) - 1
+        best = max(best, len(np.arange(start, end, max((end - start) // 10, 1))))
+    return best
 
 
 def _to_cpu(snippets):

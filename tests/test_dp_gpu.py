@@ -140,28 +140,43 @@ def test_bench_gpus_flag_starts_n_ranks_or_fails_loudly():
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
     if n >= 2:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
-                            "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT)
+                            "--no-cpu-baseline", "--sustain-seconds", "0"], capture_output=True, text=True, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["comm"]["allreduce_bytes_per_step"] > 100e6
 
 
-def test_bench_distributed_branch_with_world_size_one():
-    """SAIS_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1: RCCL process group, hook-driven all-reduces of
-    every gradient slice (~122 MB per step), barriers and the rank-0 JSON line."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+def _force_dist_bench(*extra):
     port = 29600 + (os.getpid() % 2000)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"],
-                       capture_output=True, text=True, cwd=ROOT,
+                        "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--sustain-seconds", "0",
+                        *extra],
+                       capture_output=True, text=True, cwd=ROOT, timeout=900,
                        env=dict(os.environ, SAIS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["config"]["launch"] == "eager"
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_distributed_branch_with_world_size_one():
+    """SAIS_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1: RCCL process group, hook-driven all-reduces of
+    every gradient slice (~122 MB per step) CAPTURED INTO THE STEP'S hipGraph (the same launch path as N = 1), barriers
+    and the rank-0 JSON line; the replayed graph and an eager step from the same weights must give the same loss."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    line = _force_dist_bench()
+    assert line["n_gpus"] == 1 and line["config"]["launch"] == "hipGraph replay"
+    assert line["graph_vs_eager"]["abs_diff"] <= 1e-6
     assert 100e6 < line["comm"]["allreduce_bytes_per_step"] < 140e6       # 30.45 M touched params x 4 B (SURVEY §8e)
-    assert line["comm"]["exposed_comm_ms_per_step"] >= 0
+    assert line["comm"]["exposed_comm_ms_per_step"] >= 0 and line["comm"]["payload_dtype"] == "fp32"
+    assert 14 <= line["comm"]["allreduce_launches_per_step"] <= 30        # 12 blocks + embedding + norm + temporal slices
+
+
+def test_bench_distributed_branch_eager_launch_path():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    line = _force_dist_bench("--no-graph")
+    assert line["config"]["launch"] == "eager" and 100e6 < line["comm"]["allreduce_bytes_per_step"] < 140e6
 
 
 def test_bench_two_ranks_complete_and_print_one_line(tmp_path):
@@ -174,7 +189,8 @@ def test_bench_two_ranks_complete_and_print_one_line(tmp_path):
     env = dict(os.environ, SAIS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "2", "--frames", "8"],
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--clips", "2", "--frames", "8",
+                        "--sustain-seconds", "0"],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

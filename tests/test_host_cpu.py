@@ -166,6 +166,43 @@ def test_data_parallel_gradient_exchange_gloo_world2(tmp_path):
     assert int(nbytes) > 4 * 3_000_000
 
 
+def _sync_state_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sais_amd.parallel import GradSync
+    sync = GradSync(world)
+    torch.manual_seed(50 + rank)                       # every rank draws its own initial state, as loadModel does
+    flat, proto = torch.rand(1000), torch.rand(1, 256)
+    mine = flat.clone()
+    sync.broadcast_initial_state([flat, proto])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(g, gathered[0]) for g in gathered) and (rank == 0) == torch.equal(flat, mine)
+    tmax = sync.agree_max(7 + 4 * rank, "cpu")
+    mean = sync.mean_scalar(1.0 + rank, "cpu")
+
+    class M:
+        _touched_T = 9
+    sync._temporal = (M(), 5)                          # a 9-frame stream turned up, the exchange was sized for 5
+    try:
+        sync.flush_temporal()
+        raised = False
+    except RuntimeError:
+        raised = True
+    open(out + f".{rank}", "w").write(f"{same} {tmax} {mean} {raised}")
+    dist.destroy_process_group()
+
+
+def test_replicas_start_from_rank0_state_and_agree_on_scalars_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res")
+    mp.spawn(_sync_state_worker, args=(2, 31500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    for r in range(2):
+        same, tmax, mean, raised = open(out + f".{r}").read().split()
+        assert (same, int(tmax), float(mean), raised) == ("True", 11, 1.5, "True")
+
+
 class _StubModel:
     """Stands in for fullModel in the CPU test of the sharded window loop: deterministic host arithmetic on the batch."""
     modalities, importance_loss = "RGB-Flow", False

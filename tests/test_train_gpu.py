@@ -106,7 +106,7 @@ def _dp_train_worker(rank, world, port, root, out):
     loaders, _ = T.load_dataloaders(root, "Custom_Gestures", 4, ["train", "val"], "in_vs_out", "ViT_SelfSupervised_ImageNet",
                                     rank, world, seed=0)
     savepath = os.path.join(root, "params", f"Fold_0_r{rank}")
-    torch.manual_seed(0)
+    torch.manual_seed(1234 + rank)          # every rank its own initial draws: trainModel must broadcast rank 0's
     hist = T.trainModel(0, world, root, savepath, "Custom_Gestures", "reps", 4, 2, "in_vs_out", ["train", "val"], 0.1,
                         "RGB-Flow", False, False, "Prototypes", True, False, False, "None", True, False, "ViT",
                         "ViT_SelfSupervised_ImageNet", 5, 1, 0, 384, 2, 0, 1, dataloader=loaders)

@@ -27,10 +27,16 @@ NT_NAMES = {0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_b
 ROW_NAMES = {0: "gemm_nt<bias_bf16>(row)", 1: "gemm_nt<resid_f32>(row)", 2: "gemm_ln_fwd", 3: "gemm_ln_bwd"}
 
 
+# the row kernel runs two shapes per family and the name does not carry K: dispatches of a family follow the training
+# step's launch order (vit.py), so K is read off the position inside the step
+ROW_K_PATTERN = {"gemm_ln_fwd": [384, 1536] * 11 + [384],          # proj + norm2, fc2 + next norm1 (the last fc2 is plain)
+                 "gemm_ln_bwd": [1536, 1152] * 12}                 # dX fc1 + norm2', dX qkv + norm1'
+
+
 def timer_name(kernel):
-    m = re.search(r"gemm_nt_row_kernel<(\d+)>|gemm_nt_row_kernelILi(\d+)E", kernel)
+    m = re.search(r"gemm_nt_row_kernel<(\d+), *(?:true|false)>|gemm_nt_row_kernel<(\d+)>|gemm_nt_row_kernelILi(\d+)E", kernel)
     if m:
-        return ROW_NAMES[int(m.group(1) or m.group(2))]
+        return ROW_NAMES[int(m.group(1) or m.group(2) or m.group(3))]
     m = re.search(r"gemm_nt(?:_w8p)?_kernel<(\d+)>|gemm_nt(?:_w8p)?_kernelILi(\d+)E", kernel)
     if m:
         return "gemm_nt<%s>" % NT_NAMES[int(m.group(1) or m.group(2))]
@@ -44,13 +50,20 @@ def timer_name(kernel):
 
 
 def collect(folder):
-    """{kernel: {counter: [values per dispatch]}}"""
+    """{kernel family: {counter: [values per dispatch]}}; the LayerNorm-fused row GEMMs are split by K ("gemm_ln_fwd[K384]")."""
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(folder, "**", "*_counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
+        seen = collections.defaultdict(dict)                # family -> {dispatch id: ordinal}
+        for r in rows:
             n = timer_name(r["Kernel_Name"])
-            if n:
-                agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if not n:
+                continue
+            if n in ROW_K_PATTERN:
+                ordinal = seen[n].setdefault(r["Dispatch_Id"], len(seen[n]))
+                pat = ROW_K_PATTERN[n]
+                n = "%s[K%d]" % (n, pat[ordinal % len(pat)])
+            agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
@@ -84,7 +97,16 @@ def main():
         tr[n] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_kb_raw": int(f), "write_kb": int(w),
                  "launches_sampled": len(fetch[n].get("FETCH_SIZE", [])),
                  "note": "separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled (gfx950 correction)"}
+    # whole-step HBM bytes by counters: launches per step x bytes per launch over every family that was matched (steps in
+    # the profiled run = dW launches / 12 blocks)
+    nsteps = max(1, len(fetch.get("gemm_tn_grouped", {}).get("FETCH_SIZE", [])) // 12)
+    per_step = {n: round(v["launches_sampled"] / nsteps, 2) for n, v in tr.items()}
+    step_bytes = sum(tr[n]["hbm_bytes_per_launch"] * per_step[n] for n in tr)
+    tr["_step"] = {"step_hbm_bytes": int(step_bytes), "steps_profiled": nsteps, "launches_per_step": per_step,
+                   "note": "sum over the matched kernel families (all GEMM / attention / LayerNorm / SGD kernels; the "
+                           "temporal-encoder kernels and elementwise torch kernels are not matched)"}
     json.dump(tr, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    print("step_hbm_bytes %.2f GB over %d steps" % (step_bytes / 1e9, nsteps))
     for n, v in mf.items():
         t = tr.get(n, {}).get("hbm_bytes_per_launch", 0) / 1e6
         print(f"{n:28s} mfma {v['mfma_busy_frac_of_cu_busy']}  wait_any {v['wait_any_frac_of_wave_cycles']}  "
