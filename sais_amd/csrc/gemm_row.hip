@@ -32,6 +32,8 @@
 // coalesced row segments, the next row's operands prefetched BEFORE the current row's stores are issued (vmcnt counts
 // stores).  LN_BWD reads x once; dgamma / dbeta are per-lane column sums reduced through LDS, one atomic per column
 // and workgroup.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/sais_hip.h"
 
@@ -39,7 +41,13 @@ namespace {
 
 constexpr int RBN = 384, RBK = 64, RMT = 7;         // 7 row tiles of 16 = 112 rows computed per workgroup
 constexpr int RTILE = 128 * 64 * 2;                 // 16 KiB: 128 rows x 64 k bf16
-constexpr int ROW_LDS = 5 * RTILE;                  // A x 2, W x 3
+// NW = waves per workgroup.  4: one 112-row half, two workgroups per CU (small / odd M).  8: TWO 112-row halves that share
+// every W chunk (waves 0-3 rows 0..111, waves 4-7 rows 112..223), ONE workgroup per CU: the W fill stream per flop halves
+// (145 flop per LDS-DMA byte instead of 84), and M = 50 432 = 256 x 197 gives every CU exactly one frame's rows.
+template <int NW> constexpr int row_lds() { return 2 * (NW / 4) * RTILE + 3 * RTILE; }      // A x 2, W x 3
+
+template <int N> DEVINL void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N) : "memory"); }
+template <int N> DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
 enum { ROW_BIAS_BF16 = 0, ROW_RESID_F32, ROW_LN_FWD, ROW_LN_BWD };
 
@@ -64,11 +72,16 @@ struct RowParams {
 // so that lane group a = lane>>4 ends up with 8 CONTIGUOUS output columns (t = MFMA tile 0/1, b = accumulator register)
 DEVINL int perm32(int r) { return (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3); }
 
-template <int EPI, bool DP>
-__global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
+template <int EPI, bool DP, int NW, bool STAG = false>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_nt_row_kernel(RowParams p) {
+    static_assert(!STAG || NW == 8, "the stagger pairs waves w and w + 4 of one SIMD");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HALVES = NW / 4;                   // 112-row halves of the tile
+    constexpr int ATILE = HALVES * RTILE;            // one A slot: 128 LDS rows per half
+    constexpr int WP = 16 / NW;                      // LDS-DMA pieces (8 rows) of a W chunk per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wid >> 2, wq = wid & 3;         // row half, column quarter (96 columns)
     const int g = lane >> 4, li = lane & 15;
     // tiles are numbered column-group fastest, so the N/384 workgroups that share an A row panel run side by side on
     // one XCD (xcd_remap hands every XCD a contiguous run of tiles) and the panel is fetched from HBM once
@@ -78,34 +91,40 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
     const int m0 = (tile / ngrp) * p.rows_per_tile;
     const int mend = min(p.M, m0 + p.rows_per_tile);                 // rows [m0, mend) are this workgroup's
 
-    // staging: wave w issues pieces 4w..4w+3 (8 LDS rows each) of every 128-row slot.  A: tile rows; W chunk c: LDS rows
-    // 32 w' + j (w' = owning wave) <- weight rows 96 w' + 32 c + perm32(j)
+    // staging: wave w issues pieces 4w..4w+3 (8 LDS rows each) of the A slot (LDS row 128 h + r' <- tile row 112 h + r')
+    // and pieces WP w .. WP w + WP - 1 of every W chunk.  W chunk c: LDS rows 32 q + j (q = owning column quarter) <- weight
+    // rows 96 q + 32 c + perm32(j)
     const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
-    unsigned aoff[4], woff[4];                                       // per-lane byte offsets from the uniform bases
+    unsigned aoff[4], woff[WP];                                      // per-lane byte offsets from the uniform bases
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (4 * wid + j) + sub;
-        int m = m0 + r;
+        const int r = 8 * (4 * wid + j) + sub;                       // LDS row of the slot
+        const int rt = 112 * (r >> 7) + (r & 127);                   // tile row (LDS rows 112..127 of a half are never read)
+        int m = (r & 127) < 112 ? m0 + rt : m0;
         m = m < p.M ? m : p.M - 1;                                   // clamp: rows outside the tile are never stored
         aoff[j] = ((unsigned)m * (unsigned)p.lda + schunk * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+        const int r = 8 * (WP * wid + j) + sub;
         woff[j] = ((unsigned)(n0 + 96 * (r >> 5) + perm32(r & 31)) * (unsigned)p.ldw + schunk * 8) * 2u;
     }
     char* const sA = smem;
-    char* const sW = smem + 2 * RTILE;
+    char* const sW = smem + 2 * ATILE;
     const char* const Ab = (const char*)p.A;
     const char* const Wb = (const char*)p.W;
     const size_t wchunk = (size_t)32 * p.ldw * 2;                    // bytes between chunk c and c + 1 of a wave's columns
     auto issue_a = [&](int kt) {
-        char* s = sA + (kt & 1) * RTILE + (4 * wid) * 1024;
+        char* s = sA + (kt & 1) * ATILE + (4 * wid) * 1024;
         const char* b = Ab + (size_t)kt * (RBK * 2);
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(b + aoff[j], s + j * 1024);
     };
     auto issue_w = [&](int kt, int c) {
-        char* s = sW + c * RTILE + (4 * wid) * 1024;
+        char* s = sW + c * RTILE + (WP * wid) * 1024;
         const char* b = Wb + c * wchunk + (size_t)kt * (RBK * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(b + woff[j], s + j * 1024);
+        for (int j = 0; j < WP; ++j) glds16(b + woff[j], s + j * 1024);
     };
 
     f32x4 acc[RMT][6];
@@ -114,59 +133,98 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-#define ROW_COMPUTE(C)                                                                          \
+    // fragments of one 32-deep k-half of chunk C: 2 W + 7 A ds_read_b128; then 14 MFMAs
+    bf16x8 fa[RMT], fb[2];
+#define ROW_READ(C, KS)                                                                         \
     {                                                                                           \
-        const char* sa = sA + (kt & 1) * RTILE;                                                 \
+        const char* sa = sA + (kt & 1) * ATILE + half * RTILE;                                  \
         const char* sb = sW + (C) * RTILE;                                                      \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                      \
-            bf16x8 fa[RMT], fb[2];                                                              \
-            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                       \
-                fb[t] = *(const bf16x8*)(sb + swz(32 * wid + 16 * t + li, ks * 4 + g));         \
-            _Pragma("unroll") for (int t = 0; t < RMT; ++t)                                     \
-                fa[t] = *(const bf16x8*)(sa + swz(16 * t + li, ks * 4 + g));                    \
-            _Pragma("unroll") for (int mt = 0; mt < RMT; ++mt)                                  \
-                _Pragma("unroll") for (int t = 0; t < 2; ++t)                                   \
-                    acc[mt][2 * (C) + t] = mfma16(fb[t], fa[mt], acc[mt][2 * (C) + t]);         \
-        }                                                                                       \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                           \
+            fb[t] = *(const bf16x8*)(sb + swz(32 * wq + 16 * t + li, (KS) * 4 + g));            \
+        _Pragma("unroll") for (int t = 0; t < RMT; ++t)                                         \
+            fa[t] = *(const bf16x8*)(sa + swz(16 * t + li, (KS) * 4 + g));                      \
     }
+#define ROW_MMA(C)                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < RMT; ++mt)                                          \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                           \
+            acc[mt][2 * (C) + t] = mfma16(fb[t], fa[mt], acc[mt][2 * (C) + t]);
+    // STAG (eight waves): waves 4-7, the SIMD partners of waves 0-3, run HALF A PHASE behind inside every barrier interval —
+    // they open the interval with the 14 MFMAs of the previous chunk's second k-half (its fragments stay in registers across
+    // the barrier, so the LDS slot may be refilled) while their partners read fragments, and alternate from there: one wave
+    // of each SIMD is in the matrix pipe while the other is in the LDS (MI355X_MICROARCH.md, two waves per SIMD, item 9).
 #define ROW_WAIT(MORE, NMORE)                                                                   \
-    if (more) asm volatile("s_waitcnt vmcnt(" #MORE ") lgkmcnt(0)" ::: "memory");               \
-    else asm volatile("s_waitcnt vmcnt(" #NMORE ") lgkmcnt(0)" ::: "memory");                   \
+    if (more) wait_vm_lgkm0<(MORE)>();                                                          \
+    else wait_vm_lgkm0<(NMORE)>();                                                              \
     __builtin_amdgcn_s_barrier();
+    // LATE = true (STAG, waves 4-7): a barrier interval opens with the 14 MFMAs of the PREVIOUS chunk's second k-half
+#define ROW_COMPUTE(C, CPREV)                                                                   \
+    if constexpr (LATE) {                                                                       \
+        ROW_MMA(CPREV)                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        ROW_READ(C, 0)                                                                          \
+        ROW_MMA(C)                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        ROW_READ(C, 1)                                                                          \
+    } else {                                                                                    \
+        ROW_READ(C, 0)                                                                          \
+        ROW_MMA(C)                                                                              \
+        ROW_READ(C, 1)                                                                          \
+        ROW_MMA(C)                                                                              \
+    }
 
     const int nk = p.K / RBK;
     issue_a(0);
     issue_w(0, 0);
     issue_w(0, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                 // A(0), W(0,0) landed; W(0,1) may fly
+    wait_vm<WP>();                                                   // A(0), W(0,0) landed; W(0,1) may fly
     __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        // sub-step 0: needs A(kt), W(kt,0).  Issue W(kt,2) then A(kt+1) (A last: it may stay in flight longest)
-        issue_w(kt, 2);
-        if (more) issue_a(kt + 1);
-        ROW_COMPUTE(0)
-        ROW_WAIT(8, 4)                                               // W(kt,1) landed; W(kt,2) [+ A(kt+1)] in flight
-        // sub-step 1
-        if (more) issue_w(kt + 1, 0);
-        ROW_COMPUTE(1)
-        ROW_WAIT(8, 0)                                               // W(kt,2) landed; A(kt+1), W(kt+1,0) in flight
-        // sub-step 2
-        if (more) issue_w(kt + 1, 1);
-        ROW_COMPUTE(2)
-        ROW_WAIT(4, 0)                                               // A(kt+1), W(kt+1,0) landed; W(kt+1,1) in flight
-    }
+    // STAG (eight waves): waves 4-7, the SIMD partners of waves 0-3, run HALF A PHASE behind inside every barrier interval:
+    // the fragments of a chunk's second k-half stay in registers across the barrier (so the LDS slot may be refilled) and
+    // their 14 MFMAs open the next interval while the partner wave reads its fragments, and the two alternate from there —
+    // one wave of each SIMD in the matrix pipe, the other in the LDS (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+    // The two schedules are two complete copies of the loop (same barrier count), chosen once per wave.
+    auto kloop = [&](auto late_c) {
+        constexpr bool LATE = decltype(late_c)::value;
+        if constexpr (LATE) {                                        // the first "previous k-half" adds zeros
+#pragma unroll
+            for (int t = 0; t < RMT; ++t) fa[t] = zero8();
+            fb[0] = zero8(); fb[1] = zero8();
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            // sub-step 0: needs A(kt), W(kt,0).  Issue W(kt,2) then A(kt+1) (A last: it may stay in flight longest)
+            issue_w(kt, 2);
+            if (more) issue_a(kt + 1);
+            ROW_COMPUTE(0, 2)
+            ROW_WAIT(WP + 4, WP)                                     // W(kt,1) landed; W(kt,2) [+ A(kt+1)] in flight
+            // sub-step 1
+            if (more) issue_w(kt + 1, 0);
+            ROW_COMPUTE(1, 0)
+            ROW_WAIT(4 + WP, 0)                                      // W(kt,2) landed; A(kt+1), W(kt+1,0) in flight
+            // sub-step 2
+            if (more) issue_w(kt + 1, 1);
+            ROW_COMPUTE(2, 1)
+            ROW_WAIT(WP, 0)                                          // A(kt+1), W(kt+1,0) landed; W(kt+1,1) in flight
+        }
+        if constexpr (LATE) { ROW_MMA(2) }                           // the last chunk's second k-half
+    };
+    if (STAG && half) kloop(std::true_type{});
+    else kloop(std::false_type{});
+#undef ROW_READ
+#undef ROW_MMA
 #undef ROW_COMPUTE
 #undef ROW_WAIT
 
     // ------------------------------------------------------------------------------------------- epilogues
-    // lane: rows m0 + 16 mt + li (mt = 0..6); per chunk c the 8 columns 96 wid + 32 c + 8 g + (4 t + e)
-    const int cbase = 96 * wid + 8 * g;                              // + 32 c
+    // lane: tile rows 112 half + 16 mt + li (mt = 0..6); per chunk c the 8 columns 96 wq + 32 c + 8 g + (4 t + e)
+    const int cbase = 96 * wq + 8 * g;                               // + 32 c
     {
-        // ---- every epilogue: 32-row fp32 slabs through LDS, then a row-streaming phase ----------------------------
+        // ---- every epilogue: (32 HALVES)-row fp32 slabs through LDS, then a row-streaming phase -------------------
         constexpr int SLD = 388;                                     // floats per slab row (1552 B: conflict-free dumps)
-        float* const slab = (float*)smem;                            // [32][SLD]; the operand slots are free now
-        float* const scr = slab + 32 * SLD;                          // LN_BWD: [8][2][384] column sums + gamma
+        constexpr int SROWS = 32 * HALVES;                           // rows per slab
+        constexpr int NHW = 2 * NW;                                  // half-waves that stream rows
+        float* const slab = (float*)smem;                            // [SROWS][SLD]; the operand slots are free now
+        float* const scr = slab;                                     // LN_BWD column sums [NHW][2][384]: after the last slab
         const int l32 = tid & 31, hw = tid >> 5;
         auto clampm = [&](int m) { return m < p.M ? m : p.M - 1; };
         auto ld12 = [&](const float* q, float (&v)[12]) {
@@ -193,13 +251,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
             return v;
         };
-        // slab s = tile rows 32 s .. 32 s + 31 = row tiles 2 s, 2 s + 1 (the last slab holds one row tile)
+        // slab s = local row tiles 2 s, 2 s + 1 of EVERY half (the last slab: local tile 6): slab rows 32 h .. 32 h + 31
+        // belong to half h, so all waves free their accumulators at the same pace
         auto dump = [&](int s) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int mt = 2 * s + h;
                 if (mt >= RMT) break;
-                float* row = slab + (16 * h + li) * SLD + cbase;
+                float* row = slab + (32 * half + 16 * h + li) * SLD + cbase;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     *(f32x4*)(row + 32 * c) = acc[mt][2 * c];
@@ -207,8 +266,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                 }
             }
         };
-        // the rows a half-wave streams: tile row 32 s + hw + 8 q, q = 0..3 (slab 3: q = 0, 1); it = 4 s + q
-        auto trow = [&](int it) { return 32 * (it >> 2) + hw + 8 * (it & 3); };
+        // the rows a half-wave streams: iteration it = 4 s + q' (slab 3: q' = 0, 1).  q' -> q (slab 3: q = HALVES q'),
+        // half hh = q / QPH, local row = hw + NHW (q % QPH): slab row 32 hh + local, tile row 112 hh + 32 s + local
+        constexpr int QPH = 4 / HALVES;
+        auto qof = [&](int it) { return it < 12 ? (it & 3) : (it - 12) * HALVES; };
+        auto srow = [&](int it) { const int q = qof(it); return 32 * (q / QPH) + hw + NHW * (q % QPH); };
+        auto trow = [&](int it) { const int q = qof(it); return 112 * (q / QPH) + 32 * (it >> 2) + hw + NHW * (q % QPH); };
         constexpr int NIT = 14;                                      // 3 x 4 + 2
 
         if constexpr (EPI == ROW_BIAS_BF16 || EPI == ROW_RESID_F32) {
@@ -235,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                 for (int q = 0; q < nq; ++q) {
                     const int it = 4 * s + q, m = m0 + trow(it);
                     float v[12], acur[12];
-                    ld12(slab + (hw + 8 * q) * SLD, v);
+                    ld12(slab + srow(it) * SLD, v);
                     if constexpr (HAS_AUX) {
 #pragma unroll
                         for (int i = 0; i < 12; ++i) acur[i] = anext[i];
@@ -281,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                 for (int q = 0; q < nq; ++q) {
                     const int it = 4 * s + q, m = m0 + trow(it);
                     float v[12], rcur[12];
-                    ld12(slab + (hw + 8 * q) * SLD, v);
+                    ld12(slab + srow(it) * SLD, v);
 #pragma unroll
                     for (int i = 0; i < 12; ++i) rcur[i] = rnext[i];
                     if (it + 1 < NIT)                                // next row's residual: issued before this row's stores
@@ -315,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
             }
         } else {  // ROW_LN_BWD: acc = dy
             float ag[12], ab[12];
-            float* const gls = scr + 16 * RBN;                       // gamma, kept in LDS (no registers to spare)
-            for (int i = tid; i < RBN; i += 256) gls[i] = p.gamma[i];
+            float* const gls = slab + SROWS * SLD;                   // gamma, kept in LDS (no registers to spare)
+            for (int i = tid; i < RBN; i += 64 * NW) gls[i] = p.gamma[i];
 #pragma unroll
             for (int i = 0; i < 12; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
             float xnext[12], dnext[12], munext, rsnext;
@@ -336,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                 for (int q = 0; q < nq; ++q) {
                     const int it = 4 * s + q, m = m0 + trow(it);
                     float dy[12], xv[12], dr[12], gm[12];
-                    ld12(slab + (hw + 8 * q) * SLD, dy);
+                    ld12(slab + srow(it) * SLD, dy);
                     ld12(gls, gm);
                     const float mu = munext, rs = rsnext;
 #pragma unroll
@@ -375,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                 if (s < 3) __syncthreads();
             }
             if (p.dgamma) {
+                __syncthreads();                                     // the column sums go where the last slab was
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -383,11 +447,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
                         scr[(hw * 2 + 1) * RBN + 128 * i + 4 * l32 + e] = ab[4 * i + e];
                     }
                 __syncthreads();
-                for (int c = tid; c < 2 * RBN; c += 256) {
+                for (int c = tid; c < 2 * RBN; c += 64 * NW) {
                     const int which = c / RBN, col = c - which * RBN;
                     float t = 0.f;
 #pragma unroll
-                    for (int h = 0; h < 8; ++h) t += scr[(h * 2 + which) * RBN + col];
+                    for (int h = 0; h < NHW; ++h) t += scr[(h * 2 + which) * RBN + col];
                     atomicAdd((which ? p.dbeta : p.dgamma) + col, t);
                 }
             }
@@ -395,18 +459,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_row_kernel(RowParams p) {
     }
 }
 
-// rows per workgroup: one round of 2 workgroups per CU when M allows it (M = 50 432 -> 99 rows, 510 tiles), whole
-// 112-row tiles for small M, r rounds of 512 tiles for M beyond 57 344
+// rows per workgroup.  NW = 4: one round of 2 workgroups per CU when M allows it (M = 50 432 -> 99 rows, 510 tiles), whole
+// 112-row tiles for small M, r rounds of 512 tiles for M beyond 57 344.  NW = 8: one workgroup per CU, 224 rows at most
+// (M = 50 432 -> 197 rows = one frame, 256 tiles).
+template <int NW>
 int rows_per_tile(int M) {
-    const int slots = 512;
-    const int rounds = (M + slots * 112 - 1) / (slots * 112);
+    constexpr int cap = 112 * (NW / 4), slots = NW == 4 ? 512 : 256;
+    const int rounds = (M + slots * cap - 1) / (slots * cap);
     int rows = (M + slots * rounds - 1) / (slots * rounds);
-    if (rows < 64) rows = 112;
+    if (rows < cap / 2 + 8) rows = cap;
     return rows;
 }
 
+// the eight-wave tile pays when a launch fills the chip with whole 1-workgroup-per-CU rounds: the ViT GEMMs of a training
+// step and of large extraction batches.  SAIS_ROW_WAVES=4 / 8 forces one form (A/B measurements).
+bool use_eight_waves(int M) {
+    static const int forced = [] { const char* e = getenv("SAIS_ROW_WAVES"); return e ? atoi(e) : 0; }();
+    if (forced == 4) return false;
+    if (forced == 8) return true;
+    return M >= 256 * 112;
+}
+
+template <int EPI, bool DP, int NW, bool STAG = false>
+int launch_row_nw(RowParams& p, void* stream) {
+    static thread_local bool set = false;
+    if (!set) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_row_kernel<EPI, DP, NW, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                row_lds<NW>()) != hipSuccess)
+            return SAIS_ERR_LAUNCH;
+        set = true;
+    }
+    // 32-bit byte offsets inside the kernel
+    if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAIS_ERR_ARG;
+    p.rows_per_tile = rows_per_tile<NW>(p.M);
+    const int grid = (p.N / RBN) * ((p.M + p.rows_per_tile - 1) / p.rows_per_tile);
+    hipLaunchKernelGGL((gemm_nt_row_kernel<EPI, DP, NW, STAG>), dim3(grid), dim3(64 * NW), row_lds<NW>(), (hipStream_t)stream, p);
+    return sais_check_launch();
+}
+
 template <int EPI, bool DP>
-int launch_row_dp(RowParams& p, void* stream);
+int launch_row_dp(RowParams& p, void* stream) {
+    static const bool stag = [] { const char* e = getenv("SAIS_ROW_STAG"); return e ? atoi(e) != 0 : true; }();
+    if (!use_eight_waves(p.M)) return launch_row_nw<EPI, DP, 4>(p, stream);
+    return stag ? launch_row_nw<EPI, DP, 8, true>(p, stream) : launch_row_nw<EPI, DP, 8, false>(p, stream);
+}
 
 template <int EPI>
 int launch_row(RowParams& p, void* stream) {
@@ -414,23 +510,6 @@ int launch_row(RowParams& p, void* stream) {
         if (p.rowscale) return launch_row_dp<EPI, true>(p, stream);
     }
     return launch_row_dp<EPI, false>(p, stream);
-}
-
-template <int EPI, bool DP>
-int launch_row_dp(RowParams& p, void* stream) {
-    static thread_local bool set = false;
-    if (!set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_row_kernel<EPI, DP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                ROW_LDS) != hipSuccess)
-            return SAIS_ERR_LAUNCH;
-        set = true;
-    }
-    // 32-bit byte offsets inside the kernel
-    if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAIS_ERR_ARG;
-    p.rows_per_tile = rows_per_tile(p.M);
-    const int grid = (p.N / RBN) * ((p.M + p.rows_per_tile - 1) / p.rows_per_tile);
-    hipLaunchKernelGGL((gemm_nt_row_kernel<EPI, DP>), dim3(grid), dim3(256), ROW_LDS, (hipStream_t)stream, p);
-    return sais_check_launch();
 }
 
 }  // namespace

@@ -85,11 +85,18 @@ def test_train_step_stagewise_vs_oracle_at_benchmark_dispatch(gpu, B, T):
         e_ref, a_ref = O.temporal_forward(tsd, reps_ref.detach().view(B, 1, T, 384), None, pad, None, "RGB")
         sim_ref = O.cosine_logits(e_ref, pr)
         loss_ref = O.nce_loss(e_ref, lab, pr)
+    from conftest import parity_log
+    tag = f"step[B{B},T{T}]/"
     dfeat = (reps.detach().cpu() - reps_ref.detach()).abs().max().item()
+    parity_log(tag + "features max-abs / max|ref|", dfeat / reps_ref.detach().abs().max().item(), FEAT_REL)
     assert dfeat <= FEAT_REL * reps_ref.detach().abs().max().item(), dfeat
     dlogit = (sim.cpu() - sim_ref).abs().max().item()
+    parity_log(tag + "cosine logits max-abs", dlogit, LOGIT_TOL)
     assert dlogit <= LOGIT_TOL, dlogit
-    assert (attn.cpu() - a_ref).abs().max().item() <= 2e-3
+    dattn = (attn.cpu() - a_ref).abs().max().item()
+    parity_log(tag + "attention map max-abs", dattn, 2e-3)
+    assert dattn <= 2e-3
+    parity_log(tag + "loss abs", abs(loss.item() - loss_ref.item()), LOGIT_TOL)
     assert abs(loss.item() - loss_ref.item()) <= LOGIT_TOL
 
     # stage 1: temporal backward at the GPU's own features
@@ -102,6 +109,7 @@ def test_train_step_stagewise_vs_oracle_at_benchmark_dispatch(gpu, B, T):
               "transEncoderFrame.layers.0.self_attn.in_proj_weight", "transEncoderFrame.layers.3.norm2.bias",
               "transEncoderFrame.layers.1.linear1.weight", "transEncoderFrame.layers.2.linear2.bias"):
         r = rel_l2(P[n].grad, tsd[n].grad)
+        parity_log(tag + "temporal parameter gradients, worst tensor rel-L2", r, GRAD_REL)
         if r > GRAD_REL:
             bad[n] = r
     for k in protos.keys():
@@ -109,16 +117,20 @@ def test_train_step_stagewise_vs_oracle_at_benchmark_dispatch(gpu, B, T):
         if r > GRAD_REL:
             bad["proto" + k] = r
     r = rel_l2(reps.grad, rx.grad.reshape(F, 384))
+    parity_log(tag + "d loss / d features rel-L2", r, GRAD_REL)
     if r > GRAD_REL:
         bad["d loss / d reps"] = r
     assert not bad, bad
 
     # stage 2: ViT backward driven by the GPU's own upstream gradient (all frames: parameter gradients sum over them)
     bad = {}
+    worst = 0.0
     for n, q in vit.named_parameters():
         r = rel_l2(q.grad, vsd[n].grad)
+        worst = max(worst, r)
         if r > VIT_GRAD_REL:
             bad[n] = r
+    parity_log(tag + "ViT parameter gradients, worst tensor rel-L2 (150 tensors)", worst, VIT_GRAD_REL)
     assert not bad, bad
 
 

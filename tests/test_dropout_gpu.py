@@ -190,7 +190,8 @@ def _vit(depth, rate):
     return v.to(DEV)
 
 
-@pytest.mark.parametrize("frames,depth", [(6, 4), (48, 2)])          # M = 1182: stand-alone kernels; M = 9456: LN-fused row GEMMs
+# M = 1182: stand-alone kernels; M = 9456: LN-fused row GEMMs (four-wave tile); M = 28 762: the eight-wave tile
+@pytest.mark.parametrize("frames,depth", [(6, 4), (48, 2), (146, 2)])
 def test_droppath_train_mode_vs_oracle_with_the_same_draws(ops, frames, depth):
     """vision_transformer.py:27-46,105-113 in train(): per-sample keep / (1 - p_i) on both residual branches, forward and
     backward.  The draws are this library's (Philox): the per-row scales a forward used are exported, reduced to per-sample

@@ -63,7 +63,7 @@ def test_gemm_tn_exact_integers(ops):
 # second round); the last-but-one shape is 304 tiles x 9 column tiles = more tiles than persistent workgroups
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (50432 // 8, 1152, 384), (264, 2048, 384), (128, 384, 1536),
                                    (8192 + 3 * 128 + 57, 384, 384), (50432 - 128 * 90, 1152, 384),
-                                   (8192 + 128 + 5, 512, 384), (8192 + 99 * 3 + 7, 1536, 384)])
+                                   (8192 + 128 + 5, 512, 384), (8192 + 99 * 3 + 7, 1536, 384), (197 * 150 + 77, 384, 384)])
 def test_gemm_nt_epilogues(ops, M, N, K):
     from sais_amd import _lib as L
     a = rnd(M, K, seed=3, dtype=torch.bfloat16)
@@ -425,7 +425,9 @@ def _ln_ref(x, gamma, beta, eps):
     return F.layer_norm(x, (384,), gamma, beta, eps)
 
 
-@pytest.mark.parametrize("M,K", [(300, 384), (8192 + 128 + 57, 1536), (12608, 384)])
+# M >= 28 672 takes the eight-wave tile (two 112-row halves, one workgroup per CU): ragged (197 x 146 + 5 rows -> 113-row
+# tiles: the second half stores ONE row) and whole-frame tiles
+@pytest.mark.parametrize("M,K", [(300, 384), (8192 + 128 + 57, 1536), (12608, 384), (197 * 146 + 5, 1536), (197 * 200, 384)])
 def test_gemm_ln_fwd(ops, M, K):
     """x_out = A.W^T + b + resid ; xn = LayerNorm(x_out) in ONE launch vs fp32 torch (ragged last tile included)."""
     a = rnd(M, K, seed=200, dtype=torch.bfloat16)
@@ -448,7 +450,7 @@ def test_gemm_ln_fwd(ops, M, K):
     assert torch.equal(r2, x_out)
 
 
-@pytest.mark.parametrize("M,K", [(300, 1152), (8192 + 57, 1536), (12608, 1152)])
+@pytest.mark.parametrize("M,K", [(300, 1152), (8192 + 57, 1536), (12608, 1152), (197 * 146 + 5, 1152), (197 * 200, 1536)])
 def test_gemm_ln_bwd(ops, M, K):
     """dy = A.W^T ; dx = dres + dLN(dy) ; dgamma, dbeta — vs torch autograd of layer_norm on the fp32 dy."""
     a = rnd(M, K, seed=210, scale=0.5, dtype=torch.bfloat16)
