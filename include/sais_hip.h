@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 5
+#define SAIS_ABI_VERSION 6
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -77,6 +77,46 @@ int sais_gemm_nt(const SaisGemm* g, void* stream);
  * Optional split-K for these few-row problems: out2 = caller workspace f32 [ldo2][M][N], ldo2 = number of K
  * splits (must divide K/64); partial sums land there and a second tiny kernel reduces + applies the epilogue. */
 int sais_gemm_nt_f32(const SaisGemm* g, void* stream);
+
+/* ---------------------------------------------------------------- the temporal encoder's linear layers (round 3)
+ * The same "bf16x3" arithmetic as sais_gemm_nt_f32, tiled for M = clips x (T + 1) = a few hundred rows: 64 x 64 output
+ * tiles, two K-steps of loads in flight, optional split-K into RAW partial slabs out[z][M][N] (z < nsplit, nsplit divides
+ * K / 64) that the row kernels below consume — there is no separate reduce launch.  N % 64 == 0, K % 64 == 0.
+ *   SAIS_TG_RAW        out[z] = partial A . W^T                      (out_proj / linear2 forward; every N = 384 dX)
+ *   SAIS_TG_BIAS       out = A . W^T + bias (bias may be NULL)       (in_proj, prepare_model.py:213 -> MultiheadAttention)
+ *   SAIS_TG_BIAS_RELU  out = drop(relu(A . W^T + bias))              (linear1 + activation + dropout)
+ *   SAIS_TG_DRELU      out = drop(A . W^T) where aux > 0, else 0     (its backward; aux = the saved, dropped relu output)
+ * drop(): train-mode dropout, mask element m * N + n of `site`, p_drop = 0 for none.                                  */
+#define SAIS_TG_RAW 0
+#define SAIS_TG_BIAS 1
+#define SAIS_TG_BIAS_RELU 2
+#define SAIS_TG_DRELU 3
+typedef struct SaisTGemm {
+    const float* A; long lda;      /* f32 [M,K]                          */
+    const float* W; long ldw;      /* f32 [N,K]  (nn.Linear weight, or its transpose for dX) */
+    int M, N, K;
+    int epilogue;                  /* SAIS_TG_*                          */
+    int nsplit;                    /* SAIS_TG_RAW: number of K splits = slabs written; otherwise 1 */
+    const float* bias;             /* f32 [N] or NULL                    */
+    const float* aux; long ldaux;  /* SAIS_TG_DRELU                      */
+    float* out; long ldo;          /* f32 [M,N] (RAW: [nsplit][M][N], ldo = N) */
+    float p_drop; const unsigned long long* rng_state; unsigned site;
+} SaisTGemm;
+int sais_tgemm(const SaisTGemm* g, void* stream);
+/* Row kernels over D = 384 that CONSUME the slabs (split-K reduce + epilogue + LayerNorm in one pass):
+ *   sais_temporal_ln_fwd:  y = resid + drop(sum_z slabs[z] + bias) ;  z = LayerNorm(y; gamma, beta, eps) ; mean / rstd saved
+ *       = `src = src + dropout1(out_proj(..))` / `src = src + dropout2(linear2(..))` followed by norm1 / norm2 of the
+ *         torch-1.8 post-norm TransformerEncoderLayer (prepare_model.py:74-81).  y may be NULL (inference).
+ *   sais_temporal_ln_bwd:  dy = sum_z slabs[z] + add (either may be NULL) ;  dx = autograd of that LayerNorm at (x, mean,
+ *       rstd) ;  dx_drop = drop(dx) (optional second output: the gradient entering the residual BRANCH) ;
+ *       dgamma += sum_m dy xhat ; dbeta += sum_m dy.                                                                  */
+int sais_temporal_ln_fwd(const float* slabs, int nslab, long slab_stride, const float* bias, const float* resid, int rows,
+                         float p_drop, const unsigned long long* rng_state, unsigned site, float* y, const float* gamma,
+                         const float* beta, float eps, float* z, float* mean, float* rstd, void* stream);
+int sais_temporal_ln_bwd(const float* slabs, int nslab, long slab_stride, const float* add, const float* x,
+                         const float* mean, const float* rstd, const float* gamma, int rows, float* dx, float* dx_drop,
+                         float p_drop, const unsigned long long* rng_state, unsigned site, float* dgamma, float* dbeta,
+                         void* stream);
 
 /* dW[N1,N2] += P[M,N1]^T . Q[M,N2]  and (db != NULL)  db[N1] += column sums of P.
  * Weight / bias gradients of every nn.Linear above (autograd of F.linear).  Accumulates with f32
@@ -208,7 +248,8 @@ void sais_preprocess_plan_destroy(SaisPreprocessPlan* plan);
  * (out of place: the reference's in-place += on the caller's tensor is NOT reproduced).          */
 int sais_temporal_prepare_fwd(const float* x, long x_clip_stride, long x_frame_stride, const float* pos /*[T,384]*/,
                               const float* cls, int B, int T, float* z_f32, void* z_bf16 /*optional*/, void* stream);
-int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf16 /*optional, added*/, int B, int T, float* dx,
+/* backward: dz = dz_f32 + sum_z slabs[z] (either may be NULL; slabs = the raw split-K output of the in_proj dX GEMM) */
+int sais_temporal_prepare_bwd(const float* dz_f32, const float* slabs, int nslab, long slab_stride, int B, int T, float* dx,
                               long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos, float* dcls,
                               void* stream);
 /* nn.MultiheadAttention core of the torch-1.8 post-norm TransformerEncoderLayer (prepare_model.py:74-81,
@@ -219,9 +260,10 @@ int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf16 /*optiona
 int sais_temporal_attn_fwd(const float* qkv /*[B*S,1152]*/, const unsigned char* key_pad /*[B,S]*/, int B, int S,
                            float* ctx /*[B*S,384]*/, float* attn_avg, float p_drop, const unsigned long long* rng_state,
                            unsigned site, void* stream);
-int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B, int S, const float* dctx,
-                           float* dqkv /*[B*S,1152]*/, float p_drop, const unsigned long long* rng_state, unsigned site,
-                           void* stream);
+/* dctx = sum over nslab raw split-K slabs (slab_stride floats apart) of the out_proj dX GEMM; nslab = 1: a plain tensor */
+int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B, int S, const float* dctx, int nslab,
+                           long slab_stride, float* dqkv /*[B*S,1152]*/, float p_drop, const unsigned long long* rng_state,
+                           unsigned site, void* stream);
 /* Train mode (model.train(), train.py:59): nn.TransformerEncoderLayer's default dropout = 0.1 (prepare_model.py:75) acts at
  * four sites per layer: on the attention weights (p_drop above: after the softmax, before P v; the returned map is the
  * dropped one, as in torch 1.8), after out_proj (dropout1), after the ReLU (dropout) and after linear2 (dropout2).

@@ -24,6 +24,13 @@ class SaisGemm(ctypes.Structure):
                 ("p_drop", c_float), ("rng_state", c_void_p), ("site", ctypes.c_uint)]
 
 
+class SaisTGemm(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_long), ("W", c_void_p), ("ldw", c_long), ("M", c_int), ("N", c_int),
+                ("K", c_int), ("epilogue", c_int), ("nsplit", c_int), ("bias", c_void_p), ("aux", c_void_p),
+                ("ldaux", c_long), ("out", c_void_p), ("ldo", c_long), ("p_drop", c_float), ("rng_state", c_void_p),
+                ("site", ctypes.c_uint)]
+
+
 class SaisTnItem(ctypes.Structure):
     _fields_ = [("P", c_void_p), ("ldp", c_int), ("Q", c_void_p), ("ldq", c_int), ("N1", c_int), ("N2", c_int),
                 ("dW", c_void_p), ("ldw", c_int), ("db", c_void_p)]
@@ -41,6 +48,7 @@ EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
 EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
 EPI_BIAS_GELU_GRAD_BF16, EPI_MUL_BF16 = 10, 11
+TG_RAW, TG_BIAS, TG_BIAS_RELU, TG_DRELU = 0, 1, 2, 3
 
 # name -> argtypes; every symbol include/sais_hip.h declares (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -77,10 +85,16 @@ SIGNATURES = {
     "sais_scale_f32": [c_void_p, c_long, c_float, c_void_p],
     "sais_temporal_prepare_fwd": [c_void_p, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p],
-    "sais_temporal_prepare_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_long, c_long, c_int, c_void_p,
+    "sais_temporal_prepare_bwd": [c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_long, c_long, c_int, c_void_p,
                                   c_void_p, c_void_p],
+    "sais_tgemm": [ctypes.POINTER(SaisTGemm), c_void_p],
+    "sais_temporal_ln_fwd": [c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_float, c_void_p, ctypes.c_uint, c_void_p,
+                             c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sais_temporal_ln_bwd": [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                             c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p, c_void_p, c_void_p],
     "sais_temporal_attn_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
-    "sais_temporal_attn_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
+    "sais_temporal_attn_bwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_float, c_void_p,
+                               ctypes.c_uint, c_void_p],
     "sais_rng_advance": [c_void_p, c_void_p],
     "sais_droppath_scales": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, ctypes.c_uint, c_void_p],
     "sais_cast_bf16_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],

@@ -44,7 +44,13 @@ constexpr int RTILE = 128 * 64 * 2;                 // 16 KiB: 128 rows x 64 k b
 // NW = waves per workgroup.  4: one 112-row half, two workgroups per CU (small / odd M).  8: TWO 112-row halves that share
 // every W chunk (waves 0-3 rows 0..111, waves 4-7 rows 112..223), ONE workgroup per CU: the W fill stream per flop halves
 // (145 flop per LDS-DMA byte instead of 84), and M = 50 432 = 256 x 197 gives every CU exactly one frame's rows.
-template <int NW> constexpr int row_lds() { return 2 * (NW / 4) * RTILE + 3 * RTILE; }      // A x 2, W x 3
+// SPEC (eight waves): staging roles are split — waves 0-3 issue every W chunk, waves 4-7 every A tile, into a THREE-slot A
+// ring, so that the A stream (first-touch HBM rows) runs TWO K-steps ahead.  vmcnt is one in-order counter per wave: a
+// wave that issues both operands has to retire its A loads whenever it waits for the (younger, sooner-needed) W chunk
+// behind them, which caps the A lead at one K-step = 28-32 KB in flight per CU; measured (r3b): with that cap the K = 1536
+// kernels take the same time at 84 and at 145 flop per LDS-DMA byte, with and without the stagger — they are paced by the
+// latency x bytes-in-flight of the A stream, not by the fill rate.
+template <int NW, bool SPEC = false> constexpr int row_lds() { return (SPEC ? 3 : 2) * (NW / 4) * RTILE + 3 * RTILE; }
 
 template <int N> DEVINL void wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N) : "memory"); }
 template <int N> DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
@@ -72,9 +78,11 @@ struct RowParams {
 // so that lane group a = lane>>4 ends up with 8 CONTIGUOUS output columns (t = MFMA tile 0/1, b = accumulator register)
 DEVINL int perm32(int r) { return (((r >> 2) & 3) << 3) | (((r >> 4) & 1) << 2) | (r & 3); }
 
-template <int EPI, bool DP, int NW, bool STAG = false>
+template <int EPI, bool DP, int NW, bool STAG = false, bool SPEC = false>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_row_kernel(RowParams p) {
     static_assert(!STAG || NW == 8, "the stagger pairs waves w and w + 4 of one SIMD");
+    static_assert(!SPEC || NW == 8, "role-split staging needs the two wave groups");
+    constexpr int ASLOTS = SPEC ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALVES = NW / 4;                   // 112-row halves of the tile
     constexpr int ATILE = HALVES * RTILE;            // one A slot: 128 LDS rows per half
@@ -95,36 +103,47 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_row_kernel(RowParams p) {
     // and pieces WP w .. WP w + WP - 1 of every W chunk.  W chunk c: LDS rows 32 q + j (q = owning column quarter) <- weight
     // rows 96 q + 32 c + perm32(j)
     const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
-    unsigned aoff[4], woff[WP];                                      // per-lane byte offsets from the uniform bases
+    // per-lane byte offsets from the uniform bases.  SPEC: one array, A offsets (8 pieces) on waves 4-7, W offsets (4
+    // pieces of every chunk) on waves 0-3
+    constexpr int NA = SPEC ? 8 : 4, NWP = SPEC ? 4 : WP;
+    unsigned aoff[NA], woff_[SPEC ? 1 : WP];
+    unsigned (&woff)[SPEC ? NA : WP] = *(unsigned (*)[SPEC ? NA : WP])(SPEC ? aoff : woff_);
+    if (!SPEC || half) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (4 * wid + j) + sub;                       // LDS row of the slot
-        const int rt = 112 * (r >> 7) + (r & 127);                   // tile row (LDS rows 112..127 of a half are never read)
-        int m = (r & 127) < 112 ? m0 + rt : m0;
-        m = m < p.M ? m : p.M - 1;                                   // clamp: rows outside the tile are never stored
-        aoff[j] = ((unsigned)m * (unsigned)p.lda + schunk * 8) * 2u;
+        for (int j = 0; j < NA; ++j) {
+            const int r = 8 * (NA * (SPEC ? wq : wid) + j) + sub;    // LDS row of the slot
+            const int rt = 112 * (r >> 7) + (r & 127);               // tile row (LDS rows 112..127 of a half are never read)
+            int m = (r & 127) < 112 ? m0 + rt : m0;
+            m = m < p.M ? m : p.M - 1;                               // clamp: rows outside the tile are never stored
+            aoff[j] = ((unsigned)m * (unsigned)p.lda + schunk * 8) * 2u;
+        }
     }
+    if (!SPEC || !half) {
 #pragma unroll
-    for (int j = 0; j < WP; ++j) {
-        const int r = 8 * (WP * wid + j) + sub;
-        woff[j] = ((unsigned)(n0 + 96 * (r >> 5) + perm32(r & 31)) * (unsigned)p.ldw + schunk * 8) * 2u;
+        for (int j = 0; j < NWP; ++j) {
+            const int r = 8 * (NWP * (SPEC ? wq : wid) + j) + sub;
+            woff[j] = ((unsigned)(n0 + 96 * (r >> 5) + perm32(r & 31)) * (unsigned)p.ldw + schunk * 8) * 2u;
+        }
     }
     char* const sA = smem;
-    char* const sW = smem + 2 * ATILE;
+    char* const sW = smem + ASLOTS * ATILE;
     const char* const Ab = (const char*)p.A;
     const char* const Wb = (const char*)p.W;
     const size_t wchunk = (size_t)32 * p.ldw * 2;                    // bytes between chunk c and c + 1 of a wave's columns
-    auto issue_a = [&](int kt) {
-        char* s = sA + (kt & 1) * ATILE + (4 * wid) * 1024;
+    // pieces [J0, J1) of this wave's share of A(kt) into ring slot `slot`
+    auto issue_a_part = [&](int kt, int slot, auto j0c, auto j1c) {
+        constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;
+        char* s = sA + slot * ATILE + (NA * (SPEC ? wq : wid)) * 1024;
         const char* b = Ab + (size_t)kt * (RBK * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(b + aoff[j], s + j * 1024);
+        for (int j = J0; j < J1; ++j) glds16(b + aoff[j], s + j * 1024);
     };
+    auto issue_a = [&](int kt) { issue_a_part(kt, SPEC ? kt % 3 : (kt & 1), std::integral_constant<int, 0>{}, std::integral_constant<int, NA>{}); };
     auto issue_w = [&](int kt, int c) {
-        char* s = sW + c * RTILE + (WP * wid) * 1024;
+        char* s = sW + c * RTILE + (NWP * (SPEC ? wq : wid)) * 1024;
         const char* b = Wb + c * wchunk + (size_t)kt * (RBK * 2);
 #pragma unroll
-        for (int j = 0; j < WP; ++j) glds16(b + woff[j], s + j * 1024);
+        for (int j = 0; j < NWP; ++j) glds16(b + woff[j], s + j * 1024);
     };
 
     f32x4 acc[RMT][6];
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_row_kernel(RowParams p) {
     bf16x8 fa[RMT], fb[2];
 #define ROW_READ(C, KS)                                                                         \
     {                                                                                           \
-        const char* sa = sA + (kt & 1) * ATILE + half * RTILE;                                  \
+        const char* sa = sA + aslot * ATILE + half * RTILE;                                     \
         const char* sb = sW + (C) * RTILE;                                                      \
         _Pragma("unroll") for (int t = 0; t < 2; ++t)                                           \
             fb[t] = *(const bf16x8*)(sb + swz(32 * wq + 16 * t + li, (KS) * 4 + g));            \
@@ -173,42 +192,89 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_row_kernel(RowParams p) {
     }
 
     const int nk = p.K / RBK;
-    issue_a(0);
-    issue_w(0, 0);
-    issue_w(0, 1);
-    wait_vm<WP>();                                                   // A(0), W(0,0) landed; W(0,1) may fly
+    if constexpr (SPEC) {
+        if (half) {                                                  // A waves: two tiles ahead from the start
+            issue_a(0);
+            if (nk > 1) { issue_a(1); wait_vm<8>(); } else wait_vm<0>();
+        } else {
+            issue_w(0, 0);
+            issue_w(0, 1);
+            wait_vm<4>();                                            // W(0,0) landed; W(0,1) may fly
+        }
+    } else {
+        issue_a(0);
+        issue_w(0, 0);
+        issue_w(0, 1);
+        wait_vm<WP>();                                               // A(0), W(0,0) landed; W(0,1) may fly
+    }
     __builtin_amdgcn_s_barrier();
     // STAG (eight waves): waves 4-7, the SIMD partners of waves 0-3, run HALF A PHASE behind inside every barrier interval:
     // the fragments of a chunk's second k-half stay in registers across the barrier (so the LDS slot may be refilled) and
     // their 14 MFMAs open the next interval while the partner wave reads its fragments, and the two alternate from there —
     // one wave of each SIMD in the matrix pipe, the other in the LDS (MI355X_MICROARCH.md, two waves per SIMD, item 9).
-    // The two schedules are two complete copies of the loop (same barrier count), chosen once per wave.
-    auto kloop = [&](auto late_c) {
-        constexpr bool LATE = decltype(late_c)::value;
+    // The two wave groups run two complete copies of the loop (same barrier count), chosen once per wave.
+    auto kloop = [&](auto grp_c) {
+        constexpr bool GRP1 = decltype(grp_c)::value;                // waves 4-7
+        constexpr bool LATE = STAG && GRP1;
+        using I = std::integral_constant<int, 0>;
         if constexpr (LATE) {                                        // the first "previous k-half" adds zeros
 #pragma unroll
             for (int t = 0; t < RMT; ++t) fa[t] = zero8();
             fb[0] = zero8(); fb[1] = zero8();
         }
+        int aslot = 0, anext = SPEC ? 2 : 1;                         // ring slots of A(kt) and of the tile issued in step kt
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk;
-            // sub-step 0: needs A(kt), W(kt,0).  Issue W(kt,2) then A(kt+1) (A last: it may stay in flight longest)
-            issue_w(kt, 2);
-            if (more) issue_a(kt + 1);
-            ROW_COMPUTE(0, 2)
-            ROW_WAIT(WP + 4, WP)                                     // W(kt,1) landed; W(kt,2) [+ A(kt+1)] in flight
-            // sub-step 1
-            if (more) issue_w(kt + 1, 0);
-            ROW_COMPUTE(1, 0)
-            ROW_WAIT(4 + WP, 0)                                      // W(kt,2) landed; A(kt+1), W(kt+1,0) in flight
-            // sub-step 2
-            if (more) issue_w(kt + 1, 1);
-            ROW_COMPUTE(2, 1)
-            ROW_WAIT(WP, 0)                                          // A(kt+1), W(kt+1,0) landed; W(kt+1,1) in flight
+            if constexpr (!SPEC) {
+                // sub-step 0: needs A(kt), W(kt,0).  Issue W(kt,2) then A(kt+1) (A last: it may stay in flight longest)
+                issue_w(kt, 2);
+                if (more) issue_a(kt + 1);
+                ROW_COMPUTE(0, 2)
+                ROW_WAIT(WP + 4, WP)                                 // W(kt,1) landed; W(kt,2) [+ A(kt+1)] in flight
+                if (more) issue_w(kt + 1, 0);
+                ROW_COMPUTE(1, 0)
+                ROW_WAIT(4 + WP, 0)                                  // W(kt,2) landed; A(kt+1), W(kt+1,0) in flight
+                if (more) issue_w(kt + 1, 1);
+                ROW_COMPUTE(2, 1)
+                ROW_WAIT(WP, 0)                                      // A(kt+1), W(kt+1,0) landed; W(kt+1,1) in flight
+                aslot ^= 1;
+            } else if constexpr (GRP1) {
+                // A waves: A(kt+2) goes out in three parts (3 + 3 + 2 pieces) into the slot A(kt-1) left; the only wait is
+                // at the end of the K-step: A(kt+1) landed, the 8 pieces of A(kt+2) may fly
+                const bool more2 = kt + 2 < nk;
+                (void)I{};
+                if (more2) issue_a_part(kt + 2, anext, std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+                ROW_COMPUTE(0, 2)
+                wait_vm_lgkm0<63>();                                 // (vmcnt 63 = no wait on loads)
+                __builtin_amdgcn_s_barrier();
+                if (more2) issue_a_part(kt + 2, anext, std::integral_constant<int, 3>{}, std::integral_constant<int, 6>{});
+                ROW_COMPUTE(1, 0)
+                wait_vm_lgkm0<63>();
+                __builtin_amdgcn_s_barrier();
+                if (more2) issue_a_part(kt + 2, anext, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+                ROW_COMPUTE(2, 1)
+                if (more2) wait_vm_lgkm0<8>(); else wait_vm_lgkm0<0>();
+                __builtin_amdgcn_s_barrier();
+                aslot = aslot == 2 ? 0 : aslot + 1;
+                anext = anext == 2 ? 0 : anext + 1;
+            } else {
+                // W waves: chunk q + 2 goes out in sub-step q; at its end chunk q + 1 has landed, the one just issued may fly
+                issue_w(kt, 2);
+                ROW_COMPUTE(0, 2)
+                wait_vm_lgkm0<4>();
+                __builtin_amdgcn_s_barrier();
+                if (more) issue_w(kt + 1, 0);
+                ROW_COMPUTE(1, 0)
+                ROW_WAIT(4, 0)
+                if (more) issue_w(kt + 1, 1);
+                ROW_COMPUTE(2, 1)
+                ROW_WAIT(4, 0)
+                aslot = aslot == 2 ? 0 : aslot + 1;
+            }
         }
         if constexpr (LATE) { ROW_MMA(2) }                           // the last chunk's second k-half
     };
-    if (STAG && half) kloop(std::true_type{});
+    if ((STAG || SPEC) && half) kloop(std::true_type{});
     else kloop(std::false_type{});
 #undef ROW_READ
 #undef ROW_MMA
@@ -480,12 +546,13 @@ bool use_eight_waves(int M) {
     return M >= 256 * 112;
 }
 
-template <int EPI, bool DP, int NW, bool STAG = false>
+template <int EPI, bool DP, int NW, bool STAG = false, bool SPEC = false>
 int launch_row_nw(RowParams& p, void* stream) {
     static thread_local bool set = false;
     if (!set) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_row_kernel<EPI, DP, NW, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                row_lds<NW>()) != hipSuccess)
+        constexpr int lds_max = row_lds<NW, SPEC>();
+        if (hipFuncSetAttribute((const void*)gemm_nt_row_kernel<EPI, DP, NW, STAG, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_max) != hipSuccess)
             return SAIS_ERR_LAUNCH;
         set = true;
     }
@@ -493,7 +560,8 @@ int launch_row_nw(RowParams& p, void* stream) {
     if ((double)p.M * p.lda * 2.0 >= 4294967296.0 || (double)p.N * p.ldw * 2.0 >= 4294967296.0) return SAIS_ERR_ARG;
     p.rows_per_tile = rows_per_tile<NW>(p.M);
     const int grid = (p.N / RBN) * ((p.M + p.rows_per_tile - 1) / p.rows_per_tile);
-    hipLaunchKernelGGL((gemm_nt_row_kernel<EPI, DP, NW, STAG>), dim3(grid), dim3(64 * NW), row_lds<NW>(), (hipStream_t)stream, p);
+    constexpr int lds = row_lds<NW, SPEC>();
+    hipLaunchKernelGGL((gemm_nt_row_kernel<EPI, DP, NW, STAG, SPEC>), dim3(grid), dim3(64 * NW), lds, (hipStream_t)stream, p);
     return sais_check_launch();
 }
 
@@ -501,6 +569,8 @@ template <int EPI, bool DP>
 int launch_row_dp(RowParams& p, void* stream) {
     static const bool stag = [] { const char* e = getenv("SAIS_ROW_STAG"); return e ? atoi(e) != 0 : true; }();
     if (!use_eight_waves(p.M)) return launch_row_nw<EPI, DP, 4>(p, stream);
+    static const bool spec = [] { const char* e = getenv("SAIS_ROW_SPEC"); return e ? atoi(e) != 0 : true; }();
+    if (spec) return stag ? launch_row_nw<EPI, DP, 8, true, true>(p, stream) : launch_row_nw<EPI, DP, 8, false, true>(p, stream);
     return stag ? launch_row_nw<EPI, DP, 8, true>(p, stream) : launch_row_nw<EPI, DP, 8, false>(p, stream);
 }
 

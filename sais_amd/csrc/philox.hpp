@@ -26,6 +26,19 @@ DEVINL unsigned philox_u32(const unsigned long long* state, unsigned sid, unsign
     return k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3];
 }
 
+// the whole block of four draws that covers elements idx .. idx + 3 (idx % 4 == 0): one tenth of the arithmetic per
+// element of four philox_u32 calls
+DEVINL void philox_u32x4(const unsigned long long* state, unsigned sid, unsigned long long idx, unsigned (&c)[4]) {
+    const unsigned long long seed = state[0], off = state[1], q = idx >> 2;
+    c[0] = (unsigned)q; c[1] = (unsigned)(q >> 32); c[2] = sid; c[3] = (unsigned)off;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32) ^ (unsigned)(off >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
 // p in [0, 1): threshold on the raw 32-bit draw; p = 0 keeps everything
 // (4294967040 = 2^32 - 256 is the largest fp32 below 2^32: the clamp keeps the float -> unsigned conversion defined)
 DEVINL unsigned drop_threshold(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967040.0f); }

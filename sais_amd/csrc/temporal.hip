@@ -40,9 +40,10 @@ __global__ void prepare_fwd_kernel(const float* x, long x_clip_stride, long x_fr
     }
 }
 
-// dz = dz32 + dz16 ; dx[b,t] (+)= dz[b,1+t] ; dpos[t] += sum_b ; dcls += sum_b dz[b,0]
-__global__ void prepare_bwd_kernel(const float* dz32, const bf16* dz16, int B, int T, float* dx, long dx_clip_stride,
-                                   long dx_frame_stride, int accumulate, float* dpos, float* dcls) {
+// dz = dz32 + sum_z slabs[z] (either may be absent) ; dx[b,t] (+)= dz[b,1+t] ; dpos[t] += sum_b ; dcls += sum_b dz[b,0]
+__global__ void prepare_bwd_kernel(const float* dz32, const float* slabs, int nslab, long slab_stride, int B, int T,
+                                   float* dx, long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos,
+                                   float* dcls) {
     const int S = T + 1;
     int i = blockIdx.x * 256 + threadIdx.x;            // over S*D
     if (i >= S * D) return;
@@ -50,7 +51,8 @@ __global__ void prepare_bwd_kernel(const float* dz32, const bf16* dz16, int B, i
     float acc = 0.f;
     for (int b = 0; b < B; ++b) {
         size_t idx = ((size_t)b * S + s) * D + c;
-        float v = dz32[idx] + (dz16 ? (float)dz16[idx] : 0.f);
+        float v = dz32 ? dz32[idx] : 0.f;
+        for (int z = 0; z < nslab; ++z) v += slabs[(size_t)z * slab_stride + idx];
         acc += v;
         if (s > 0 && dx) {
             float* o = dx + (size_t)b * dx_clip_stride + (size_t)(s - 1) * dx_frame_stride + c;
@@ -138,9 +140,10 @@ __global__ __launch_bounds__(1024) void tattn_fwd_kernel(const float* qkv, const
 
 // With dropout: ctx = P' v, P' = P m / (1 - p).  dV = P'^T dctx; dP = (dctx v^T) m / (1 - p); dS = P (dP - rowsum(P dP)).
 // The mask is regenerated from (rng, sid) and kept in the SIGN BIT of the stored P (P >= 0): negative = dropped.
+// dctx = sum_z dctx[z] (nslab raw split-K slabs of the out_proj dX GEMM, slab_stride floats apart; nslab = 1: a plain tensor)
 __global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const unsigned char* key_pad, int S,
-                                                        const float* dctx, float* dqkv, float p_drop,
-                                                        const unsigned long long* rng, unsigned sid) {
+                                                        const float* dctx, int nslab, long slab_stride, float* dqkv,
+                                                        float p_drop, const unsigned long long* rng, unsigned sid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sQ = (float*)smem;
     float* sK = sQ + S * QS;
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const
     for (int i = tid; i < S * (THD / 4); i += nt) {
         int s = i / (THD / 4), c4 = i % (THD / 4);
         f32x4 v = *(const f32x4*)(dctx + ((size_t)b * S + s) * D + h * THD + 4 * c4);
+        for (int z = 1; z < nslab; ++z) v += *(const f32x4*)(dctx + (size_t)z * slab_stride + ((size_t)b * S + s) * D + h * THD + 4 * c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sG[s * QS + 4 * c4 + e] = v[e];
     }
@@ -445,13 +449,14 @@ extern "C" int sais_temporal_prepare_fwd(const float* x, long x_clip_stride, lon
     return sais_check_launch();
 }
 
-extern "C" int sais_temporal_prepare_bwd(const float* dz_f32, const void* dz_bf16, int B, int T, float* dx,
-                                         long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos,
+extern "C" int sais_temporal_prepare_bwd(const float* dz_f32, const float* slabs, int nslab, long slab_stride, int B, int T,
+                                         float* dx, long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos,
                                          float* dcls, void* stream) {
     SAIS_ENTER();
-    if (!dz_f32 || !dpos || !dcls || B <= 0 || T <= 0) return SAIS_ERR_ARG;
+    if ((!dz_f32 && !slabs) || (slabs && nslab <= 0) || !dpos || !dcls || B <= 0 || T <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(prepare_bwd_kernel, dim3(((T + 1) * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz_f32,
-                       (const bf16*)dz_bf16, B, T, dx, dx_clip_stride, dx_frame_stride, accumulate, dpos, dcls);
+                       slabs, slabs ? nslab : 0, slab_stride, B, T, dx, dx_clip_stride, dx_frame_stride, accumulate, dpos,
+                       dcls);
     return sais_check_launch();
 }
 
@@ -471,16 +476,16 @@ extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key
 }
 
 extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B, int S,
-                                      const float* dctx, float* dqkv, float p_drop,
+                                      const float* dctx, int nslab, long slab_stride, float* dqkv, float p_drop,
                                       const unsigned long long* rng_state, unsigned site, void* stream) {
     SAIS_ENTER();
-    if (!qkv || !key_pad || !dctx || !dqkv || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_BWD)
+    if (!qkv || !key_pad || !dctx || !dqkv || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_BWD || nslab <= 0 || (slab_stride & 3))
         return SAIS_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !rng_state)) return SAIS_ERR_ARG;
     int lds = (4 * S * QS + 2 * S * (S + 1)) * 4;
     if (set_lds(tattn_bwd_kernel, lds)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(1024), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, dqkv,
-                       p_drop, rng_state, site);
+    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(1024), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, nslab,
+                       slab_stride, dqkv, p_drop, rng_state, site);
     return sais_check_launch();
 }
 

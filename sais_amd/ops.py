@@ -147,6 +147,39 @@ def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None, drop=None):
     return out
 
 
+def tgemm(a, w, epilogue, out, bias=None, aux=None, nsplit=1, drop=None):
+    """Temporal-encoder linear layer (include/sais_hip.h, sais_tgemm): out = a f32[M,K] . w f32[N,K]^T on the bf16x3 path.
+    epilogue L.TG_RAW: out is f32 [nsplit, M, N] of partial sums (consumed by temporal_ln_fwd / _bwd, temporal_attn_bwd,
+    temporal_prepare_bwd); TG_BIAS / TG_BIAS_RELU / TG_DRELU: out f32 [M, N].  drop = (p, rng_state, site)."""
+    _chk(a, F32, "A"); _chk(w, F32, "W"); _chk(bias, F32, "bias"); _chk(out, F32, "out"); _chk(aux, F32, "aux")
+    M, K = a.shape
+    N = w.shape[0]
+    g = L.SaisTGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, nsplit, _p(bias), _p(aux),
+                    0 if aux is None else aux.stride(0), _p(out), out.stride(-2),
+                    0.0 if drop is None else float(drop[0]), None if drop is None else _p(drop[1]),
+                    0 if drop is None else int(drop[2]))
+    _timed("tgemm", 2.0 * M * N * K, 4 * (M * K + N * K + M * N), lambda: L.call("sais_tgemm", ctypes.byref(g), _stream()))
+    return out
+
+
+def temporal_ln_fwd(slabs, bias, resid, gamma, beta, eps, z, y=None, mean=None, rstd=None, drop=None):
+    """y = resid + drop(sum_z slabs[z] + bias) ; z = LayerNorm(y).  slabs f32 [nslab, M, 384]."""
+    _chk(slabs, F32, "slabs"); _chk(resid, F32, "resid"); _chk(z, F32, "z"); _chk(y, F32, "y")
+    L.call("sais_temporal_ln_fwd", _p(slabs), slabs.shape[0], slabs.stride(0), _p(bias), _p(resid), slabs.shape[1],
+           0.0 if drop is None else float(drop[0]), None if drop is None else _p(drop[1]), 0 if drop is None else int(drop[2]),
+           _p(y), _p(gamma), _p(beta), eps, _p(z), _p(mean), _p(rstd), _stream())
+
+
+def temporal_ln_bwd(slabs, add, x, mean, rstd, gamma, dx, dx_drop=None, drop=None, dgamma=None, dbeta=None):
+    """dy = sum_z slabs[z] + add ; dx = LayerNorm'(dy) at (x, mean, rstd) ; dx_drop = drop(dx)."""
+    _chk(slabs, F32, "slabs"); _chk(add, F32, "add"); _chk(x, F32, "x"); _chk(dx, F32, "dx"); _chk(dx_drop, F32, "dx_drop")
+    rows = x.shape[0]
+    L.call("sais_temporal_ln_bwd", _p(slabs), 0 if slabs is None else slabs.shape[0], 0 if slabs is None else slabs.stride(0),
+           _p(add), _p(x), _p(mean), _p(rstd), _p(gamma), rows, _p(dx), _p(dx_drop),
+           0.0 if drop is None else float(drop[0]), None if drop is None else _p(drop[1]), 0 if drop is None else int(drop[2]),
+           _p(dgamma), _p(dbeta), _stream())
+
+
 def gemm_tn(p, q, dW, db=None, nsplit=None):
     """dW[N1,N2] += p[M,N1]^T . q[M,N2] ; db[N1] += colsum(p).  p, q both bf16 or both f32."""
     f32 = p.dtype == F32
@@ -273,8 +306,11 @@ def temporal_prepare_fwd(x, clip_stride, frame_stride, pos, cls, B, T, z32, z16)
            _stream())
 
 
-def temporal_prepare_bwd(dz32, dz16, B, T, dx, clip_stride, frame_stride, accumulate, dpos, dcls):
-    L.call("sais_temporal_prepare_bwd", _p(dz32), _p(dz16), B, T, _p(dx), clip_stride, frame_stride,
+def temporal_prepare_bwd(dz32, slabs, B, T, dx, clip_stride, frame_stride, accumulate, dpos, dcls):
+    """dz = dz32 (f32 [B*(T+1),384] or None) + sum of the raw split-K slabs (f32 [nslab, B*(T+1), 384] or None)."""
+    _chk(dz32, F32, "dz32"); _chk(slabs, F32, "slabs")
+    L.call("sais_temporal_prepare_bwd", _p(dz32), _p(slabs), 0 if slabs is None else slabs.shape[0],
+           0 if slabs is None else slabs.stride(0), B, T, _p(dx), clip_stride, frame_stride,
            1 if accumulate else 0, _p(dpos), _p(dcls), _stream())
 
 
@@ -284,8 +320,10 @@ def temporal_attn_fwd(qkv, key_pad_u8, B, S, ctx, attn_avg=None, p_drop=0.0, rng
 
 
 def temporal_attn_bwd(qkv, key_pad_u8, B, S, dctx, dqkv, p_drop=0.0, rng=None, site=0):
-    L.call("sais_temporal_attn_bwd", _p(qkv), _p(key_pad_u8), B, S, _p(dctx), _p(dqkv), float(p_drop), _p(rng), site,
-           _stream())
+    """dctx: f32 [B*S,384], or the raw split-K slabs [nslab, B*S, 384] of the out_proj dX GEMM (summed on load)."""
+    nslab, stride = (dctx.shape[0], dctx.stride(0)) if dctx.dim() == 3 else (1, 0)
+    L.call("sais_temporal_attn_bwd", _p(qkv), _p(key_pad_u8), B, S, _p(dctx), nslab, stride, _p(dqkv), float(p_drop),
+           _p(rng), site, _stream())
 
 
 # ---- train-mode dropout: rng = int64 device tensor {seed, offset} (include/sais_hip.h)

@@ -23,22 +23,16 @@ def golden():
 
 
 # ---- worst observed deviation per parity quantity of a run (report the values, not just pass / fail).
-# Tests call parity_log(name, value, bar); the session writes gpurun_out/parity_worst.json (max per name).
-_WORST = {}
-
-
-def parity_log(name, value, bar):
-    v = float(value)
-    cur = _WORST.get(name)
-    if cur is None or v > cur["worst"]:
-        _WORST[name] = {"worst": v, "bar": float(bar)}
+# Tests call parity.parity_log(name, value, bar); the session writes gpurun_out/parity_worst.json (max per name).
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if not _WORST:
+    import parity
+    if not parity.WORST:
         return
     import json
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_worst.json"), "w") as fh:
-        json.dump(dict(sorted(_WORST.items())), fh, indent=1)
+        json.dump(dict(sorted(parity.WORST.items())), fh, indent=1)

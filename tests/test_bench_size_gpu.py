@@ -85,7 +85,7 @@ def test_train_step_stagewise_vs_oracle_at_benchmark_dispatch(gpu, B, T):
         e_ref, a_ref = O.temporal_forward(tsd, reps_ref.detach().view(B, 1, T, 384), None, pad, None, "RGB")
         sim_ref = O.cosine_logits(e_ref, pr)
         loss_ref = O.nce_loss(e_ref, lab, pr)
-    from conftest import parity_log
+    from parity import parity_log
     tag = f"step[B{B},T{T}]/"
     dfeat = (reps.detach().cpu() - reps_ref.detach()).abs().max().item()
     parity_log(tag + "features max-abs / max|ref|", dfeat / reps_ref.detach().abs().max().item(), FEAT_REL)
