@@ -217,9 +217,27 @@ class fullModel(nn.Module):
         return pad.to(device=dev, dtype=torch.uint8).contiguous()
 
     # ------------------------------------------------------------------ kernels
-    # All temporal activations are fp32 in HBM (they are tiny: clips*(T+1) rows) and every nn.Linear runs
-    # on sais_gemm_nt_f32 (bf16x3 split on the matrix cores): the cosine logits inherit ~fp32 accuracy
-    # from this half of the path, leaving the whole 1e-3 budget to the bf16 ViT.
+    # All temporal activations are fp32 in HBM (they are tiny: clips*(T+1) rows) and every nn.Linear runs on sais_tgemm
+    # (bf16x3 split on the matrix cores, 64 x 64 tiles): the cosine logits inherit ~fp32 accuracy from this half of the
+    # path, leaving the whole 1e-3 budget to the bf16 ViT.  The N = 384 GEMMs (out_proj, linear2 and every dX) write RAW
+    # split-K slabs; the kernel that consumes them (LayerNorm forward / backward, attention backward, prepare backward)
+    # sums the slabs and applies bias / dropout / residual itself, so a layer is 7 launches forward and 8 backward.
+    @staticmethod
+    def _nsplit(M, N, K):
+        """K splits of a RAW GEMM: as many workgroups as fit one round of the chip, at least two K-steps each."""
+        tiles, nk, best = -(-M // 64) * (N // 64), K // 64, 1
+        for ns in range(1, nk + 1):
+            if nk % ns == 0 and nk // ns >= 2 and tiles * ns <= 256:
+                best = ns
+        return best
+
+    def _raw(self, a, w):
+        """a . w^T as raw split-K slabs f32 [nsplit, M, N] (ops.tgemm, TG_RAW)."""
+        M, N, K = a.shape[0], w.shape[0], w.shape[1]
+        ns = self._nsplit(M, N, K)
+        out = torch.empty(ns, M, N, dtype=torch.float32, device=a.device)
+        return ops.tgemm(a, w, L.TG_RAW, out, nsplit=ns)
+
     def _stream_fwd(self, x, pad, save, want_attn, drop=None, sidx=0):
         fl = self.flat
         dev = x.device
@@ -239,29 +257,28 @@ class fullModel(nn.Module):
             p = self._lnames(l)
             last = l == self.nlayers - 1
             qkv, ctx = e32(M, 3 * D), e32(M, D)
-            ops.gemm_nt_f32(z, fl.w32(p + "self_attn.in_proj_weight"), L.EPI_BIAS_F32, qkv,
-                            bias=fl.w32(p + "self_attn.in_proj_bias"))
+            ops.tgemm(z, fl.w32(p + "self_attn.in_proj_weight"), L.TG_BIAS, qkv, bias=fl.w32(p + "self_attn.in_proj_bias"))
             if want_attn and last:
                 attn = e32(B, S, S)
             # train mode: dropout sites 0-3 of this layer (attention weights, dropout1, dropout, dropout2)
             site = (sidx * self.nlayers + l) * 4
             pd, rng = drop if drop is not None else (0.0, None)
             ops.temporal_attn_fwd(qkv, pad, B, S, ctx, attn if last else None, p_drop=pd, rng=rng, site=site)
-            y1 = e32(M, D)
-            dsite = (lambda k: None if drop is None else (pd, rng, site + k))      # dropout fused into the GEMM epilogues
-            ops.gemm_nt_f32(ctx, fl.w32(p + "self_attn.out_proj.weight"), L.EPI_BIAS_RESID_F32, y1,
-                            bias=fl.w32(p + "self_attn.out_proj.bias"), aux=z, drop=dsite(1))   # src + dropout1(out_proj(ctx))
-            z1, m1, r1 = e32(M, D), e32(M), e32(M)
-            ops.layernorm_fwd(y1, M, D, fl.w32(p + "norm1.weight"), fl.w32(p + "norm1.bias"), 1e-5, y32=z1, mean=m1, rstd=r1)
+            dsite = (lambda k: None if drop is None else (pd, rng, site + k))      # dropout fused into the consumers
+            # src = norm1(src + dropout1(out_proj(ctx)))
+            y1 = e32(M, D) if save else None
+            z1, m1, r1 = e32(M, D), (e32(M) if save else None), (e32(M) if save else None)
+            ops.temporal_ln_fwd(self._raw(ctx, fl.w32(p + "self_attn.out_proj.weight")), fl.w32(p + "self_attn.out_proj.bias"),
+                                z, fl.w32(p + "norm1.weight"), fl.w32(p + "norm1.bias"), 1e-5, z1, y=y1, mean=m1, rstd=r1,
+                                drop=dsite(1))
+            # src = norm2(src + dropout2(linear2(dropout(relu(linear1(src))))))
             h = e32(M, FF)
-            # src + dropout2(linear2(dropout(relu(linear1(src)))))
-            ops.gemm_nt_f32(z1, fl.w32(p + "linear1.weight"), L.EPI_BIAS_RELU_F32, h, bias=fl.w32(p + "linear1.bias"),
-                            drop=dsite(2))
-            y2 = e32(M, D)
-            ops.gemm_nt_f32(h, fl.w32(p + "linear2.weight"), L.EPI_BIAS_RESID_F32, y2, bias=fl.w32(p + "linear2.bias"),
-                            aux=z1, drop=dsite(3))
-            zo, m2, r2 = e32(M, D), e32(M), e32(M)
-            ops.layernorm_fwd(y2, M, D, fl.w32(p + "norm2.weight"), fl.w32(p + "norm2.bias"), 1e-5, y32=zo, mean=m2, rstd=r2)
+            ops.tgemm(z1, fl.w32(p + "linear1.weight"), L.TG_BIAS_RELU, h, bias=fl.w32(p + "linear1.bias"), drop=dsite(2))
+            y2 = e32(M, D) if save else None
+            zo, m2, r2 = e32(M, D), (e32(M) if save else None), (e32(M) if save else None)
+            ops.temporal_ln_fwd(self._raw(h, fl.w32(p + "linear2.weight")), fl.w32(p + "linear2.bias"), z1,
+                                fl.w32(p + "norm2.weight"), fl.w32(p + "norm2.bias"), 1e-5, zo, y=y2, mean=m2, rstd=r2,
+                                drop=dsite(3))
             if save:
                 layers.append(dict(z=z, qkv=qkv, ctx=ctx, y1=y1, m1=m1, r1=r1, z1=z1, h=h, y2=y2, m2=m2, r2=r2))
             z = zo
@@ -310,6 +327,7 @@ class fullModel(nn.Module):
         B, T = s["B"], s["T"]
         S, M = T + 1, B * (T + 1)
         e32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        slabs, add = None, dz                      # the gradient entering a layer = sum of `slabs` (raw dX GEMM output) + add
         for l in reversed(range(self.nlayers)):
             p = self._lnames(l)
             a = s["layers"][l]
@@ -322,24 +340,19 @@ class fullModel(nn.Module):
             dsite = (lambda k: None if drop is None else (pd, rng, site + k))
             dy2 = e32(M, D)
             dt2 = dy2 if drop is None else e32(M, D)
-            ops.layernorm_bwd(a["y2"], D, a["m2"], a["r2"], fl.w32(p + "norm2.weight"), M, dy32=dz, dx32=dy2,
-                              dgamma=fl.g(p + "norm2.weight"), dbeta=fl.g(p + "norm2.bias"),
-                              dx32_drop=None if drop is None else dt2, drop=dsite(3))
+            ops.temporal_ln_bwd(slabs, add, a["y2"], a["m2"], a["r2"], fl.w32(p + "norm2.weight"), dy2,
+                                dx_drop=None if drop is None else dt2, drop=dsite(3),
+                                dgamma=fl.g(p + "norm2.weight"), dbeta=fl.g(p + "norm2.bias"))
             dh = e32(M, FF)
-            ops.gemm_nt_f32(dt2, fl.wt16[p + "linear2.weight"], L.EPI_DRELU_F32, dh, aux=a["h"], drop=dsite(2))
-            dz1 = e32(M, D)                                   # = dy2 (residual) + dh . W1
-            ops.gemm_nt_f32(dh, fl.wt16[p + "linear1.weight"], L.EPI_BIAS_RESID_F32, dz1, aux=dy2)
-            dy1 = e32(M, D)
+            ops.tgemm(dt2, fl.wt16[p + "linear2.weight"], L.TG_DRELU, dh, aux=a["h"], drop=dsite(2))
+            dy1 = e32(M, D)                                   # LayerNorm'(dy2 (residual) + dh . W1)
             dt1 = dy1 if drop is None else e32(M, D)
-            ops.layernorm_bwd(a["y1"], D, a["m1"], a["r1"], fl.w32(p + "norm1.weight"), M, dy32=dz1, dx32=dy1,
-                              dgamma=fl.g(p + "norm1.weight"), dbeta=fl.g(p + "norm1.bias"),
-                              dx32_drop=None if drop is None else dt1, drop=dsite(1))
-            dctx = e32(M, D)
-            ops.gemm_nt_f32(dt1, fl.wt16[p + "self_attn.out_proj.weight"], L.EPI_BIAS_F32, dctx)
+            ops.temporal_ln_bwd(self._raw(dh, fl.wt16[p + "linear1.weight"]), dy2, a["y1"], a["m1"], a["r1"],
+                                fl.w32(p + "norm1.weight"), dy1, dx_drop=None if drop is None else dt1, drop=dsite(1),
+                                dgamma=fl.g(p + "norm1.weight"), dbeta=fl.g(p + "norm1.bias"))
             dqkv = e32(M, 3 * D)
-            ops.temporal_attn_bwd(a["qkv"], s["pad"], B, S, dctx, dqkv, p_drop=pd, rng=rng, site=site)
-            dz = e32(M, D)                                    # = dy1 (residual) + dqkv . Win
-            ops.gemm_nt_f32(dqkv, fl.wt16[p + "self_attn.in_proj_weight"], L.EPI_BIAS_RESID_F32, dz, aux=dy1)
+            ops.temporal_attn_bwd(a["qkv"], s["pad"], B, S, self._raw(dt1, fl.wt16[p + "self_attn.out_proj.weight"]), dqkv,
+                                  p_drop=pd, rng=rng, site=site)
             # the four weight / bias gradients of the layer in one launch (M is a few hundred rows: launch-bound); one M-split:
             # every workgroup owns its output tile and accumulates without atomics
             ops.gemm_tn_grouped([
@@ -347,11 +360,13 @@ class fullModel(nn.Module):
                 (dh, a["z1"], fl.g(p + "linear1.weight"), fl.g(p + "linear1.bias")),
                 (dt1, a["ctx"], fl.g(p + "self_attn.out_proj.weight"), fl.g(p + "self_attn.out_proj.bias")),
                 (dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))], M, nsplit=1)
+            # gradient wrt the layer input = dy1 (residual) + dqkv . Win: left as slabs for the next consumer
+            slabs, add = self._raw(dqkv, fl.wt16[p + "self_attn.in_proj_weight"]), dy1
         x = s["x"]
         dx = torch.empty_like(x) if need_dx else None
         self._touched_T = max(self._touched_T, T)
         o = fl.offsets["frame_pos_embeddings.0"]
-        ops.temporal_prepare_bwd(dz, None, B, T, dx, 0 if dx is None else dx.stride(0), 0 if dx is None else dx.stride(2),
+        ops.temporal_prepare_bwd(add, slabs, B, T, dx, 0 if dx is None else dx.stride(0), 0 if dx is None else dx.stride(2),
                                  False, fl.grad[o:o + T * D], fl.g("frame_cls"))
         return dx
 

@@ -329,6 +329,12 @@ def test_temporal_attention_fwd_bwd(ops, S, lens):
     dqkv = torch.empty(B * S, 1152, device=DEV)
     ops.temporal_attn_bwd(qkv, padu, B, S, dctx, dqkv)
     assert_close(dqkv, qr.grad, atol=1e-4 * max(1.0, qr.grad.abs().max().item()), name="dqkv")
+    # dctx handed over as raw split-K slabs (summed on load)
+    parts = rnd(3, B * S, 384, seed=62)
+    parts[2] = dctx - parts[0] - parts[1]
+    dqkv2 = torch.empty_like(dqkv)
+    ops.temporal_attn_bwd(qkv, padu, B, S, parts, dqkv2)
+    assert_close(dqkv2, qr.grad, atol=2e-4 * max(1.0, qr.grad.abs().max().item()), name="dqkv (slabs)")
 
 
 @pytest.mark.parametrize("M,N,K", [(264, 1152, 384), (48, 384, 2048), (300, 256, 128)])
@@ -355,6 +361,82 @@ def test_gemm_nt_f32_bf16x3(ops, M, N, K):
     dW = torch.zeros(256, 128, device=DEV)
     ops.gemm_tn(p32, q32, dW, None)
     assert_close(dW, p32.to(torch.bfloat16).float().t() @ q32.to(torch.bfloat16).float(), atol=2e-3 * math.sqrt(M))
+
+
+@pytest.mark.parametrize("M,N,K", [(264, 1152, 384), (264, 384, 2048), (264, 2048, 384), (48, 384, 1152), (301, 64, 128)])
+def test_tgemm_bf16x3_epilogues_and_slabs(ops, M, N, K):
+    """sais_tgemm (the temporal encoder's 64 x 64 bf16x3 GEMM): every epilogue at ~fp32 accuracy, raw split-K slabs that sum
+    to the product for every legal split, dropout masks = the exported masks of the site."""
+    from sais_amd import _lib as L
+    a, w = rnd(M, K, seed=190), rnd(N, K, seed=191, scale=0.05)
+    bias, aux = rnd(N, seed=192, scale=0.1), rnd(M, N, seed=193)
+    prod = (a.double() @ w.double().t()).float()
+    tol = 2e-5 * math.sqrt(K)
+    out = torch.empty(M, N, device=DEV)
+    ops.tgemm(a, w, L.TG_BIAS, out, bias=bias)
+    assert_close(out, prod + bias, atol=tol, name="bias")
+    ops.tgemm(a, w, L.TG_BIAS, out)
+    assert_close(out, prod, atol=tol, name="no bias")
+    ops.tgemm(a, w, L.TG_BIAS_RELU, out, bias=bias)
+    assert_close(out, (prod + bias).relu(), atol=tol, name="relu")
+    ops.tgemm(a, w, L.TG_DRELU, out, aux=aux)
+    assert_close(out, prod * (aux > 0), atol=tol, name="drelu")
+    nk = K // 64
+    for ns in [d for d in (1, 2, 3, 4, 6, 8, 16) if nk % d == 0]:
+        slabs = torch.full((ns, M, N), float("nan"), device=DEV)
+        ops.tgemm(a, w, L.TG_RAW, slabs, nsplit=ns)
+        assert_close(slabs.sum(0), prod, atol=tol, name=f"raw slabs, nsplit {ns}")
+    with pytest.raises(L.SaisHipError):
+        ops.tgemm(a, w, L.TG_BIAS, out, nsplit=2)                      # only raw partial sums can be split
+    # train-mode dropout in the epilogues: mask element m * N + n of the site
+    st = ops.rng_state(3, DEV)
+    keep = ops.dropout_mask(M * N, 0.25, st, 5, DEV).view(M, N).float() / 0.75
+    ops.tgemm(a, w, L.TG_BIAS_RELU, out, bias=bias, drop=(0.25, st, 5))
+    assert_close(out, (prod + bias).relu() * keep, atol=2 * tol, name="relu + dropout")
+    ops.tgemm(a, w, L.TG_DRELU, out, aux=aux, drop=(0.25, st, 5))
+    assert_close(out, prod * (aux > 0) * keep, atol=2 * tol, name="drelu + dropout")
+
+
+@pytest.mark.parametrize("M,nslab", [(264, 3), (13, 1), (1000, 8)])
+def test_temporal_ln_fwd_bwd_consume_slabs(ops, M, nslab):
+    """y = resid + drop(sum slabs + bias), z = LayerNorm(y) and its backward with dy = sum slabs + add, vs torch."""
+    slabs = rnd(nslab, M, 384, seed=300)
+    bias, resid = rnd(384, seed=301, scale=0.1), rnd(M, 384, seed=302, scale=2.0)
+    gamma, beta = 1 + 0.1 * rnd(384, seed=303), 0.05 * rnd(384, seed=304)
+    st = ops.rng_state(9, DEV)
+    for p_drop in (0.0, 0.1):
+        keep = 1.0 if p_drop == 0 else ops.dropout_mask(M * 384, p_drop, st, 2, DEV).view(M, 384).float() / (1 - p_drop)
+        drop = None if p_drop == 0 else (p_drop, st, 2)
+        y, z = torch.empty(M, 384, device=DEV), torch.empty(M, 384, device=DEV)
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        ops.temporal_ln_fwd(slabs, bias, resid, gamma, beta, 1e-5, z, y=y, mean=mean, rstd=rstd, drop=drop)
+        y_ref = resid + (slabs.sum(0) + bias) * keep
+        assert_close(y, y_ref, atol=1e-5, name="y")
+        assert_close(z, F.layer_norm(y_ref, (384,), gamma, beta, 1e-5), atol=2e-5, name="z")
+        assert_close(mean, y_ref.mean(1), atol=1e-5, name="mean")
+        assert_close(rstd, 1 / torch.sqrt(y_ref.var(1, unbiased=False) + 1e-5), atol=0, rtol=1e-5, name="rstd")
+        z2 = torch.empty_like(z)
+        ops.temporal_ln_fwd(slabs, bias, resid, gamma, beta, 1e-5, z2, drop=drop)          # inference form: nothing saved
+        assert torch.equal(z2, z)
+        # backward at (y, mean, rstd)
+        add = rnd(M, 384, seed=305)
+        dy_ref = slabs.sum(0) + add
+        yr = y_ref.clone().requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        F.layer_norm(yr, (384,), gr, br, 1e-5).backward(dy_ref)
+        dx, dxd = torch.empty(M, 384, device=DEV), torch.empty(M, 384, device=DEV)
+        dg, db = torch.zeros(384, device=DEV), torch.zeros(384, device=DEV)
+        ops.temporal_ln_bwd(slabs, add, y, mean, rstd, gamma, dx, dx_drop=None if drop is None else dxd, drop=drop,
+                            dgamma=dg, dbeta=db)
+        sc = max(1.0, dy_ref.abs().max().item())
+        assert_close(dx, yr.grad, atol=2e-5 * sc, name="dx")
+        if drop is not None:
+            assert_close(dxd, yr.grad * keep, atol=4e-5 * sc, name="dropout(dx)")
+        assert_close(dg, gr.grad, atol=2e-5 * sc * math.sqrt(M), name="dgamma")
+        assert_close(db, br.grad, atol=2e-5 * sc * math.sqrt(M), name="dbeta")
+        dx2 = torch.empty_like(dx)
+        ops.temporal_ln_bwd(None, dy_ref, y, mean, rstd, gamma, dx2)                          # add only, no column sums
+        assert_close(dx2, yr.grad, atol=2e-5 * sc, name="dx (add only)")
 
 
 @pytest.mark.parametrize("two_stream", [False, True])
