@@ -293,11 +293,28 @@ int sais_cast_bf16_rows(const float* src, const float* rowscale, void* dst_bf16,
  * The two streams may have different padded lengths (sequence strides): at inference the flow stream
  * has 1-2 frames per 15-frame window (prepare_dataset.py:2660-2666).                              */
 int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, long clip_stride_flow, int B,
-                  int nsnippets, const float* W /*[256,384]*/, const float* bias, float* rep /*[B,384] saved*/,
-                  float* emb /*[B,256]*/, void* stream);
+                  int nsnippets, const float* W /*[256,384]*/, const float* bias,
+                  const unsigned char* use_b /*[B] or NULL*/, const float* WB, const float* biasB,
+                  float* rep /*[B,384] saved*/, float* emb /*[B,256]*/, void* stream);
+/* use_b: multi-domain models ('+' in the domain name, two-stream, prepare_model.py:405-414): clips flagged 1 (domain !=
+ * 'NH_02') go through linearB = (WB, biasB) instead of linear = (W, bias); the backward routes dz through the same head
+ * and accumulates each clip's weight / bias gradient into the head it used (dW / dbias or dWB / dbiasB).              */
 int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb, const float* z_flow,
-                  long clip_stride, long clip_stride_flow, int B, int nsnippets, float* dW, float* dbias,
-                  float* dz_rgb, float* dz_flow, void* stream);
+                  long clip_stride, long clip_stride_flow, int B, int nsnippets, const unsigned char* use_b,
+                  const float* WB, float* dW, float* dbias, float* dWB, float* dbiasB, float* dz_rgb, float* dz_flow,
+                  void* stream);
+/* MIL pathway, inference direction (fullModel.forward task 'MIL', prepare_model.py:356-361; its training raises inside the
+ * reference).  sais_mil_forward: tokens[b, s] = relu(z_rgb[(b * ns + s), CLS row]) + clip_pos[s] = the input of
+ * getClipReps' clip-level encoder (:452-460; z_rgb = frame-encoder output, seq_stride floats between sequences).  The
+ * encoder itself is the same kernel chain as the frame encoder on transEncoderClip's weights (no mask, no CLS).
+ * sais_mil_head: reps = relu(enc) (:465), then MIL_Head (:470-488): gated attention over the snippets per class
+ * (calcAttention :131-138), video representation and score (:140-148).  attention is [nclasses][B][nsnippets].        */
+int sais_mil_forward(const float* z_rgb, long seq_stride, const float* clip_pos /*[ns,384]*/, int B, int nsnippets,
+                     float* tokens /*[B*ns,384]*/, void* stream);
+int sais_mil_head(const float* enc /*[B*ns,384]*/, int B, int nsnippets, int nclasses, const float* WA, const float* bA,
+                  const float* WB, const float* bB, const float* w_att /*[3,256]*/, const float* b_att /*[3]*/,
+                  const float* w_fin /*[3,384]*/, const float* b_fin /*[3]*/, float* reps, float* logits /*[B,C]*/,
+                  float* attention, void* stream);
 /* Optional importance head (-il): importance_function = Linear(384 -> 1) on the ReLU'd encoder output sequence,
  * prepare_model.py:55-56,419-421.  out[m] = w . relu(z[m,:]) + b.  bwd ACCUMULATES into dz / dw / db.        */
 int sais_importance_fwd(const float* z /*[M,384] pre-ReLU*/, const float* w, const float* b, int M, float* out, void* stream);

@@ -153,16 +153,18 @@ def temporal_aggregate(sd, seq, pad, nlayers=4, trace=None, drop=None, p=0.1):
 
 
 def temporal_forward(sd, x, f, xpad, fpad, modalities="RGB-Flow", nlayers=4, importance=False, trace=None, drop=None,
-                     p=0.1):
+                     p=0.1, domains=None):
     """fullModel.forward, data_type='reps', encoder 'ViT', task 'Prototypes', self_attention
     — prepare_model.py:246-448.  Tensor inputs -> (emb [B,256], attn [B*ns,S,S]); list inputs
     (test-time augmentation, :331-346) -> (list of embs, attn of version 0).
-    drop = {"rgb": [per-layer masks], "flow": [...]}: train mode with these dropout keep masks (temporal_layer)."""
+    drop = {"rgb": [per-layer masks], "flow": [...]}: train mode with these dropout keep masks (temporal_layer).
+    domains (multi-domain models, a state dict WITH linearB, two-stream only — :405-414): samples whose domain is not
+    'NH_02' go through linearB instead of linear."""
     if isinstance(x, (list, tuple)):
         embs, attn0 = [], None
         for v in range(len(x)):
             e, a = temporal_forward(sd, x[v], f[v] if f is not None else None, xpad[v],
-                                    fpad[v] if fpad is not None else None, modalities, nlayers)[:2]
+                                    fpad[v] if fpad is not None else None, modalities, nlayers, domains=domains)[:2]
             embs.append(e)
             attn0 = a if v == 0 else attn0
         return embs, attn0
@@ -179,10 +181,41 @@ def temporal_forward(sd, x, f, xpad, fpad, modalities="RGB-Flow", nlayers=4, imp
         else:
             rep = rep + flow.mean(dim=1)                                               # :412
     emb = F.linear(F.relu(rep), sd["linear.weight"], sd["linear.bias"])                # :416 (double ReLU, App. B.4)
+    if "linearB.weight" in sd and modalities == "RGB-Flow" and domains is not None:      # :405-414
+        embB = F.linear(F.relu(rep), sd["linearB.weight"], sd["linearB.bias"])
+        useB = torch.tensor([d != 'NH_02' for d in domains]).view(-1, 1)
+        emb = torch.where(useB, embB, emb)
     if importance:
         imp = F.linear(full, sd["importance_function.weight"], sd["importance_function.bias"])   # :419-421
         return imp, emb, attn
     return emb, attn
+
+
+def mil_forward(sd, x, f, xpad, fpad, nclasses=2, nlayers=4):
+    """fullModel.forward, task 'MIL', modalities 'RGB-Flow', eval mode — prepare_model.py:356-361 with getClipReps
+    :452-468 and MIL_Head :470-488 / calcAttention :131-138 / obtainVideoRep :140-143 / obtainVideoScore :145-148.
+    Per-snippet relu'd CLS rows [B,ns,D] -> + clip position rows -> transEncoderClip (no mask, no CLS token) -> ReLU ->
+    per class gated attention over the snippets and a linear score.  Returns the reference's four outputs:
+    snip_sequence [ns,B,D] (the position-added encoder INPUT, permuted as :463 leaves it), snip_reps [B,ns,D],
+    logits [B,nclasses], {class: attention [B,ns]}.  (The flow stream's clip representations are computed and dropped
+    there: MIL_Head(snip_reps, flow_reps=None).)"""
+    _, rgb, _ = temporal_aggregate(sd, temporal_prepare(sd, x), xpad, nlayers)
+    B, ns, D = rgb.shape
+    pos = torch.cat([sd[f"clip_pos_embeddings.{i}"] for i in range(ns)], 0)             # [ns, D]
+    seq = rgb + pos.view(1, ns, D)
+    z = seq
+    for l in range(nlayers):
+        z, _ = temporal_layer(sd, f"transEncoderClip.layers.{l}.", z, torch.zeros(B, ns, dtype=torch.bool))
+    reps = F.relu(z)
+    a = torch.tanh(F.linear(reps, sd["attentionA.weight"], sd["attentionA.bias"]))
+    g = torch.sigmoid(F.linear(reps, sd["attentionB.weight"], sd["attentionB.bias"]))
+    logits, att = [], {}
+    for c in range(nclasses):
+        w = torch.softmax(F.linear(a * g, sd[f"attentionModules.{c}.weight"], sd[f"attentionModules.{c}.bias"]), 1)   # [B,ns,1]
+        video = (w * reps).sum(1)                                                        # bmm(attention, snip_reps)
+        logits.append(F.linear(video, sd[f"finalModules.{c}.weight"], sd[f"finalModules.{c}.bias"]))
+        att[c] = w.squeeze(-1)
+    return seq.permute(1, 0, 2), reps, torch.cat(logits, 1), att
 
 
 # --------------------------------------------------------------------------- SupCon / prototype head

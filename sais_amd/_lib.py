@@ -100,9 +100,13 @@ SIGNATURES = {
     "sais_cast_bf16_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "sais_dropout_f32": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_void_p, ctypes.c_uint, c_void_p],
     "sais_dropout_mask": [c_void_p, c_long, c_float, c_void_p, ctypes.c_uint, c_void_p],
-    "sais_head_fwd": [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
-    "sais_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p,
+    "sais_head_fwd": [c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                       c_void_p, c_void_p, c_void_p],
+    "sais_head_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_void_p, c_void_p,
+                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "sais_mil_forward": [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "sais_mil_head": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "sais_importance_fwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "sais_importance_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "sais_importance_loss": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p],

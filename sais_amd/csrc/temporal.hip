@@ -218,8 +218,11 @@ __global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const
 
 // ---------------------------------------------------------------- head
 // rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = W relu(rep) + bias
+// useB (optional, [B]): clips flagged 1 go through (WB, biasB) instead of (W, bias) — the per-sample linear / linearB
+// selection of multi-domain models (prepare_model.py:405-414)
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const float* zf, long clip_stride,
                                                        long clip_stride_f, int ns, const float* W, const float* bias,
+                                                       const unsigned char* useB, const float* WB, const float* biasB,
                                                        float* rep, float* emb) {
     __shared__ float sr[D];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -236,8 +239,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const fl
         sr[c] = fmaxf(v, 0.f);
     }
     __syncthreads();
-    float a = bias[tid];
-    const float* w = W + (size_t)tid * D;
+    const bool second = useB && useB[b];
+    float a = (second ? biasB : bias)[tid];
+    const float* w = (second ? WB : W) + (size_t)tid * D;
     for (int c = 0; c < D; c += 4) {
         f32x4 t = *(const f32x4*)(w + c);
         a += t[0] * sr[c] + t[1] * sr[c + 1] + t[2] * sr[c + 2] + t[3] * sr[c + 3];
@@ -250,10 +254,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const fl
 // 54 us -> a few us at B = 8)
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const float* W, const float* rep,
                                                        const float* zr, const float* zf, long clip_stride,
-                                                       long clip_stride_f, int B, int ns, float* dzr, float* dzf) {
+                                                       long clip_stride_f, int B, int ns, const unsigned char* useB,
+                                                       const float* WB, float* dzr, float* dzf) {
     __shared__ float sd[EMB];
     const int b = blockIdx.x, tid = threadIdx.x;
     sd[tid] = demb[(size_t)b * EMB + tid];
+    if (useB && useB[b]) W = WB;
     __syncthreads();
     for (int c = tid; c < D; c += 256) {
         const float r = rep[(size_t)b * D + c];
@@ -268,18 +274,91 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* demb, const 
     }
 }
 
-__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* demb, const float* rep, int B, float* dW,
-                                                          float* dbias) {
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* demb, const float* rep, int B,
+                                                          const unsigned char* useB, float* dW, float* dbias, float* dWB,
+                                                          float* dbiasB) {
     const int c = blockIdx.x, o = threadIdx.x;               // grid D (+1 block for the bias), 256 threads = EMB
-    if (c == D) {
-        float a = 0.f;
-        for (int b = 0; b < B; ++b) a += demb[(size_t)b * EMB + o];
-        dbias[o] += a;
-        return;
+    float a = 0.f, a2 = 0.f;                                 // a: clips of the first head, a2: clips flagged for linearB
+    for (int b = 0; b < B; ++b) {
+        const float t = demb[(size_t)b * EMB + o] * (c == D ? 1.f : fmaxf(rep[(size_t)b * D + c], 0.f));
+        if (useB && useB[b]) a2 += t; else a += t;
     }
-    float a = 0.f;
-    for (int b = 0; b < B; ++b) a += demb[(size_t)b * EMB + o] * fmaxf(rep[(size_t)b * D + c], 0.f);
-    dW[(size_t)o * D + c] += a;
+    if (c == D) {
+        dbias[o] += a;
+        if (useB) dbiasB[o] += a2;
+    } else {
+        dW[(size_t)o * D + c] += a;
+        if (useB) dWB[(size_t)o * D + c] += a2;
+    }
+}
+
+// ---------------------------------------------------------------- MIL pathway, inference (prepare_model.py:356-361)
+// getClipReps input (:452-460): tokens[b, s] = relu(z[b * ns + s, CLS row]) + clip_pos[s]   (one sequence of ns snippets per clip)
+__global__ __launch_bounds__(128) void mil_prepare_kernel(const float* z, long seq_stride, const float* clip_pos, int ns,
+                                                          float* tokens) {
+    const int r = blockIdx.x, s = r % ns;                    // r = b * ns + s
+    for (int c = threadIdx.x; c < D; c += 128)
+        tokens[(size_t)r * D + c] = fmaxf(z[(size_t)r * seq_stride + c], 0.f) + clip_pos[(size_t)s * D + c];
+}
+
+// MIL_Head (:470-488) on reps = relu(clip encoder output) [B, ns, 384], one workgroup per clip, thread e = one of the 256
+// gate units: gated[s][e] = tanh(A reps_s + a)[e] * sigmoid(Bm reps_s + bm)[e]  (calcAttention :131-138); per class c:
+// att_c = softmax_s(w_c . gated[s] + b_c), video_c = sum_s att_c[s] reps_s, logit_c = f_c . video_c + g_c (:140-148).
+// Writes reps (the relu), logits [B, C], attention [C, B, ns].  ns <= 128, C <= 3.
+__global__ __launch_bounds__(256) void mil_head_kernel(const float* enc, int ns, int C, const float* WA, const float* bA,
+                                                       const float* WB, const float* bB, const float* wAtt,
+                                                       const float* bAtt, const float* wFin, const float* bFin,
+                                                       float* reps, float* logits, float* attention, int B) {
+    __shared__ float row[D];
+    __shared__ float red[3][4];
+    __shared__ float score[3][128];
+    const int b = blockIdx.x, e = threadIdx.x, lane = e & 63, w = e >> 6;
+    for (int s = 0; s < ns; ++s) {
+        __syncthreads();
+        for (int c = e; c < D; c += 256) {
+            const float v = fmaxf(enc[((size_t)b * ns + s) * D + c], 0.f);
+            row[c] = v;
+            reps[((size_t)b * ns + s) * D + c] = v;
+        }
+        __syncthreads();
+        float a = bA[e], g = bB[e];
+        for (int c = 0; c < D; c += 4) {
+            const f32x4 ta = *(const f32x4*)(WA + (size_t)e * D + c), tb = *(const f32x4*)(WB + (size_t)e * D + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a += ta[j] * row[c + j]; g += tb[j] * row[c + j]; }
+        }
+        const float gated = tanhf(a) * (1.0f / (1.0f + __expf(-g)));
+        for (int c = 0; c < C; ++c) {
+            const float t = wave_sum(gated * wAtt[(size_t)c * EMB + e]);
+            if (lane == 0) red[c][w] = t;
+        }
+        __syncthreads();
+        if (e < C) score[e][s] = red[e][0] + red[e][1] + red[e][2] + red[e][3] + bAtt[e];
+    }
+    __syncthreads();
+    if (e < C) {                                             // softmax over the snippets
+        float m = -INFINITY, sum = 0.f;
+        for (int s = 0; s < ns; ++s) m = fmaxf(m, score[e][s]);
+        for (int s = 0; s < ns; ++s) { const float t = __expf(score[e][s] - m); score[e][s] = t; sum += t; }
+        for (int s = 0; s < ns; ++s) {
+            score[e][s] /= sum;
+            attention[((size_t)e * B + b) * ns + s] = score[e][s];
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        float part = 0.f;
+        for (int d = e; d < D; d += 256) {
+            float v = 0.f;
+            for (int s = 0; s < ns; ++s) v += score[c][s] * fmaxf(enc[((size_t)b * ns + s) * D + d], 0.f);
+            part += v * wFin[(size_t)c * D + d];
+        }
+        part = wave_sum(part);
+        __syncthreads();
+        if (lane == 0) red[0][w] = part;
+        __syncthreads();
+        if (e == 0) logits[(size_t)b * C + c] = red[0][0] + red[0][1] + red[0][2] + red[0][3] + bFin[c];
+    }
 }
 
 // ---------------------------------------------------------------- importance head (-il): Linear(384 -> 1) on relu(z)
@@ -490,23 +569,49 @@ extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key
 }
 
 extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_stride, long clip_stride_flow, int B,
-                             int nsnippets, const float* W, const float* bias, float* rep, float* emb, void* stream) {
+                             int nsnippets, const float* W, const float* bias, const unsigned char* use_b, const float* WB,
+                             const float* biasB, float* rep, float* emb, void* stream) {
     SAIS_ENTER();
     if ((!z_rgb && !z_flow) || !W || !bias || !rep || !emb || B <= 0 || nsnippets <= 0) return SAIS_ERR_ARG;
+    if (use_b && (!WB || !biasB)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride,
-                       clip_stride_flow, nsnippets, W, bias, rep, emb);
+                       clip_stride_flow, nsnippets, W, bias, use_b, WB, biasB, rep, emb);
+    return sais_check_launch();
+}
+
+extern "C" int sais_mil_forward(const float* z_rgb, long seq_stride, const float* clip_pos, int B, int nsnippets, float* tokens,
+                                void* stream) {
+    SAIS_ENTER();
+    if (!z_rgb || !clip_pos || !tokens || B <= 0 || nsnippets <= 0) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(mil_prepare_kernel, dim3(B * nsnippets), dim3(128), 0, (hipStream_t)stream, z_rgb, seq_stride,
+                       clip_pos, nsnippets, tokens);
+    return sais_check_launch();
+}
+
+extern "C" int sais_mil_head(const float* enc, int B, int nsnippets, int nclasses, const float* WA, const float* bA,
+                             const float* WB, const float* bB, const float* w_att, const float* b_att, const float* w_fin,
+                             const float* b_fin, float* reps, float* logits, float* attention, void* stream) {
+    SAIS_ENTER();
+    if (!enc || !WA || !bA || !WB || !bB || !w_att || !b_att || !w_fin || !b_fin || !reps || !logits || !attention)
+        return SAIS_ERR_ARG;
+    if (B <= 0 || nsnippets <= 0 || nsnippets > 128 || nclasses <= 0 || nclasses > 3) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(mil_head_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, enc, nsnippets, nclasses, WA, bA, WB, bB,
+                       w_att, b_att, w_fin, b_fin, reps, logits, attention, B);
     return sais_check_launch();
 }
 
 extern "C" int sais_head_bwd(const float* demb, const float* W, const float* rep, const float* z_rgb,
                              const float* z_flow, long clip_stride, long clip_stride_flow, int B, int nsnippets,
-                             float* dW, float* dbias, float* dz_rgb, float* dz_flow, void* stream) {
+                             const unsigned char* use_b, const float* WB, float* dW, float* dbias, float* dWB, float* dbiasB,
+                             float* dz_rgb, float* dz_flow, void* stream) {
     SAIS_ENTER();
     if (!demb || !W || !rep || !dW || !dbias || B <= 0 || nsnippets <= 0) return SAIS_ERR_ARG;
     if ((z_rgb && !dz_rgb) || (z_flow && !dz_flow)) return SAIS_ERR_ARG;
+    if (use_b && (!WB || !dWB || !dbiasB)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, demb, W, rep, z_rgb, z_flow,
-                       clip_stride, clip_stride_flow, B, nsnippets, dz_rgb, dz_flow);
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(D + 1), dim3(EMB), 0, (hipStream_t)stream, demb, rep, B, dW, dbias);
+                       clip_stride, clip_stride_flow, B, nsnippets, use_b, WB, dz_rgb, dz_flow);
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3(D + 1), dim3(EMB), 0, (hipStream_t)stream, demb, rep, B, use_b, dW, dbias,
+                       dWB, dbiasB);
     return sais_check_launch();
 }
 

@@ -363,16 +363,30 @@ def dropout_mask(n, p, rng, site, device):
     return m
 
 
-def head_fwd(z_rgb, z_flow, clip_stride, B, W, bias, rep, emb, clip_stride_flow=None, nsnippets=1):
+def head_fwd(z_rgb, z_flow, clip_stride, B, W, bias, rep, emb, clip_stride_flow=None, nsnippets=1, second=None):
+    """second = (use_b u8 [B], WB, biasB): clips flagged 1 go through linearB (multi-domain models)."""
     csf = clip_stride if clip_stride_flow is None else clip_stride_flow
-    L.call("sais_head_fwd", _p(z_rgb), _p(z_flow), clip_stride, csf, B, nsnippets, _p(W), _p(bias), _p(rep), _p(emb),
-           _stream())
+    ub, WB, bB = second if second is not None else (None, None, None)
+    L.call("sais_head_fwd", _p(z_rgb), _p(z_flow), clip_stride, csf, B, nsnippets, _p(W), _p(bias), _p(ub), _p(WB), _p(bB),
+           _p(rep), _p(emb), _stream())
 
 
-def head_bwd(demb, W, rep, z_rgb, z_flow, clip_stride, B, dW, dbias, dz_rgb, dz_flow, clip_stride_flow=None, nsnippets=1):
+def head_bwd(demb, W, rep, z_rgb, z_flow, clip_stride, B, dW, dbias, dz_rgb, dz_flow, clip_stride_flow=None, nsnippets=1,
+             second=None):
+    """second = (use_b u8 [B], WB, dWB, dbiasB)."""
     csf = clip_stride if clip_stride_flow is None else clip_stride_flow
-    L.call("sais_head_bwd", _p(demb), _p(W), _p(rep), _p(z_rgb), _p(z_flow), clip_stride, csf, B, nsnippets, _p(dW),
-           _p(dbias), _p(dz_rgb), _p(dz_flow), _stream())
+    ub, WB, dWB, dbB = second if second is not None else (None, None, None, None)
+    L.call("sais_head_bwd", _p(demb), _p(W), _p(rep), _p(z_rgb), _p(z_flow), clip_stride, csf, B, nsnippets, _p(ub), _p(WB),
+           _p(dW), _p(dbias), _p(dWB), _p(dbB), _p(dz_rgb), _p(dz_flow), _stream())
+
+
+def mil_forward(z_rgb, seq_stride, clip_pos, B, nsnippets, tokens):
+    L.call("sais_mil_forward", _p(z_rgb), seq_stride, _p(clip_pos), B, nsnippets, _p(tokens), _stream())
+
+
+def mil_head(enc, B, nsnippets, nclasses, WA, bA, WB, bB, w_att, b_att, w_fin, b_fin, reps, logits, attention):
+    L.call("sais_mil_head", _p(enc), B, nsnippets, nclasses, _p(WA), _p(bA), _p(WB), _p(bB), _p(w_att), _p(b_att),
+           _p(w_fin), _p(b_fin), _p(reps), _p(logits), _p(attention), _stream())
 
 
 def importance_fwd(z, w, b, M, out):

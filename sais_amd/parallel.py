@@ -41,7 +41,8 @@ class GradSync:
         (the reference's disabled DDP needed find_unused_parameters=True for them, prepare_model.py:549)."""
         f = model.flat
         first_clip = "transEncoderClip.layers.0.self_attn.in_proj_weight"
-        r = [(f.offsets["linear.weight"], f.offsets["linear.bias"] + 256),
+        head_end = (f.offsets["linearB.bias"] if "linearB.bias" in f.offsets else f.offsets["linear.bias"]) + 256
+        r = [(f.offsets["linear.weight"], head_end),                                  # linear (+ linearB, multi-domain)
              (f.offsets["frame_cls"], f.offsets["frame_cls"] + 384),
              (f.offsets["frame_pos_embeddings.0"], f.offsets["frame_pos_embeddings.0"] + T * 384),
              (f.offsets["transEncoderFrame.layers.0.self_attn.in_proj_weight"], f.offsets[first_clip])]

@@ -17,7 +17,8 @@ The MFMA GEMMs here are the fp32-operand "bf16x3" variant (sais_gemm_nt_f32).
 Deliberate differences: inputs are never mutated (the reference does `x += pos` in place,
 :192, and `rgb += flow`, :412); dropout (p=0.1, the nn.TransformerEncoderLayer default, train() only) is applied at its four sites per layer with
 Philox masks of this library's own stream (`dropout_p`, `dropout_seed`; `dropout_p = 0` switches it off);
-MIL / ClassificationHead / R3D / raw branches are out of scope and raise.  Inputs [B, nsnippets, T, 384]: every
+ClassificationHead / R3D / raw branches are out of scope and raise; task 'MIL' runs in the inference direction (its
+training raises inside the reference), multi-domain models ('+' in the domain) select linear / linearB per sample.  Inputs [B, nsnippets, T, 384]: every
 (clip, snippet) pair is one sequence of the encoder, the head averages the ReLU'd CLS rows over the snippets of a clip
 (:381-382) and the returned attention map is [B*nsnippets, T+1, T+1], as in the reference.
 """
@@ -41,8 +42,8 @@ def _make_encoder(rep_dim):
 
 class _TemporalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, x, f, xpad, fpad, anchor):
-        emb, attn, imp, saved = model._forward_kernels(x, f, xpad, fpad, save=True)
+    def forward(ctx, model, x, f, xpad, fpad, anchor, second=None):
+        emb, attn, imp, saved = model._forward_kernels(x, f, xpad, fpad, save=True, second=second)
         ctx.model, ctx.saved = model, saved
         ctx.needs = (x is not None and x.requires_grad, f is not None and f.requires_grad)
         ctx.mark_non_differentiable(attn)
@@ -56,7 +57,7 @@ class _TemporalFn(torch.autograd.Function):
         dimp = dimp.contiguous() if ctx.model.importance_loss and dimp is not None else None
         dx, df = ctx.model._backward_kernels(ctx.saved, demb.contiguous(), ctx.needs, dimp)
         ctx.saved = None
-        return None, dx, df, None, None, None
+        return None, dx, df, None, None, None, None
 
 
 class fullModel(nn.Module):
@@ -115,8 +116,8 @@ class fullModel(nn.Module):
     def nlayers(self):
         return len(self.transEncoderFrame.layers)
 
-    def _lnames(self, l):
-        return f"transEncoderFrame.layers.{l}."
+    def _lnames(self, l, enc="transEncoderFrame"):
+        return f"{enc}.layers.{l}."
 
     def _t_names(self):
         out = []
@@ -125,6 +126,45 @@ class fullModel(nn.Module):
             out += [p + "self_attn.in_proj_weight", p + "self_attn.out_proj.weight", p + "linear1.weight",
                     p + "linear2.weight"]
         return out
+
+    def _mil_forward(self, x, f, xpad, fpad):
+        """task 'MIL' (prepare_model.py:356-361), inference: per-snippet frame encoder -> relu'd CLS rows + clip position
+        rows -> transEncoderClip over the snippets (no mask, no CLS) -> ReLU -> gated-attention MIL head.  Returns the
+        reference's (snip_sequence [ns,B,384], snip_reps [B,ns,384], output_logits [B,nclasses], {class: attention [B,ns]}).
+        The reference computes the flow stream's clip representations too and drops them (MIL_Head(snip_reps, None)), and it
+        indexes the flow tensor unconditionally, so the path exists for modalities 'RGB-Flow' only; training it raises in
+        the reference (an in-place add on a ReLU output), so this is an eval() / no-grad path."""
+        if self.modalities != 'RGB-Flow':
+            raise NotImplementedError("task 'MIL' indexes both streams in the reference (prepare_model.py:358-359): "
+                                      "modalities must be 'RGB-Flow'")
+        if self.training:
+            raise NotImplementedError("task 'MIL' is an inference path: its backward raises inside the reference "
+                                      "(getClipReps adds the position rows in place into a ReLU output, :459)")
+        if isinstance(x, (list, tuple)):
+            raise NotImplementedError("task 'MIL' takes tensor inputs (the reference's list branch never reaches it)")
+        x = self._check(x, "x")
+        dev = x.device
+        xpad = self._mask(xpad, x, dev)
+        fl = self._engine(dev)
+        B, ns = x.shape[0], x.shape[1]
+        S = x.shape[2] + 1
+        with torch.no_grad():
+            zr, _, _ = self._stream_fwd(x, xpad, save=False, want_attn=False)
+            tokens = torch.empty(B * ns, D, dtype=torch.float32, device=dev)
+            o = fl.offsets["clip_pos_embeddings.0"]
+            assert fl.offsets[f"clip_pos_embeddings.{ns - 1}"] == o + (ns - 1) * D
+            ops.mil_forward(zr, S * D, fl.flat[o:o + ns * D], B, ns, tokens)
+            nopad = torch.zeros(B, ns, dtype=torch.uint8, device=dev)
+            enc, _, _ = self._encoder_fwd(tokens, nopad, B, ns, "transEncoderClip", save=False, want_attn=False)
+            reps = torch.empty(B, ns, D, dtype=torch.float32, device=dev)
+            logits = torch.empty(B, self.nclasses, dtype=torch.float32, device=dev)
+            att = torch.empty(self.nclasses, B, ns, dtype=torch.float32, device=dev)
+            cat = lambda fmt: torch.cat([fl.w32(fmt % c).reshape(1, -1) for c in range(3)], 0).contiguous()
+            ops.mil_head(enc, B, ns, self.nclasses, fl.w32("attentionA.weight"), fl.w32("attentionA.bias"),
+                         fl.w32("attentionB.weight"), fl.w32("attentionB.bias"), cat("attentionModules.%d.weight"),
+                         cat("attentionModules.%d.bias").reshape(-1), cat("finalModules.%d.weight"),
+                         cat("finalModules.%d.bias").reshape(-1), reps, logits, att)
+        return tokens.view(B, ns, D).permute(1, 0, 2), reps, logits, {c: att[c] for c in range(self.nclasses)}
 
     def _sentinels(self):
         return ["linear.weight", "frame_cls", "frame_pos_embeddings.0", self._lnames(0) + "self_attn.in_proj_weight",
@@ -163,27 +203,34 @@ class fullModel(nn.Module):
 
     # ------------------------------------------------------------------ reference signature
     def forward(self, x, f, xlens, flens, task, xpad, fpad, domains=None):
+        if task == 'MIL':
+            return self._mil_forward(x, f, xpad, fpad)
         if task != 'Prototypes':
-            raise NotImplementedError(f"task {task!r}: only 'Prototypes' is on the MI355X hot path")
-        if '+' in self.domain:
-            # the reference sends samples whose domain is not 'NH_02' through linearB (prepare_model.py:405-414);
-            # linearB is registered (state_dict contract) but the per-sample head selection is not built
-            raise NotImplementedError("multi-domain training ('+' in the domain name: per-sample linear / linearB "
-                                      "selection, prepare_model.py:405-414) is not on the MI355X hot path")
+            raise NotImplementedError(f"task {task!r}: 'Prototypes' (training and inference) and 'MIL' (inference) are on "
+                                      "the MI355X path")
+        # multi-domain models ('+' in the domain name): in the two-stream branch the reference sends samples whose domain is
+        # not 'NH_02' through linearB (prepare_model.py:405-414); the single-stream branches use linear for everyone
+        second = None
+        if '+' in self.domain and self.modalities == 'RGB-Flow':
+            if domains is None:
+                raise ValueError("a multi-domain model needs the per-sample `domains` (prepare_model.py:405-414)")
+            ref = x if x is not None else f
+            dev = (ref[0] if isinstance(ref, (list, tuple)) else ref).device
+            second = torch.tensor([0 if d == 'NH_02' else 1 for d in domains], dtype=torch.uint8, device=dev)
         if isinstance(x, (list, tuple)) or isinstance(f, (list, tuple)):          # TTA versions, :331-346
             n = len(x) if x is not None else len(f)
             embs, attn0, imp0 = [], None, None
             for v in range(n):
                 e, a, im = self._forward_one(None if x is None else x[v], None if f is None else f[v],
-                                             None if xpad is None else xpad[v], None if fpad is None else fpad[v])
+                                             None if xpad is None else xpad[v], None if fpad is None else fpad[v], second)
                 embs.append(e)
                 if v == 0:
                     attn0, imp0 = a, im
             return (imp0, embs, attn0) if self.importance_loss else (embs, attn0)
-        emb, attn, imp = self._forward_one(x, f, xpad, fpad)
+        emb, attn, imp = self._forward_one(x, f, xpad, fpad, second)
         return (imp, emb, attn) if self.importance_loss else (emb, attn)          # :444-448
 
-    def _forward_one(self, x, f, xpad, fpad):
+    def _forward_one(self, x, f, xpad, fpad, second=None):
         use_x = self.modalities in ('RGB', 'RGB-Flow')
         use_f = self.modalities in ('Flow', 'RGB-Flow')
         x = self._check(x, "x") if use_x else None
@@ -193,9 +240,9 @@ class fullModel(nn.Module):
         fpad = self._mask(fpad, f, dev) if use_f else None
         self._engine(dev)
         if torch.is_grad_enabled() and self.linear.weight.requires_grad:
-            emb, attn, imp = _TemporalFn.apply(self, x, f, xpad, fpad, self._anchor)
+            emb, attn, imp = _TemporalFn.apply(self, x, f, xpad, fpad, self._anchor, second)
             return emb, attn, (imp if self.importance_loss else None)
-        emb, attn, imp, _ = self._forward_kernels(x, f, xpad, fpad, save=False)
+        emb, attn, imp, _ = self._forward_kernels(x, f, xpad, fpad, save=False, second=second)
         return emb, attn, imp
 
     @staticmethod
@@ -246,15 +293,24 @@ class fullModel(nn.Module):
         S, M = T + 1, B * (T + 1)
         if T > NPOS:
             raise ValueError("at most 2000 frames (position table, prepare_model.py:67)")
-        e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        z = e32(M, D)
+        z = torch.empty(M, D, dtype=torch.float32, device=dev)
         o = fl.offsets["frame_pos_embeddings.0"]
         assert fl.offsets[f"frame_pos_embeddings.{T - 1}"] == o + (T - 1) * D      # rows contiguous in the flat buffer
         ops.temporal_prepare_fwd(x, x.stride(0), x.stride(2), fl.flat[o:o + T * D], fl.w32("frame_cls"), B, T, z, None)
+        z, attn, layers = self._encoder_fwd(z, pad, B, S, "transEncoderFrame", save, want_attn, drop, sidx)
+        return z, attn, dict(layers=layers, pad=pad, B=B, T=T, x=x, drop=drop, sidx=sidx) if save else None
+
+    def _encoder_fwd(self, z, pad, B, S, enc, save, want_attn, drop=None, sidx=0):
+        """The four post-norm layers of `enc` (transEncoderFrame | transEncoderClip) over B sequences of S tokens,
+        z f32 [B*S, 384]; pad u8 [B, S] (1 = masked key).  Returns (output, last layer's head-averaged attention, saved)."""
+        fl = self.flat
+        dev = z.device
+        M = B * S
+        e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         layers = []
         attn = None
         for l in range(self.nlayers):
-            p = self._lnames(l)
+            p = self._lnames(l, enc)
             last = l == self.nlayers - 1
             qkv, ctx = e32(M, 3 * D), e32(M, D)
             ops.tgemm(z, fl.w32(p + "self_attn.in_proj_weight"), L.TG_BIAS, qkv, bias=fl.w32(p + "self_attn.in_proj_bias"))
@@ -282,9 +338,9 @@ class fullModel(nn.Module):
             if save:
                 layers.append(dict(z=z, qkv=qkv, ctx=ctx, y1=y1, m1=m1, r1=r1, z1=z1, h=h, y2=y2, m2=m2, r2=r2))
             z = zo
-        return z, attn, dict(layers=layers, pad=pad, B=B, T=T, x=x, drop=drop, sidx=sidx) if save else None
+        return z, attn, layers
 
-    def _forward_kernels(self, x, f, xpad, fpad, save):
+    def _forward_kernels(self, x, f, xpad, fpad, save, second=None):
         fl = self.flat
         zr = zf = sr = sf = attn = None
         drop = None
@@ -311,12 +367,13 @@ class fullModel(nn.Module):
         rep = torch.empty(B, D, dtype=torch.float32, device=ref.device)
         emb = torch.empty(B, EMB, dtype=torch.float32, device=ref.device)
         ops.head_fwd(zr, zf, (Sx if zr is not None else Sf) * D, B, fl.w32("linear.weight"), fl.w32("linear.bias"), rep, emb,
-                     clip_stride_flow=Sf * D, nsnippets=ns)
+                     clip_stride_flow=Sf * D, nsnippets=ns,
+                     second=None if second is None else (second, fl.w32("linearB.weight"), fl.w32("linearB.bias")))
         imp = None
         if self.importance_loss:                              # importance_function(full RGB sequence), :419-421
             imp = torch.empty(B, ns, Sx, 1, dtype=torch.float32, device=ref.device)
             ops.importance_fwd(zr, fl.w32("importance_function.weight"), fl.w32("importance_function.bias"), B * ns * Sx, imp)
-        saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, ns=ns, Sx=Sx, Sf=Sf,
+        saved = dict(sr=sr, sf=sf, zr=zr, zf=zf, rep=rep, B=B, ns=ns, Sx=Sx, Sf=Sf, second=second,
                      xshape=None if x is None else x.shape, fshape=None if f is None else f.shape) if save else None
         return emb, attn, imp, saved
 
@@ -377,8 +434,11 @@ class fullModel(nn.Module):
         zr, zf = saved["zr"], saved["zf"]
         dzr = torch.zeros_like(zr) if zr is not None else None
         dzf = torch.zeros_like(zf) if zf is not None else None
+        sec = saved.get("second")
         ops.head_bwd(demb, fl.w32("linear.weight"), saved["rep"], zr, zf, (Sx if zr is not None else Sf) * D, B,
-                     fl.g("linear.weight"), fl.g("linear.bias"), dzr, dzf, clip_stride_flow=Sf * D, nsnippets=ns)
+                     fl.g("linear.weight"), fl.g("linear.bias"), dzr, dzf, clip_stride_flow=Sf * D, nsnippets=ns,
+                     second=None if sec is None else (sec, fl.w32("linearB.weight"), fl.g("linearB.weight"),
+                                                      fl.g("linearB.bias")))
         if dimp is not None:
             ops.importance_bwd(dimp, zr, fl.w32("importance_function.weight"), B * ns * Sx, dzr,
                                fl.g("importance_function.weight"), fl.g("importance_function.bias"))

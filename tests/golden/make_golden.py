@@ -449,6 +449,65 @@ def golden_snippets(prepare_model, misc, out):
     print("snippets.npz keys", len(g), "attn", attn.shape)
 
 
+def multidomain_inputs():
+    """Two-domain batch for the per-sample linear / linearB head (prepare_model.py:405-414): shared with tests/."""
+    B, T = 4, 7
+    lens = [7, 5, 7, 3]
+    x, f = synth.reps(seed=610, B=B, T=T), synth.reps(seed=611, B=B, T=T)
+    for b in range(B):
+        x[b, :, lens[b]:] = 0
+        f[b, :, lens[b]:] = 0
+    return x, f, synth.padding_mask(lens), synth.labels(seed=612, B=B), ['NH_02', 'HMH_01', 'HMH_01', 'NH_02'], lens
+
+
+def golden_multidomain(prepare_model, misc, out):
+    """fullModel(domain = 'NH_02+HMH_01', modalities = 'RGB-Flow'): samples whose domain is not 'NH_02' go through linearB."""
+    g = {}
+    x, f, pad, lab, domains, lens = multidomain_inputs()
+    m = prepare_model.fullModel('reps', 2, 'NH_02+HMH_01', 384, 'ViT', modalities='RGB-Flow', freeze_encoder_params=True,
+                                self_attention=True, importance_loss=False)
+    m.load_state_dict(synth.temporal_state_dict(seed=1, multidomain=True), strict=True)
+    m.eval()
+    protos = nn.ParameterDict({k: nn.Parameter(v.clone()) for k, v in synth.prototypes(seed=2, nclasses=2).items()})
+    x_in, f_in = x.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    emb, attn = m(x_in * 1.0, f_in * 1.0, lens, lens, 'Prototypes', pad.clone(), pad.clone(), domains)
+    loss = misc.calcNCELoss(0, emb, lab, list("abcd"), protos, domains)
+    loss.backward()
+    g["emb"], g["attn"], g["loss"] = emb.detach().numpy(), attn.detach().numpy(), np.float32(loss.item())
+    g["grad_x"], g["grad_f"] = x_in.grad.numpy(), f_in.grad.numpy()
+    P = dict(m.named_parameters())
+    for n in ("linear.weight", "linear.bias", "linearB.weight", "linearB.bias", "frame_cls",
+              "transEncoderFrame.layers.3.norm2.bias"):
+        g["grad/" + n] = P[n].grad.numpy()
+    # TTA list form (:405-407): three versions, same per-sample selection
+    xs = [x[:, :, :7], x[:, :, :5], x[:, :, :3]]
+    fs = [f[:, :, :7], f[:, :, :5], f[:, :, :3]]
+    pads = [synth.padding_mask([min(l, n) for l in lens])[:, :, :n + 1] for n in (7, 5, 3)]
+    vlens = [[min(l, n) for l in lens] for n in (7, 5, 3)]
+    with torch.no_grad():
+        embs, attn0 = m([t.clone() for t in xs], [t.clone() for t in fs], vlens, vlens, 'Prototypes',
+                        [p_.clone() for p_ in pads], [p_.clone() for p_ in pads], domains)
+    for v in range(3):
+        g[f"tta/emb{v}"] = embs[v].numpy()
+    np.savez_compressed(os.path.join(out, "multidomain.npz"), **g)
+    print("multidomain.npz keys", len(g))
+
+
+def golden_mil(prepare_model, misc, out):
+    """task = 'MIL' in eval mode (prepare_model.py:356-361,452-488,131-148): clip-level encoder over the snippet
+    representations, gated-attention MIL head.  (Training this path raises inside the reference: DESIGN.md §7.)"""
+    g = {}
+    x, f, pad, lab = snippet_inputs()
+    m = build_full(prepare_model, 2, "RGB-Flow")
+    with torch.no_grad():
+        seq, reps, logits, att = m(x.clone(), f.clone(), None, None, 'MIL', pad.clone(), pad.clone(), None)
+    g["snip_sequence"], g["snip_reps"], g["logits"] = seq.numpy(), reps.numpy(), logits.numpy()
+    for c, a in att.items():
+        g[f"attention{c}"] = a.numpy()
+    np.savez_compressed(os.path.join(out, "mil.npz"), **g)
+    print("mil.npz keys", len(g), "seq", tuple(seq.shape), "reps", tuple(reps.shape), "logits", tuple(logits.shape))
+
+
 def golden_outlier(vits, prepare_model, misc, out):
     """DINO-like dynamic range (synth.vit_state_dict_outlier): ViT features, last-block residual statistics, embeddings,
     attention map and cosine logits of a 2-clip x 8-frame batch, from the reference's own modules."""
@@ -604,7 +663,9 @@ def main():
     vits, prepare_model, misc = import_reference()
     if len(sys.argv) > 2 and sys.argv[1] == "--only":
         {"dropout": lambda: golden_dropout(prepare_model, misc, HERE),
-         "droppath": lambda: golden_droppath(vits, HERE)}[sys.argv[2]]()
+         "droppath": lambda: golden_droppath(vits, HERE),
+         "multidomain": lambda: golden_multidomain(prepare_model, misc, HERE),
+         "mil": lambda: golden_mil(prepare_model, misc, HERE)}[sys.argv[2]]()
         return
     golden_dropout(prepare_model, misc, HERE)
     golden_droppath(vits, HERE)
@@ -615,6 +676,8 @@ def main():
     golden_importance(prepare_model, misc, HERE)
     golden_outlier(vits, prepare_model, misc, HERE)
     golden_snippets(prepare_model, misc, HERE)
+    golden_multidomain(prepare_model, misc, HERE)
+    golden_mil(prepare_model, misc, HERE)
 
 
 if __name__ == "__main__":

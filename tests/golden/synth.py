@@ -117,12 +117,16 @@ def temporal_keys(importance=False, nlayers=T_LAYERS):
     return out
 
 
-def temporal_state_dict(seed=1, importance=False, nlayers=T_LAYERS, w_std=0.05):
+def temporal_state_dict(seed=1, importance=False, nlayers=T_LAYERS, w_std=0.05, multidomain=False):
     """Each of the 4 layers gets independent weights (nn.TransformerEncoder clones one layer,
-    which would hide layer-indexing bugs: SURVEY §8c)."""
+    which would hide layer-indexing bugs: SURVEY §8c).  multidomain: plus linearB ('+' in the domain name,
+    prepare_model.py:47-48), drawn AFTER everything else so the other tensors are those of the single-domain dict."""
     g = _gen(seed)
     sd = {}
-    for name, shape, kind in temporal_keys(importance, nlayers):
+    keys = temporal_keys(importance, nlayers)
+    if multidomain:
+        keys = keys + [("linearB.weight", (EMB, T_DIM), "w"), ("linearB.bias", (EMB,), "b")]
+    for name, shape, kind in keys:
         if kind == "w":
             t = torch.randn(shape, generator=g) * w_std
         elif kind == "u":

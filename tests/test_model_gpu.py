@@ -425,3 +425,60 @@ def test_multiple_snippets_per_clip_vs_golden(gpu, golden, modal):
     for k in g.files:
         if k.startswith(key + "grad/"):
             assert rel_l2(P[k[len(key + "grad/"):]].grad, g[k]) <= GRAD_REL, k
+
+
+def test_multidomain_head_selects_linear_or_linearb_per_sample(gpu, golden):
+    """fullModel(domain 'NH_02+HMH_01', 'RGB-Flow') (prepare_model.py:405-414): samples whose domain is not 'NH_02' go
+    through linearB — embeddings, loss and both heads' gradients vs the reference's own two-domain run; TTA list form too."""
+    import make_golden as MG
+    from sais_amd.loss import calcNCELoss
+    from sais_amd.temporal import fullModel
+    g = golden("multidomain")
+    x, f, pad, lab, domains, lens = MG.multidomain_inputs()
+    m = fullModel('reps', 2, 'NH_02+HMH_01', 384, 'ViT', modalities='RGB-Flow')
+    m.load_state_dict(synth.temporal_state_dict(seed=1, multidomain=True), strict=True)
+    m.dropout_p = 0.0
+    m = m.to(DEV).train()
+    protos = protos_dev(2)
+    xd, fd = x.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+    emb, attn = m(xd, fd, lens, lens, 'Prototypes', pad.to(DEV), pad.to(DEV), domains)
+    loss = calcNCELoss(0, emb, lab, list("abcd"), protos, domains)
+    loss.backward()
+    assert maxabs(emb, g["emb"]) <= 2e-3 * max(1.0, np.abs(g["emb"]).max())
+    assert maxabs(attn, g["attn"]) <= ATTN_TOL and abs(loss.item() - float(g["loss"])) <= LOGIT_TOL
+    assert rel_l2(xd.grad, g["grad_x"]) <= GRAD_REL and rel_l2(fd.grad, g["grad_f"]) <= GRAD_REL
+    P = dict(m.named_parameters())
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert rel_l2(P[k[5:]].grad, g[k]) <= GRAD_REL, (k, rel_l2(P[k[5:]].grad, g[k]))
+    xs, fs = [x[:, :, :7], x[:, :, :5], x[:, :, :3]], [f[:, :, :7], f[:, :, :5], f[:, :, :3]]
+    pads = [synth.padding_mask([min(l, n) for l in lens])[:, :, :n + 1].to(DEV) for n in (7, 5, 3)]
+    with torch.no_grad():
+        embs, _ = m.eval()([t.contiguous().to(DEV) for t in xs], [t.contiguous().to(DEV) for t in fs], None, None,
+                           'Prototypes', pads, pads, domains)
+    for v in range(3):
+        assert maxabs(embs[v], g[f"tta/emb{v}"]) <= 2e-3 * max(1.0, np.abs(g[f"tta/emb{v}"]).max())
+    with pytest.raises(ValueError):
+        m(xd, fd, lens, lens, 'Prototypes', pad.to(DEV), pad.to(DEV), None)        # a multi-domain model needs `domains`
+
+
+def test_mil_forward_vs_golden(gpu, golden):
+    """task 'MIL', inference (prepare_model.py:356-361,452-488,131-148): clip-level encoder over the snippet representations
+    and the gated-attention MIL head against the reference's own outputs."""
+    import make_golden as MG
+    from sais_amd import _lib as L
+    g = golden("mil")
+    x, f, pad, _ = MG.snippet_inputs()
+    m = make_full(2, "RGB-Flow")
+    seq, reps, logits, att = m(x.to(DEV), f.to(DEV), None, None, 'MIL', pad.to(DEV), pad.to(DEV), None)
+    assert tuple(seq.shape) == (3, 2, 384) and tuple(reps.shape) == (2, 3, 384) and tuple(logits.shape) == (2, 2)
+    assert maxabs(seq, g["snip_sequence"]) <= 1e-3
+    assert maxabs(reps, g["snip_reps"]) <= 2e-3 * max(1.0, np.abs(g["snip_reps"]).max())
+    assert maxabs(logits, g["logits"]) <= LOGIT_TOL, maxabs(logits, g["logits"])
+    for c in range(2):
+        assert maxabs(att[c], g[f"attention{c}"]) <= 1e-3
+    with pytest.raises(NotImplementedError):
+        m.train()(x.to(DEV), f.to(DEV), None, None, 'MIL', pad.to(DEV), pad.to(DEV), None)
+    with pytest.raises(NotImplementedError):
+        make_full(2, "RGB")(x.to(DEV), None, None, None, 'MIL', pad.to(DEV), None, None)
+    assert L is not None

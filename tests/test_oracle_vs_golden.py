@@ -250,3 +250,47 @@ def test_multiple_snippets_per_clip(golden):
         for k in g.files:
             if k.startswith(key + "grad/"):
                 close(sd[k[len(key + "grad/"):]].grad, g[k], 2e-4)
+
+
+def test_oracle_multidomain_head_vs_reference(golden):
+    """Per-sample linear / linearB selection (prepare_model.py:405-414) against the reference's own two-domain run."""
+    import make_golden as MG
+    g = golden("multidomain")
+    x, f, pad, lab, domains, lens = MG.multidomain_inputs()
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1, multidomain=True).items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(2, 2).items()}
+    xr, fr = x.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    emb, attn = O.temporal_forward(sd, xr, fr, pad, pad, "RGB-Flow", domains=domains)
+    loss = O.nce_loss(emb, lab, pr)
+    loss.backward()
+    assert np.abs(emb.detach().numpy() - g["emb"]).max() <= 5e-5 and abs(loss.item() - float(g["loss"])) <= 5e-6
+    assert np.abs(attn.detach().numpy() - g["attn"]).max() <= 5e-6
+    for n in ("linear.weight", "linear.bias", "linearB.weight", "linearB.bias", "frame_cls"):
+        ref = g["grad/" + n]
+        assert np.linalg.norm(sd[n].grad.numpy() - ref) <= 2e-4 * max(np.linalg.norm(ref), 1e-12), n
+    assert np.linalg.norm(xr.grad.numpy() - g["grad_x"]) <= 2e-4 * np.linalg.norm(g["grad_x"])
+    assert np.linalg.norm(fr.grad.numpy() - g["grad_f"]) <= 2e-4 * np.linalg.norm(g["grad_f"])
+    # rows of the other domain contribute nothing to a head's gradient
+    assert float(np.abs(g["grad/linearB.weight"]).max()) > 0 and float(np.abs(g["grad/linear.weight"]).max()) > 0
+    xs, fs = [x[:, :, :7], x[:, :, :5], x[:, :, :3]], [f[:, :, :7], f[:, :, :5], f[:, :, :3]]
+    pads = [synth.padding_mask([min(l, n) for l in lens])[:, :, :n + 1] for n in (7, 5, 3)]
+    with torch.no_grad():
+        embs, _ = O.temporal_forward(sd, xs, fs, pads, pads, "RGB-Flow", domains=domains)
+    for v in range(3):
+        assert np.abs(embs[v].numpy() - g[f"tta/emb{v}"]).max() <= 5e-5
+
+
+def test_oracle_mil_forward_vs_reference(golden):
+    """task 'MIL' in eval mode (prepare_model.py:356-361,452-488,131-148) against the reference's own outputs."""
+    import make_golden as MG
+    g = golden("mil")
+    x, f, pad, _ = MG.snippet_inputs()
+    sd = synth.temporal_state_dict(seed=1)
+    with torch.no_grad():
+        seq, reps, logits, att = O.mil_forward(sd, x, f, pad, pad, nclasses=2)
+    assert tuple(seq.shape) == (3, 2, 384) and tuple(reps.shape) == (2, 3, 384)
+    assert np.abs(seq.numpy() - g["snip_sequence"]).max() <= 5e-5
+    assert np.abs(reps.numpy() - g["snip_reps"]).max() <= 5e-5
+    assert np.abs(logits.numpy() - g["logits"]).max() <= 5e-5
+    for c in range(2):
+        assert np.abs(att[c].numpy() - g[f"attention{c}"]).max() <= 5e-6
