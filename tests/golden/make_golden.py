@@ -453,7 +453,9 @@ def multidomain_inputs():
     """Two-domain batch for the per-sample linear / linearB head (prepare_model.py:405-414): shared with tests/."""
     B, T = 4, 7
     lens = [7, 5, 7, 3]
-    x, f = synth.reps(seed=610, B=B, T=T), synth.reps(seed=611, B=B, T=T)
+    # seeds chosen so that no pre-ReLU CLS element of either stream lies within 1e-3 of zero (seed 611 puts one at +2e-6: a
+    # ReLU gate that any equally valid fp32 summation order can close, which changes that clip's gradient by 10 %)
+    x, f = synth.reps(seed=610, B=B, T=T), synth.reps(seed=613, B=B, T=T)
     for b in range(B):
         x[b, :, lens[b]:] = 0
         f[b, :, lens[b]:] = 0
