@@ -12,7 +12,6 @@
 // Orientation: scores are computed transposed, S^T = K Q^T (key on accumulator rows, query on the
 // lane), so that P^T is already the B operand of O^T = V^T P^T with no lane movement; the k-slot
 // map of that product is  element e of lane group g  <->  key 32 s + 16 (e>>2) + 4 g + (e&3).
-#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/sais_hip.h"
 
@@ -163,21 +162,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
 // dQ^T = K^T dS^T for the 32 queries of the step — complete over all keys, so dQ goes straight to HBM.
 // delta_q = sum_d dO O is computed while staging.  Five MFMA products per (query, key) tile instead of seven, one
 // exponential instead of two, every operand staged once (the two-kernel version re-staged K, V, Q, dO: 470 vs 348 MB).
-// Desynchronised workgroups (round 3).  Every problem starts with a 125-KB fetch; with a static schedule all 256 workgroups
-// fetch in the same microseconds and HBM idles while they compute (staging was 32 % of a wave's time at 7 B/clk/CU).  The
-// workgroups therefore start `stagger` x (b / 8 mod 8) microseconds apart and draw their problems from a device-wide
-// queue, so that the late starters take fewer problems instead of lengthening the tail.  g_attn_bwd_queue = {next problem,
-// finished workgroups}; the last workgroup to finish resets both, so the launch is re-entrant in stream order (graph
-// replays included) without a memset node.  One launch at a time may use the queue (the library issues them in stream order).
-__device__ unsigned g_attn_bwd_queue[2];
-
 constexpr int SROW = 96;                                   // bytes per key row of the dS image (32 queries bf16 + pad)
 constexpr int S_BYTES = TILE_ROWS * SROW;                  // 21504
 constexpr int BWD_LDS = 3 * MAT_BYTES + 2 * TILE_ROWS * 4 + 2 * S_BYTES;     // 152320
 
 __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
                                                         const bf16* out, long ldout, const float* lse, int nprob,
-                                                        bf16* dqkv, long lddq, float scale, int stagger) {
+                                                        bf16* dqkv, long lddq, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sQ = smem;
     char* const sO = smem + MAT_BYTES;
@@ -188,12 +179,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float c = scale * LOG2E;
-    __shared__ int s_next;
-    for (int i = ((blockIdx.x >> 3) & 7) * stagger; i > 0; --i) __builtin_amdgcn_s_sleep(32);      // ~1 us per unit
-    for (int prob = blockIdx.x; prob < nprob;) {
-        // the next problem is drawn now and read after this problem's closing barrier (the first gridDim.x problems are
-        // assigned statically)
-        if (tid == 0) s_next = (int)(atomicAdd(&g_attn_bwd_queue[0], 1u) + gridDim.x);
+    for (int prob = blockIdx.x; prob < nprob; prob += gridDim.x) {
         const int f = prob / NH, h = prob - f * NH;
         const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
         const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
@@ -308,16 +294,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
             }
         }
         __syncthreads();                                    // every read of this problem's images is done
-        prob = s_next;
-        __syncthreads();                                    // ... before thread 0 overwrites s_next
-    }
-    if (tid == 0 && blockIdx.x < nprob) {                   // the last workgroup out resets the queue for the next launch
-        __threadfence();
-        if (atomicAdd(&g_attn_bwd_queue[1], 1u) == min((unsigned)gridDim.x, (unsigned)nprob) - 1u) {
-            g_attn_bwd_queue[0] = 0u;
-            g_attn_bwd_queue[1] = 0u;
-            __threadfence();
-        }
     }
 }
 
@@ -358,10 +334,8 @@ extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, 
         return SAIS_ERR_ARG;
     if (set_lds(attn_bwd_kernel, BWD_LDS)) return SAIS_ERR_LAUNCH;
     const int nprob = frames * NH;
-    static const int stag_env = [] { const char* e = getenv("SAIS_ATTN_STAGGER"); return e ? atoi(e) : 2; }();
-    const int stagger = nprob >= 4 * 256 ? stag_env : 0;    // only launches with several problems per workgroup
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(nprob < 256 ? nprob : 256), dim3(1024), BWD_LDS, (hipStream_t)stream,
                        (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, nprob,
-                       (bf16*)dqkv, lddqkv, 0.125f, stagger);
+                       (bf16*)dqkv, lddqkv, 0.125f);
     return sais_check_launch();
 }
