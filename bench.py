@@ -277,9 +277,20 @@ def main():
     # backward hooks issue on ProcessGroupNCCL's stream (forked / joined with events, which the capture records as graph
     # edges) — is captured into one hipGraph.  gloo (tests on a 1-GPU box) exchanges through the host: not capturable.
     use_graph = not args.no_graph and (not dist_on or backend == "nccl")
+    graph_note = None
     if use_graph:
         from sais_amd.graph import GraphedStep
-        step = GraphedStep(eager_step, warmup=2, capture_error_mode="thread_local" if dist_on else "global")
+        try:
+            step = GraphedStep(eager_step, warmup=2, capture_error_mode="thread_local" if dist_on else "global")
+        except Exception as e:                               # noqa: BLE001
+            if not dist_on:
+                raise
+            # N > 1 only: the RCCL build refused the capture.  Every rank takes this branch together (the capture is
+            # collective), the run continues on the eager launch path and SAYS so in the line and on stderr.
+            graph_note = f"hipGraph capture of the RCCL step failed ({type(e).__name__}: {e}); eager launch path"
+            sys.stderr.write("bench.py: " + graph_note + "\n")
+            use_graph = False
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         loss = step()
 
@@ -440,7 +451,7 @@ def main():
                                     f"fwd+bwd+SGD, {B} clips x {T} frames x 224x224 per GPU (global {world * B} clips), "
                                     f"random-init weights, RGB stream"), "clips_per_gpu": B, "frames_per_clip": T,
                        "streams": nstream, "vit_frames_per_step_per_gpu": nstream * B * T,
-                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
+                       "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else (graph_note or "eager"),
                        "temporal_dropout": model.dropout_p, "vit_drop_path": vit.drop_path_rate},
             "step_tflops": round(step_flops * world * args.steps / dt / 1e12, 1),
             "frac_of_mfma_roofline": round(step_flops * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),

@@ -134,6 +134,77 @@ def test_train_step_stagewise_vs_oracle_at_benchmark_dispatch(gpu, B, T):
     assert not bad, bad
 
 
+def test_two_stream_train_step_stagewise_vs_oracle_at_config4_size(gpu):
+    """BASELINE config 4 at its bench size: 8 clips x 32 frames x 2 streams (RGB + flow frames), 512 frames through the ViT
+    in ONE pass (M = 100 864 rows: two whole rounds of the eight-wave row tiles), the temporal encoder once per stream,
+    streams fused by add (prepare_model.py:412), loss, backward — checked stage by stage like the config-2 test."""
+    from oracle import sais_oracle as O
+    from parity import parity_log
+    from sais_amd.loss import calcNCELoss, cosine_logits_and_probs
+    from sais_amd.temporal import fullModel
+    B, T = 8, 32
+    vit, _, protos = _models()
+    m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB-Flow')
+    m.load_state_dict(synth.temporal_state_dict(seed=1), strict=True)
+    m.dropout_p = 0.0
+    m = m.to(DEV).train()
+    F = 2 * B * T
+    frames = torch.cat([synth.clips(seed=2000, B=B, T=T), synth.clips(seed=2001, B=B, T=T)]).view(F, 3, 224, 224)
+    lens = [T - (5 * b) % 9 for b in range(B)]
+    lens[0] = T
+    pad = synth.padding_mask(lens)
+    lab = synth.labels(seed=2100, B=B)
+    reps = vit(frames.to(DEV))
+    reps.retain_grad()
+    r5 = reps.view(2, B, 1, T, 384)
+    emb, attn = m(r5[0], r5[1], lens, lens, 'Prototypes', pad.to(DEV), pad.to(DEV), None)
+    loss = calcNCELoss(0, emb, lab, [f"v{b}" for b in range(B)], protos, None)
+    loss.backward()
+    sim, _ = cosine_logits_and_probs(emb, protos)
+    torch.cuda.synchronize()
+    vsd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0).items()}
+    tsd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(2, 2).items()}
+    dreps_gpu = reps.grad.detach().cpu()
+    parts = []
+    for i in range(0, F, 32):
+        r = O.vit_forward(vsd, frames[i:i + 32])
+        parts.append(r.detach())
+        (r * dreps_gpu[i:i + 32]).sum().backward()
+    reps_ref = torch.cat(parts)
+    rr = reps_ref.view(2, B, 1, T, 384)
+    with torch.no_grad():
+        e_ref, a_ref = O.temporal_forward(tsd, rr[0], rr[1], pad, pad, "RGB-Flow")
+        sim_ref, loss_ref = O.cosine_logits(e_ref, pr), O.nce_loss(e_ref, lab, pr)
+    tag = "two-stream step[B8,T32]/"
+    dfeat = (reps.detach().cpu() - reps_ref).abs().max().item() / reps_ref.abs().max().item()
+    dlogit = (sim.cpu() - sim_ref).abs().max().item()
+    dattn = (attn.cpu() - a_ref).abs().max().item()
+    parity_log(tag + "features max-abs / max|ref|", dfeat, FEAT_REL)
+    parity_log(tag + "cosine logits max-abs", dlogit, LOGIT_TOL)
+    parity_log(tag + "attention map max-abs", dattn, 2e-3)
+    assert dfeat <= FEAT_REL and dlogit <= LOGIT_TOL and dattn <= 2e-3, (dfeat, dlogit, dattn)
+    assert abs(loss.item() - loss_ref.item()) <= LOGIT_TOL
+    # stage 1: temporal backward (both streams) at the GPU's own features
+    gx = reps.detach().cpu().view(2, B, 1, T, 384)
+    rx, rf = gx[0].clone().requires_grad_(True), gx[1].clone().requires_grad_(True)
+    e1, _ = O.temporal_forward(tsd, rx, rf, pad, pad, "RGB-Flow")
+    O.nce_loss(e1, lab, pr).backward()
+    r = rel_l2(reps.grad, torch.cat([rx.grad.reshape(B * T, 384), rf.grad.reshape(B * T, 384)]))
+    parity_log(tag + "d loss / d features rel-L2", r, GRAD_REL)
+    assert r <= GRAD_REL, r
+    P = dict(m.named_parameters())
+    worst = max(rel_l2(P[n].grad, tsd[n].grad) for n in (
+        "linear.weight", "frame_cls", "frame_pos_embeddings.0", "transEncoderFrame.layers.0.self_attn.in_proj_weight",
+        "transEncoderFrame.layers.3.norm2.bias", "transEncoderFrame.layers.1.linear1.weight"))
+    parity_log(tag + "temporal parameter gradients, worst tensor rel-L2", worst, GRAD_REL)
+    assert worst <= GRAD_REL, worst
+    # stage 2: ViT backward over all 512 frames
+    worst = max(rel_l2(q.grad, vsd[n].grad) for n, q in vit.named_parameters())
+    parity_log(tag + "ViT parameter gradients, worst tensor rel-L2 (150 tensors)", worst, VIT_GRAD_REL)
+    assert worst <= VIT_GRAD_REL, worst
+
+
 def test_config2_graph_replay_equals_eager_step(gpu):
     """The code path bench.py times: one config-2 step (8 clips x 32 frames, M = 50 432) replayed from a hipGraph vs
     issued eagerly, both from the same weights."""

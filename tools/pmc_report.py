@@ -34,7 +34,7 @@ ROW_K_PATTERN = {"gemm_ln_fwd": [384, 1536] * 11 + [384],          # proj + norm
 
 
 def timer_name(kernel):
-    m = re.search(r"gemm_nt_row_kernel<(\d+), *(?:true|false)>|gemm_nt_row_kernel<(\d+)>|gemm_nt_row_kernelILi(\d+)E", kernel)
+    m = re.search(r"gemm_nt_row_kernel<(\d+)[,>]|gemm_nt_row_kernel<(\d+)>|gemm_nt_row_kernelILi(\d+)E", kernel)
     if m:
         return ROW_NAMES[int(m.group(1) or m.group(2) or m.group(3))]
     m = re.search(r"gemm_nt(?:_w8p)?_kernel<(\d+)>|gemm_nt(?:_w8p)?_kernelILi(\d+)E", kernel)
@@ -43,6 +43,9 @@ def timer_name(kernel):
     for key, name in (("gemm_tn_pp_kernel", "gemm_tn_grouped"), ("gemm_tn_wide_kernel", "gemm_tn_grouped"), ("gemm_tn_grouped_kernel", "gemm_tn_grouped"),
                       ("attn_fwd_kernel", "vit_attn_fwd"), ("attn_bwd_dq_kernel", "vit_attn_bwd_dq"),
                       ("attn_bwd_dkv_kernel", "vit_attn_bwd_dkv"), ("attn_bwd_kernel", "vit_attn_bwd"),
+                      ("tln_fwd_kernel", "temporal_ln_fwd"), ("tln_bwd_kernel", "temporal_ln_bwd"), ("tgemm_kernel", "tgemm"),
+                      ("tattn_fwd_kernel", "temporal_attn_fwd"), ("tattn_bwd_kernel", "temporal_attn_bwd"),
+                      ("gemm_tn_grouped_f32_kernel", "gemm_tn_grouped_f32"),
                       ("ln_fwd_kernel", "ln_fwd"), ("ln_bwd_kernel", "ln_bwd"), ("sgd_kernel", "sgd")):
         if key in kernel:
             return name
