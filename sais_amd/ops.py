@@ -77,7 +77,11 @@ def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0,
     g = L.SaisGemm(_p(a), a.stride(0), _p(w), w.stride(0), M, N, K, epilogue, _p(bias),
                    _p(out), out.stride(-2), _p(out2), 0 if out2 is None else out2.stride(-2),
                    _p(aux), 0 if aux is None else aux.stride(-2), grp[0], grp[1], grp[2], _p(rowscale), 0.0, None, 0)
-    nbytes = 2 * (M * K + N * K) + out.element_size() * M * N
+    nbytes = 2 * (M * K + N * K) + out.element_size() * M * N          # algorithmic: operands once, every output once
+    if out2 is not None:
+        nbytes += out2.element_size() * M * N
+    if aux is not None and epilogue != L.EPI_PATCH_F32:
+        nbytes += aux.element_size() * M * N
     _timed(f"gemm_nt<{_NT_NAMES[epilogue]}>[N{N},K{K}]", 2.0 * M * N * K, nbytes,
            lambda: L.call("sais_gemm_nt", ctypes.byref(g), _stream()))
     return out
