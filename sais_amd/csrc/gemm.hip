@@ -298,6 +298,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
             for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
         float bias[8];
         EpiAux8 aux;
+        // The barrier-paced K loop outranks the epilogue of the OTHER workgroup on this CU (round 3): the two share the SIMDs'
+        // issue ports, and at equal priority the epilogue's VALU stream (GELU: ~19 slots per element) delays the waves the
+        // whole workgroup waits for at the next barrier.  fc1 + GELU' 124 -> 117-120 us, dX fc2 114 -> 108-112, qkv 67 -> 63-65
+        // on two boxes; priorities 1, 2 and 3 measure the same.
+        __builtin_amdgcn_s_setprio(2);
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) issue_w(kt + 1);
             if (kt + 2 < nk) issue_a(kt + 2);
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: only the epilogue's loads are out
             __builtin_amdgcn_s_barrier();
         }
+        __builtin_amdgcn_s_setprio(0);
         // the next tile's first loads go out before this tile's epilogue
         const int cm0 = m0, cn0 = n0;
         const int nv = v + gridDim.x;
