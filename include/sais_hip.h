@@ -103,6 +103,9 @@ typedef struct SaisTGemm {
     float p_drop; const unsigned long long* rng_state; unsigned site;
 } SaisTGemm;
 int sais_tgemm(const SaisTGemm* g, void* stream);
+/* the K split this library recommends for a SAIS_TG_RAW launch of that shape (>= 1; the slab workspace the caller passes
+ * as `out` is nsplit * M * N floats): the sizing rule lives here, not in the host language                               */
+int sais_tgemm_nsplit(int M, int N, int K);
 /* Row kernels over D = 384 that CONSUME the slabs (split-K reduce + epilogue + LayerNorm in one pass):
  *   sais_temporal_ln_fwd:  y = resid + drop(sum_z slabs[z] + bias) ;  z = LayerNorm(y; gamma, beta, eps) ; mean / rstd saved
  *       = `src = src + dropout1(out_proj(..))` / `src = src + dropout2(linear2(..))` followed by norm1 / norm2 of the

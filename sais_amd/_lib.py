@@ -88,6 +88,7 @@ SIGNATURES = {
     "sais_temporal_prepare_bwd": [c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_long, c_long, c_int, c_void_p,
                                   c_void_p, c_void_p],
     "sais_tgemm": [ctypes.POINTER(SaisTGemm), c_void_p],
+    "sais_tgemm_nsplit": [c_int, c_int, c_int],
     "sais_temporal_ln_fwd": [c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_float, c_void_p, ctypes.c_uint, c_void_p,
                              c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "sais_temporal_ln_bwd": [c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

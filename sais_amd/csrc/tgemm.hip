@@ -339,6 +339,17 @@ extern "C" int sais_tgemm(const SaisTGemm* g, void* stream) {
     return sais_check_launch();
 }
 
+// Recommended number of K splits for a SAIS_TG_RAW launch: as many workgroups as fit one round of the chip (256 CUs), at
+// least two K-steps per split.  The caller allocates nsplit * M * N floats for the slabs.  Returns 1 for bad arguments.
+extern "C" int sais_tgemm_nsplit(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64) return 1;
+    const int tiles = ((M + 63) / 64) * (N / 64), nk = K / 64;
+    int best = 1;
+    for (int ns = 1; ns <= nk; ++ns)
+        if (nk % ns == 0 && nk / ns >= 2 && tiles * ns <= 256) best = ns;
+    return best;
+}
+
 extern "C" int sais_temporal_ln_fwd(const float* slabs, int nslab, long slab_stride, const float* bias, const float* resid,
                                     int rows, float p_drop, const unsigned long long* rng_state, unsigned site, float* y,
                                     const float* gamma, const float* beta, float eps, float* z, float* mean, float* rstd,

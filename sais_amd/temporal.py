@@ -269,19 +269,10 @@ class fullModel(nn.Module):
     # path, leaving the whole 1e-3 budget to the bf16 ViT.  The N = 384 GEMMs (out_proj, linear2 and every dX) write RAW
     # split-K slabs; the kernel that consumes them (LayerNorm forward / backward, attention backward, prepare backward)
     # sums the slabs and applies bias / dropout / residual itself, so a layer is 7 launches forward and 8 backward.
-    @staticmethod
-    def _nsplit(M, N, K):
-        """K splits of a RAW GEMM: as many workgroups as fit one round of the chip, at least two K-steps each."""
-        tiles, nk, best = -(-M // 64) * (N // 64), K // 64, 1
-        for ns in range(1, nk + 1):
-            if nk % ns == 0 and nk // ns >= 2 and tiles * ns <= 256:
-                best = ns
-        return best
-
     def _raw(self, a, w):
         """a . w^T as raw split-K slabs f32 [nsplit, M, N] (ops.tgemm, TG_RAW)."""
         M, N, K = a.shape[0], w.shape[0], w.shape[1]
-        ns = self._nsplit(M, N, K)
+        ns = L.load().sais_tgemm_nsplit(M, N, K)          # the split rule lives in the C library
         out = torch.empty(ns, M, N, dtype=torch.float32, device=a.device)
         return ops.tgemm(a, w, L.TG_RAW, out, nsplit=ns)
 

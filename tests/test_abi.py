@@ -30,6 +30,12 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     g = _lib.SaisGemm()
     assert lib.sais_gemm_nt(ctypes.byref(g), None) == -1
     assert lib.sais_gemm_ln_fwd(None, None) == -1 and lib.sais_gemm_ln_bwd(ctypes.byref(_lib.SaisGemmLn()), None) == -1
+    assert lib.sais_tgemm(None, None) == -1 and lib.sais_tgemm(ctypes.byref(_lib.SaisTGemm()), None) == -1
+    assert lib.sais_temporal_ln_fwd(None, 1, 0, None, None, 8, 0.0, None, 0, None, None, None, 1e-5, None, None, None, None) == -1
+    assert lib.sais_mil_head(None, 1, 1, 2, None, None, None, None, None, None, None, None, None, None, None, None) == -1
+    # the split-K sizing rule of the temporal GEMMs is a host function of the library (no GPU): benchmark shapes
+    assert [lib.sais_tgemm_nsplit(264, 384, k) for k in (384, 1152, 2048)] == [3, 6, 8]
+    assert lib.sais_tgemm_nsplit(264, 2048, 384) == 1 and lib.sais_tgemm_nsplit(0, 384, 384) == 1
     assert lib.sais_layernorm_fwd(None, 384, 4, 384, None, None, 1e-6, None, 384, None, 384, None, None, None) == -1
     assert lib.sais_vit_attn_fwd(None, 1152, 1, None, 384, None, None, None) == -1
     assert lib.sais_temporal_attn_fwd(None, None, 1, 1000, None, None, 0.0, None, 0, None) == -1
