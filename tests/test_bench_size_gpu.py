@@ -19,7 +19,9 @@ import synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-LOGIT_TOL, FEAT_REL, GRAD_REL, VIT_GRAD_REL = 1e-3, 3e-2, 4e-2, 6e-2
+# bars at the benchmark's own size, tightened in round 3 to ~3x the worst values observed there (profiles/r03_a_parity_worst.json:
+# features 1.0 %, ViT parameter gradients 0.7 %, temporal gradients 0.1 %, d loss / d features 0.13 %)
+LOGIT_TOL, FEAT_REL, GRAD_REL, VIT_GRAD_REL = 1e-3, 2e-2, 1e-2, 2e-2
 
 
 @pytest.fixture(scope="module")
