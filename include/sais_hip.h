@@ -256,10 +256,11 @@ int sais_temporal_prepare_bwd(const float* dz_f32, const float* slabs, int nslab
                               long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos, float* dcls,
                               void* stream);
 /* nn.MultiheadAttention core of the torch-1.8 post-norm TransformerEncoderLayer (prepare_model.py:74-81,
- * called at :213) in eval mode: q scaled by 96^-0.5, key_pad[b][j] != 0 -> -inf, softmax, P v.
+ * called at :213): q scaled by 96^-0.5, key_pad[b][j] != 0 -> -inf, softmax, (dropout,) P v — exact fp32 on the matrix
+ * cores (v_mfma_f32_16x16x4_f32), one workgroup per (sequence, head).
  * attn_avg f32 [B,S,S] (optional) = P averaged over the 4 heads = the README.md:43-48 attention map. */
 #define SAIS_TEMPORAL_MAX_S_FWD 96
-#define SAIS_TEMPORAL_MAX_S_BWD 64
+#define SAIS_TEMPORAL_MAX_S_BWD 96
 int sais_temporal_attn_fwd(const float* qkv /*[B*S,1152]*/, const unsigned char* key_pad /*[B,S]*/, int B, int S,
                            float* ctx /*[B*S,384]*/, float* attn_avg, float p_drop, const unsigned long long* rng_state,
                            unsigned site, void* stream);

@@ -111,6 +111,39 @@ def temporal_prepare(sd, x):
     return torch.cat((cls, x), dim=2)                                                  # [B,ns,T+1,D]
 
 
+# ---- ReLU gates.  A training batch of the temporal encoder has millions of ReLU gates (264 rows x 2048 FFN units x 4 layers
+# x streams); a gate whose pre-activation lies within the rounding of the arithmetic that produced it is open in one
+# correct evaluation and closed in another, and ONE such gate in the CLS row of a short clip moves that clip's gradient
+# by per cents.  To test a backward pass to 1e-4 instead of 1e-2 the checker can therefore evaluate THIS restatement with
+# the gates another forward took: `with imposed_gates(list_of_bool_tensors) as ig:` makes every ReLU of the temporal path
+# (FFN of each layer, then the aggregate ReLU, per stream; the head's ReLU last — the call order of temporal_forward)
+# multiply by the next mask instead of thresholding; ig.mismatches lists, per call, how many gates differed.
+_GATES = None
+
+
+class imposed_gates:
+    def __init__(self, gates):
+        self.gates, self.mismatches = list(gates), []
+
+    def __enter__(self):
+        global _GATES
+        _GATES = self
+        return self
+
+    def __exit__(self, *exc):
+        global _GATES
+        _GATES = None
+        return False
+
+
+def _relu(t):
+    if _GATES is None or not _GATES.gates:
+        return F.relu(t)
+    gate = _GATES.gates.pop(0).reshape(t.shape)
+    _GATES.mismatches.append(int(((t > 0) != gate).sum()))
+    return t * gate.to(t.dtype)
+
+
 def temporal_layer(sd, pre, x, key_pad, heads=T_HEADS, drop=None, p=0.1):
     """torch-1.8 post-norm TransformerEncoderLayer with the README.md:43-48 edit that returns the head-averaged
     attention map.  x [Bn,S,D] (batch-first here; the reference feeds [S,Bn,D] — same math), key_pad bool [Bn,S].
@@ -130,7 +163,7 @@ def temporal_layer(sd, pre, x, key_pad, heads=T_HEADS, drop=None, p=0.1):
     ctx = (probs @ v).transpose(1, 2).reshape(Bn, S, D)
     a = F.linear(ctx, sd[pre + "self_attn.out_proj.weight"], sd[pre + "self_attn.out_proj.bias"])
     x = F.layer_norm(x + dm(a, "d1"), (D,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], 1e-5)
-    ff = F.linear(dm(F.relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])), "ff"),
+    ff = F.linear(dm(_relu(F.linear(x, sd[pre + "linear1.weight"], sd[pre + "linear1.bias"])), "ff"),
                   sd[pre + "linear2.weight"], sd[pre + "linear2.bias"])
     x = F.layer_norm(x + dm(ff, "d2"), (D,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-5)
     return x, probs.mean(dim=1)
@@ -148,7 +181,7 @@ def temporal_aggregate(sd, seq, pad, nlayers=4, trace=None, drop=None, p=0.1):
         x, attn = temporal_layer(sd, f"transEncoderFrame.layers.{l}.", x, kp, drop=None if drop is None else drop[l], p=p)
         if trace is not None:
             trace.append(x)
-    full = F.relu(x).reshape(B, ns, S, D)
+    full = _relu(x).reshape(B, ns, S, D)
     return full, full[:, :, 0, :], attn
 
 
@@ -180,9 +213,10 @@ def temporal_forward(sd, x, f, xpad, fpad, modalities="RGB-Flow", nlayers=4, imp
             rep, attn, full = flow.mean(dim=1), fattn, ffull
         else:
             rep = rep + flow.mean(dim=1)                                               # :412
-    emb = F.linear(F.relu(rep), sd["linear.weight"], sd["linear.bias"])                # :416 (double ReLU, App. B.4)
+    rrep = _relu(rep)
+    emb = F.linear(rrep, sd["linear.weight"], sd["linear.bias"])                       # :416 (double ReLU, App. B.4)
     if "linearB.weight" in sd and modalities == "RGB-Flow" and domains is not None:      # :405-414
-        embB = F.linear(F.relu(rep), sd["linearB.weight"], sd["linearB.bias"])
+        embB = F.linear(rrep, sd["linearB.weight"], sd["linearB.bias"])
         useB = torch.tensor([d != 'NH_02' for d in domains]).view(-1, 1)
         emb = torch.where(useB, embB, emb)
     if importance:

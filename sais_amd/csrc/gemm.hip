@@ -542,7 +542,9 @@ DEVINL u32x4 load8_bf16(const float* p) {
 // one 128x128 output tile over rows [mbeg, mend) of P / Q
 // OWNED: the workgroup is the only writer of its output tile in this launch (one M-split), so the accumulation into dW / db
 // is a plain read-add-write instead of 16 k atomics per tile (the few-row temporal dW GEMMs were atomics-bound: 37 -> 23 us)
-template <typename T, bool OWNED = false>
+// NP = P columns (= dW rows) per tile: 128, or 64 for the few-row temporal dW launches (twice the workgroups, half the
+// read-add-write epilogue per workgroup)
+template <typename T, bool OWNED = false, int NP = 128>
 DEVINL void tn_tile(const TnParams& p, int n1_0, int n2_0, int mbeg, int mend, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
@@ -555,7 +557,7 @@ DEVINL void tn_tile(const TnParams& p, int n1_0, int n2_0, int mbeg, int mend, c
         for (int i = 0; i < 4; ++i) {
             int m = mb + sr + 16 * i;
             bool ok = m < mend;
-            rp[i] = ok ? load8_bf16((const T*)p.P + (size_t)m * p.ldp + n1_0 + sc * 8) : u32x4{0, 0, 0, 0};
+            rp[i] = (ok && sc < NP / 8) ? load8_bf16((const T*)p.P + (size_t)m * p.ldp + n1_0 + sc * 8) : u32x4{0, 0, 0, 0};
             rq[i] = ok ? load8_bf16((const T*)p.Q + (size_t)m * p.ldq + n2_0 + sc * 8) : u32x4{0, 0, 0, 0};
         }
     };
@@ -569,10 +571,11 @@ DEVINL void tn_tile(const TnParams& p, int n1_0, int n2_0, int mbeg, int mend, c
         }
     };
 
-    f32x4 acc[4][4];
-    f32x4 accb[4];
+    constexpr int PT = NP / 32;                    // 16-column P tiles per wave (the wave owns NP / 2 dW rows)
+    f32x4 acc[PT][4];
+    f32x4 accb[PT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PT; ++i) {
         accb[i] = f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
@@ -595,23 +598,27 @@ DEVINL void tn_tile(const TnParams& p, int n1_0, int n2_0, int mbeg, int mend, c
         const char* sq = sp + TTILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fp[4], fq[4];
+            bf16x8 fp[PT], fq[4];
             // k-slot (g, e) <-> m = 32 ks + 16 (e>>2) + 4 g + (e&3): a half-wave touches 8 CONSECUTIVE rows
             // per read (conflict-free with the 288-B row stride); P and Q use the same slot map.
             const int rbase = (ks * 32 + 4 * g + q4) * TROW + p4 * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                int cp = (wr * 64 + t * 16) * 2, cq = (wc * 64 + t * 16) * 2;
-                fp[t] = cat4(lds_read_tr16(sp + rbase + cp), lds_read_tr16(sp + rbase + 16 * TROW + cp));
+                int cq = (wc * 64 + t * 16) * 2;
                 fq[t] = cat4(lds_read_tr16(sq + rbase + cq), lds_read_tr16(sq + rbase + 16 * TROW + cq));
             }
 #pragma unroll
-            for (int it = 0; it < 4; ++it)
+            for (int t = 0; t < PT; ++t) {
+                int cp = (wr * (NP / 2) + t * 16) * 2;
+                fp[t] = cat4(lds_read_tr16(sp + rbase + cp), lds_read_tr16(sp + rbase + 16 * TROW + cp));
+            }
+#pragma unroll
+            for (int it = 0; it < PT; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma16(fp[it], fq[jt], acc[it][jt]);
             if (do_bias) {
 #pragma unroll
-                for (int it = 0; it < 4; ++it) accb[it] = mfma16(fp[it], ones, accb[it]);
+                for (int it = 0; it < PT; ++it) accb[it] = mfma16(fp[it], ones, accb[it]);
             }
         }
         if (st + 1 < nsteps) lstore(cur ^ 1);
@@ -619,10 +626,10 @@ DEVINL void tn_tile(const TnParams& p, int n1_0, int n2_0, int mbeg, int mend, c
     }
     // D[i = n1][j = n2]: lane holds n2 = tile + li, n1 = tile + 4g + r
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+    for (int it = 0; it < PT; ++it)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int n1 = n1_0 + wr * 64 + it * 16 + 4 * g + r;
+            int n1 = n1_0 + wr * (NP / 2) + it * 16 + 4 * g + r;
             float* row = p.dW + (size_t)n1 * p.ldw + n2_0 + wc * 64 + li;
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
@@ -761,7 +768,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(TnGroup gp) {
 
 // the same grouping for fp32 operands (rounded to bf16 while staging): the four dW of a temporal-encoder layer, M = a few
 // hundred rows, where the launch count rather than the arithmetic is what costs
-template <bool OWNED>
+template <bool OWNED, int NP = 128>
 __global__ __launch_bounds__(256) void gemm_tn_grouped_f32_kernel(TnGroup gp) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TTILE];
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_f32_kernel(TnGroup gp) {
     const int mbeg = split * p.rows_per_split;
     const int mend = min(p.M, mbeg + p.rows_per_split);
     if (mbeg >= mend) return;
-    tn_tile<float, OWNED>(p, (t / nt2) * 128, (t % nt2) * 128, mbeg, mend, smem);
+    tn_tile<float, OWNED, NP>(p, (t / nt2) * NP, (t % nt2) * 128, mbeg, mend, smem);
 }
 
 // Wide variant of the grouped dW kernel: 128 (P columns) x 384 (Q columns) output tile per 512-thread workgroup
@@ -1152,6 +1159,17 @@ extern "C" int sais_gemm_tn_grouped_f32(const SaisTnItem* items, int nitems, int
         gp.tile_end[i] = total;
     }
     gp.ntiles = total;
+    if (ns == 1 && total < 200) {
+        // one M-split and fewer tiles than CUs (the temporal layers: 132): 64-row dW tiles = twice the workgroups
+        int t64 = 0;
+        for (int i = 0; i < nitems; ++i) {
+            t64 += (items[i].N1 / 64) * (items[i].N2 / 128);
+            gp.tile_end[i] = t64;
+        }
+        gp.ntiles = t64;
+        hipLaunchKernelGGL((gemm_tn_grouped_f32_kernel<true, 64>), dim3(t64), dim3(256), 0, (hipStream_t)stream, gp);
+        return sais_check_launch();
+    }
     if (ns == 1) hipLaunchKernelGGL(gemm_tn_grouped_f32_kernel<true>, dim3(total), dim3(256), 0, (hipStream_t)stream, gp);
     else hipLaunchKernelGGL(gemm_tn_grouped_f32_kernel<false>, dim3(total * ns), dim3(256), 0, (hipStream_t)stream, gp);
     return sais_check_launch();

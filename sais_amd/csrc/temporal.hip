@@ -4,9 +4,7 @@
 // around them go through the MFMA GEMMs in gemm.hip.
 //
 //   prepareInputForTransformer  prepare_model.py:179-195   (sais_temporal_prepare_*)
-//   nn.MultiheadAttention core inside the torch-1.8 post-norm TransformerEncoderLayer, with
-//   key_padding_mask and the README.md:43-48 head-averaged attention-map return
-//                               prepare_model.py:74-81,197-221   (sais_temporal_attn_*)
+//   (the attention core: tattn.hip; the linear layers and LayerNorms: tgemm.hip)
 //   ReLU -> CLS row -> (+flow) -> ReLU -> Linear(384->256)   prepare_model.py:215,220,381-416 (sais_head_*)
 //   calcNCELoss / getProbs      prepare_miscellaneous.py:14-46,111-126   (sais_nce_*)
 #include "common.hpp"
@@ -63,158 +61,7 @@ __global__ void prepare_bwd_kernel(const float* dz32, const float* slabs, int ns
     else atomicAdd(dpos + (size_t)(s - 1) * D + c, acc);
 }
 
-// ---------------------------------------------------------------- masked multi-head attention, one WG per (clip, head)
-DEVINL void load_head(const float* qkv, int b, int h, int S, int which, float* dst, int tid, int nt) {
-    // dst[s][QS] <- qkv[(b*S+s), which*384 + h*96 + d]
-    for (int i = tid; i < S * (THD / 4); i += nt) {
-        int s = i / (THD / 4), c4 = i % (THD / 4);
-        f32x4 v = *(const f32x4*)(qkv + ((size_t)b * S + s) * (3 * D) + which * D + h * THD + 4 * c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[s * QS + 4 * c4 + e] = v[e];
-    }
-}
-
-// P[i][j] = softmax_j( (q_i * scale) . k_j  masked by key_pad[b][j] )  -> sP[S][S+1]
-DEVINL void probs_lds(const float* sQ, const float* sK, const unsigned char* pad, int S, float scale, float* sP, int tid,
-                      int nt) {
-    const int SP = S + 1;
-    for (int idx = tid; idx < S * S; idx += nt) {
-        int i = idx / S, j = idx % S;
-        float a = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < THD; ++d) a += sQ[i * QS + d] * sK[j * QS + d];
-        sP[i * SP + j] = pad[j] ? -INFINITY : a * scale;
-    }
-    __syncthreads();
-    const int lane = tid & 63, w = tid >> 6;
-    for (int i = w; i < S; i += nt >> 6) {
-        float m = -INFINITY;
-        for (int j = lane; j < S; j += 64) m = fmaxf(m, sP[i * SP + j]);
-        m = wave_max(m);
-        float sum = 0.f;
-        for (int j = lane; j < S; j += 64) { float e = __expf(sP[i * SP + j] - m); sP[i * SP + j] = e; sum += e; }
-        sum = wave_sum(sum);
-        float inv = 1.0f / sum;
-        for (int j = lane; j < S; j += 64) sP[i * SP + j] *= inv;
-    }
-    __syncthreads();
-}
-
-// Train mode (p > 0): the attention weights are dropped AFTER the softmax and BEFORE P v, and the returned map is the
-// dropped one (torch-1.8 F.multi_head_attention_forward: softmax -> dropout -> bmm; the weights it returns are the
-// dropped ones).  Mask element index: ((b * 4 + h) * S + i) * S + j.
-__global__ __launch_bounds__(1024) void tattn_fwd_kernel(const float* qkv, const unsigned char* key_pad, int S, float* ctx,
-                                                        float* attn_avg, float p_drop, const unsigned long long* rng,
-                                                        unsigned sid) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sQ = (float*)smem;
-    float* sK = sQ + S * QS;
-    float* sV = sK + S * QS;
-    float* sP = sV + S * QS;
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x, SP = S + 1;
-    load_head(qkv, b, h, S, 0, sQ, tid, nt);
-    load_head(qkv, b, h, S, 1, sK, tid, nt);
-    load_head(qkv, b, h, S, 2, sV, tid, nt);
-    __syncthreads();
-    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, 0.10206207261596577f /* 96^-0.5 */, sP, tid, nt);
-    if (p_drop > 0.f) {
-        const unsigned thr = drop_threshold(p_drop);
-        const float inv = 1.0f / (1.0f - p_drop);
-        const unsigned long long base = ((unsigned long long)b * TH + h) * S * S;
-        for (int idx = tid; idx < S * S; idx += nt) {
-            float& v = sP[(idx / S) * SP + idx % S];
-            v = philox_keep(rng, sid, base + idx, thr) ? v * inv : 0.f;
-        }
-        __syncthreads();
-    }
-    if (attn_avg)
-        for (int idx = tid; idx < S * S; idx += nt)
-            atomicAdd(attn_avg + (size_t)b * S * S + idx, sP[(idx / S) * SP + idx % S] * (1.0f / TH));
-    for (int idx = tid; idx < S * THD; idx += nt) {
-        int i = idx / THD, d = idx % THD;
-        float a = 0.f;
-        for (int j = 0; j < S; ++j) a += sP[i * SP + j] * sV[j * QS + d];
-        ctx[((size_t)b * S + i) * D + h * THD + d] = a;
-    }
-}
-
-// With dropout: ctx = P' v, P' = P m / (1 - p).  dV = P'^T dctx; dP = (dctx v^T) m / (1 - p); dS = P (dP - rowsum(P dP)).
-// The mask is regenerated from (rng, sid) and kept in the SIGN BIT of the stored P (P >= 0): negative = dropped.
-// dctx = sum_z dctx[z] (nslab raw split-K slabs of the out_proj dX GEMM, slab_stride floats apart; nslab = 1: a plain tensor)
-__global__ __launch_bounds__(1024) void tattn_bwd_kernel(const float* qkv, const unsigned char* key_pad, int S,
-                                                        const float* dctx, int nslab, long slab_stride, float* dqkv,
-                                                        float p_drop, const unsigned long long* rng, unsigned sid) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sQ = (float*)smem;
-    float* sK = sQ + S * QS;
-    float* sV = sK + S * QS;
-    float* sG = sV + S * QS;                 // dctx
-    float* sP = sG + S * QS;
-    float* sS = sP + S * (S + 1);            // dP then dS
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nt = blockDim.x, SP = S + 1;
-    const float scale = 0.10206207261596577f;
-    load_head(qkv, b, h, S, 0, sQ, tid, nt);
-    load_head(qkv, b, h, S, 1, sK, tid, nt);
-    load_head(qkv, b, h, S, 2, sV, tid, nt);
-    for (int i = tid; i < S * (THD / 4); i += nt) {
-        int s = i / (THD / 4), c4 = i % (THD / 4);
-        f32x4 v = *(const f32x4*)(dctx + ((size_t)b * S + s) * D + h * THD + 4 * c4);
-        for (int z = 1; z < nslab; ++z) v += *(const f32x4*)(dctx + (size_t)z * slab_stride + ((size_t)b * S + s) * D + h * THD + 4 * c4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sG[s * QS + 4 * c4 + e] = v[e];
-    }
-    __syncthreads();
-    probs_lds(sQ, sK, key_pad + (size_t)b * S, S, scale, sP, tid, nt);
-    const float inv = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    if (p_drop > 0.f) {
-        const unsigned thr = drop_threshold(p_drop);
-        const unsigned long long base = ((unsigned long long)b * TH + h) * S * S;
-        for (int idx = tid; idx < S * S; idx += nt) {
-            float& v = sP[(idx / S) * SP + idx % S];
-            if (!philox_keep(rng, sid, base + idx, thr)) v = -v;          // -0.0f for P == 0: the sign bit is the flag
-        }
-        __syncthreads();
-    }
-    auto kept = [](float pv) { return !__builtin_signbit(pv); };
-    // dV[j][d] = sum_i P'[i][j] dctx[i][d]
-    for (int idx = tid; idx < S * THD; idx += nt) {
-        int j = idx / THD, d = idx % THD;
-        float a = 0.f;
-        for (int i = 0; i < S; ++i) {
-            const float pv = sP[i * SP + j];
-            a += (kept(pv) ? pv * inv : 0.f) * sG[i * QS + d];
-        }
-        dqkv[((size_t)b * S + j) * (3 * D) + 2 * D + h * THD + d] = a;
-    }
-    // dP[i][j] = (dctx_i . v_j) m / (1 - p)
-    for (int idx = tid; idx < S * S; idx += nt) {
-        int i = idx / S, j = idx % S;
-        float a = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < THD; ++d) a += sG[i * QS + d] * sV[j * QS + d];
-        sS[i * SP + j] = kept(sP[i * SP + j]) ? a * inv : 0.f;
-    }
-    __syncthreads();
-    const int lane = tid & 63, w = tid >> 6;
-    for (int i = w; i < S; i += nt >> 6) {
-        float dot = 0.f;
-        for (int j = lane; j < S; j += 64) dot += fabsf(sP[i * SP + j]) * sS[i * SP + j];
-        dot = wave_sum(dot);
-        for (int j = lane; j < S; j += 64) sS[i * SP + j] = fabsf(sP[i * SP + j]) * (sS[i * SP + j] - dot) * scale;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < S * THD; idx += nt) {
-        int i = idx / THD, d = idx % THD;
-        float aq = 0.f, ak = 0.f;
-        for (int j = 0; j < S; ++j) {
-            aq += sS[i * SP + j] * sK[j * QS + d];      // dq_i = sum_j dS[i][j] k_j
-            ak += sS[j * SP + i] * sQ[j * QS + d];      // dk_i = sum_j dS[j][i] q_j
-        }
-        size_t row = ((size_t)b * S + i) * (3 * D) + h * THD + d;
-        dqkv[row] = aq;
-        dqkv[row + D] = ak;
-    }
-}
+// (masked multi-head attention: tattn.hip)
 
 // ---------------------------------------------------------------- head
 // rep = relu(z_rgb[b,0]) (+ relu(z_flow[b,0]));  emb = W relu(rep) + bias
@@ -536,35 +383,6 @@ extern "C" int sais_temporal_prepare_bwd(const float* dz_f32, const float* slabs
     hipLaunchKernelGGL(prepare_bwd_kernel, dim3(((T + 1) * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz_f32,
                        slabs, slabs ? nslab : 0, slab_stride, B, T, dx, dx_clip_stride, dx_frame_stride, accumulate, dpos,
                        dcls);
-    return sais_check_launch();
-}
-
-extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key_pad, int B, int S, float* ctx,
-                                      float* attn_avg, float p_drop, const unsigned long long* rng_state,
-                                      unsigned site, void* stream) {
-    SAIS_ENTER();
-    if (!qkv || !key_pad || !ctx || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_FWD) return SAIS_ERR_ARG;
-    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !rng_state)) return SAIS_ERR_ARG;
-    int lds = (3 * S * QS + S * (S + 1)) * 4;
-    if (set_lds(tattn_fwd_kernel, lds)) return SAIS_ERR_LAUNCH;
-    hipStream_t s = (hipStream_t)stream;
-    if (attn_avg && hipMemsetAsync(attn_avg, 0, (size_t)B * S * S * 4, s) != hipSuccess) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(1024), lds, s, qkv, key_pad, S, ctx, attn_avg, p_drop, rng_state,
-                       site);
-    return sais_check_launch();
-}
-
-extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key_pad, int B, int S,
-                                      const float* dctx, int nslab, long slab_stride, float* dqkv, float p_drop,
-                                      const unsigned long long* rng_state, unsigned site, void* stream) {
-    SAIS_ENTER();
-    if (!qkv || !key_pad || !dctx || !dqkv || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_BWD || nslab <= 0 || (slab_stride & 3))
-        return SAIS_ERR_ARG;
-    if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !rng_state)) return SAIS_ERR_ARG;
-    int lds = (4 * S * QS + 2 * S * (S + 1)) * 4;
-    if (set_lds(tattn_bwd_kernel, lds)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(1024), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, nslab,
-                       slab_stride, dqkv, p_drop, rng_state, site);
     return sais_check_launch();
 }
 

@@ -123,6 +123,19 @@ def test_train_step_stagewise_vs_oracle_at_benchmark_dispatch(gpu, B, T):
     if r > GRAD_REL:
         bad["d loss / d reps"] = r
     assert not bad, bad
+    # ... and tightly: the fp64 oracle at the ReLU gates the HIP forward took (tests/test_model_gpu.py explains why)
+    from parity import hip_temporal_gates
+    gates = hip_temporal_gates(m, reps.detach().view(B, 1, T, 384), None, pad.to(DEV), None)
+    tsd64 = {k: v.double().clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+    pr64 = {k: v.double().clone() for k, v in synth.prototypes(2, 2).items()}
+    rx64 = reps.detach().cpu().double().view(B, 1, T, 384).clone().requires_grad_(True)
+    with O.imposed_gates(gates) as ig:
+        e64, _ = O.temporal_forward(tsd64, rx64, None, pad, None, "RGB")
+        O.nce_loss(e64, lab, pr64).backward()
+    tight = max(rel_l2(reps.grad.view(B, T, 384)[b], rx64.grad[b, 0].numpy()) for b in range(B))
+    parity_log(tag + "d loss / d features per clip vs fp64 oracle at the same ReLU gates", tight, 1e-3)
+    parity_log(tag + "ReLU gates that differ from the fp64 oracle", sum(ig.mismatches), 200)
+    assert tight <= 1e-3 and sum(ig.mismatches) <= 200, (tight, ig.mismatches)
 
     # stage 2: ViT backward driven by the GPU's own upstream gradient (all frames: parameter gradients sum over them)
     bad = {}

@@ -305,7 +305,8 @@ def test_temporal_prepare(ops):
         assert_close(dcls, d[:, 0].sum(0), atol=1e-4)
 
 
-@pytest.mark.parametrize("S,lens", [(33, [32, 20, 3, 0, 17]), (16, [15, 15]), (64, [63, 10, 40])])
+@pytest.mark.parametrize("S,lens", [(33, [32, 20, 3, 0, 17]), (16, [15, 15]), (64, [63, 10, 40]), (40, [39, 7]), (96, [95, 50, 1]),
+                                    (8, [7, 3, 0])])
 def test_temporal_attention_fwd_bwd(ops, S, lens):
     B = len(lens)
     qkv = rnd(B * S, 1152, seed=60, scale=1.0)

@@ -190,23 +190,48 @@ def test_loss_logits_and_grads_vs_golden(gpu, golden, C):
     assert maxabs(probs, g[key + "probs"]) <= LOGIT_TOL
     assert abs(loss.item() - float(g[key + "loss"])) <= LOGIT_TOL
     assert maxabs(attn, g[key + "attn"]) <= ATTN_TOL
-    assert rel_l2(x.grad, g[key + "grad_x"]) <= GRAD_REL, rel_l2(x.grad, g[key + "grad_x"])
+    # Gradients and ReLU gates.  This batch has 264 rows x 2048 FFN units x 4 layers x 2 streams = 4.3 M ReLU gates; a gate
+    # whose pre-activation lies within fp32 rounding (~1e-6 relative) of zero is open in one correct fp32 evaluation and
+    # closed in another (a few per forward: the reference's own summation order vs any other), and ONE flipped gate in the
+    # CLS row of a short clip moves that clip's gradient by 1-4 % (measured: clips without a flipped gate agree to 2e-5,
+    # clips with one to 1e-3 .. 4e-2; tests/golden multidomain fixture note).  So: every clip / tensor within GATE_REL
+    # (one or two flipped gates), and the TYPICAL clip / tensor (median) within 1e-3 — the bar that a wrong kernel fails.
+    GATE_REL = 8e-2
+    gx = g[key + "grad_x"]
+    per_clip = [rel_l2(x.grad[b], gx[b]) for b in range(B)]
+    assert max(per_clip) <= GATE_REL and float(np.median(per_clip)) <= 1e-3, per_clip
     for k in protos.keys():
         assert rel_l2(protos[k].grad, g[key + f"grad_proto{k}"]) <= GRAD_REL
     P = dict(m.named_parameters())
-    bad = {}
+    errs = {}
     for k in g.files:
         if k.startswith(key + "grad/"):
             n = k[len(key + "grad/"):]
-            r = rel_l2(P[n].grad, g[k])
+            errs[n] = rel_l2(P[n].grad, g[k])
         elif k.startswith(key + "grad8/"):
             n = k[len(key + "grad8/"):]
-            r = rel_l2(P[n].grad[:8], g[k])
-        else:
-            continue
-        if r > GRAD_REL:
-            bad[n] = r
+            errs[n] = rel_l2(P[n].grad[:8], g[k])
+    bad = {n: r for n, r in errs.items() if r > GATE_REL}
     assert not bad, bad
+    assert float(np.median(list(errs.values()))) <= 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    # The tight check: the fp64 oracle evaluated WITH THE GATES THIS FORWARD TOOK (oracle.imposed_gates) — what is left is
+    # the arithmetic of the backward kernels alone.  Measured: 1.5e-5 .. 1.7e-5 on every clip with 13 of 4.3 M gates differing.
+    from oracle import sais_oracle as O
+    from parity import hip_temporal_gates, parity_log
+    gates = hip_temporal_gates(m, x, f, pad, pad)
+    sd = {k: v.double().clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+    pr = {k: v.double().clone().requires_grad_(True) for k, v in synth.prototypes(2, C).items()}
+    xr = x.detach().cpu().double().requires_grad_(True)
+    with O.imposed_gates(gates) as ig:
+        e64, _ = O.temporal_forward(sd, xr, f.detach().cpu().double(), pad.cpu(), pad.cpu(), "RGB-Flow")
+        O.nce_loss(e64, lab, pr).backward()
+    assert sum(ig.mismatches) <= 200, ig.mismatches                       # a handful of 4.3 M, not a different network
+    tight = [rel_l2(x.grad[b], xr.grad[b].numpy()) for b in range(B)]
+    parity_log(f"temporal C{C}/d loss / d x per clip vs fp64 oracle at the same ReLU gates", max(tight), 1e-3)
+    parity_log(f"temporal C{C}/ReLU gates that differ from the fp64 oracle (of 4.3 M)", sum(ig.mismatches), 200)
+    assert max(tight) <= 1e-3, tight
+    tight_p = {n: rel_l2(P[n].grad, sd[n].grad.numpy()) for n in errs}
+    assert max(tight_p.values()) <= 2e-3, sorted(tight_p.items(), key=lambda kv: -kv[1])[:5]
     # parameters the reference never touches (clip encoder, MIL heads, unused positions, linear2) get zero grad
     assert float(P["transEncoderClip.layers.0.linear1.weight"].grad.abs().max()) == 0.0
     assert float(P["frame_pos_embeddings.40"].grad.abs().max()) == 0.0

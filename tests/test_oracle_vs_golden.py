@@ -294,3 +294,46 @@ def test_oracle_mil_forward_vs_reference(golden):
     assert np.abs(logits.numpy() - g["logits"]).max() <= 5e-5
     for c in range(2):
         assert np.abs(att[c].numpy() - g[f"attention{c}"]).max() <= 5e-6
+
+
+def test_oracle_imposed_gates_reproduce_the_plain_evaluation():
+    """oracle.imposed_gates (the checker's tool for gate-conditioned gradient parity): with the gates the plain evaluation took
+    imposed on a second evaluation nothing changes, and a flipped gate in a CLS row changes that clip's gradient only."""
+    lens = [6, 3]
+    x = synth.reps(seed=900, B=2, T=6)
+    pad = synth.padding_mask(lens)
+    lab = synth.labels(seed=901, B=2)
+
+    def run(gates=None):
+        sd = {k: v.double().clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+        pr = {k: v.double().clone() for k, v in synth.prototypes(2, 2).items()}
+        xr = x.double().clone().requires_grad_(True)
+        trace = []
+        if gates is None:
+            e, _ = O.temporal_forward(sd, xr, None, pad, None, "RGB", trace=trace)
+            mism = None
+        else:
+            with O.imposed_gates(gates) as ig:
+                e, _ = O.temporal_forward(sd, xr, None, pad, None, "RGB")
+            mism = ig.mismatches
+        O.nce_loss(e, lab, pr).backward()
+        return xr.grad, sd, trace, mism
+
+    g0, sd, trace, _ = run()
+    # the gates of the plain run: recompute them layer by layer from its trace (inputs of each layer's FFN are not exposed,
+    # so take the gates from a gate-logging pass: impose all-ones on a throwaway run to read the pre-activations' signs)
+    seen = []
+    real = O._relu
+    O._relu = lambda t: (seen.append((t > 0).clone()), real(t))[1]
+    try:
+        run()
+    finally:
+        O._relu = real
+    assert len(seen) == 6                                   # 4 FFN + aggregate + head
+    g1, _, _, mism = run(seen)
+    assert mism == [0] * 6 and torch.allclose(g1, g0, rtol=0, atol=1e-15)
+    flipped = [s.clone() for s in seen]
+    flipped[3].view(2, 7, 2048)[1, 0, :16] ^= True          # 16 gates of clip 1's CLS row in the last layer's FFN
+    g2, _, _, mism2 = run(flipped)
+    assert mism2[:4] == [0, 0, 0, 16]                      # (later gates then differ from what their new inputs would give)
+    assert torch.allclose(g2[0], g0[0], rtol=0, atol=1e-15) and not torch.allclose(g2[1], g0[1], rtol=1e-3, atol=0)
