@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
     };
     const int nk = p.K / BK;
     // store instructions one wave issues in a full tile's epilogue
-    constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2
+    constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2 : (EPI == SAIS_EPI_PATCH_F32) ? 2
                        : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
     const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
 
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
 
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        if (big && E != SAIS_EPI_PATCH_F32) {                                               \
+        if (big) {                                                                          \
             static thread_local bool set8p = false;                                         \
             if (!set8p) {                                                                   \
                 if (hipFuncSetAttribute((const void*)gemm_nt_w8p_kernel<E>,                 \

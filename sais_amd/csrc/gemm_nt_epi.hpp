@@ -45,8 +45,10 @@ DEVINL void epilogue_loads8(const NtParams& p, int mbase, int li, int n, float (
     for (int mt = 0; mt < 4; ++mt) {
         int m = mbase + mt * 16 + li;
         m = m < p.M ? m : p.M - 1;
-        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32) {
-            const float* r = (const float*)p.aux + (size_t)m * p.ldaux + n;
+        if constexpr (EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_PATCH_F32) {
+            size_t row = m;
+            if constexpr (EPI == SAIS_EPI_PATCH_F32) row = (m % p.grp_in) + p.grp_off;       // position row of the patch
+            const float* r = (const float*)p.aux + row * p.ldaux + n;
             a.r[mt][0] = *(const f32x4*)r;
             a.r[mt][1] = *(const f32x4*)(r + 4);
         } else if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16 || EPI == SAIS_EPI_MUL_BF16) {
@@ -84,6 +86,13 @@ DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], cons
         for (int i = 0; i < 8; ++i) y[i] += a.r[mt][i >> 2][i & 3];
         store_f32(p.out, p.ldo, y);
         if (p.out2) store_bf16(p.out2, p.ldo2, y);
+    } else if constexpr (EPI == SAIS_EPI_PATCH_F32) {
+        // patch embedding: + position row, token row (m / grp_in) * grp_out + m % grp_in + grp_off of the [F, 197, 384] stream
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] += a.r[mt][i >> 2][i & 3];
+        float* o = (float*)p.out + ((size_t)(m / p.grp_in) * p.grp_out + (m % p.grp_in) + p.grp_off) * p.ldo + n;
+        *(f32x4*)o = f32x4{y[0], y[1], y[2], y[3]};
+        *(f32x4*)(o + 4) = f32x4{y[4], y[5], y[6], y[7]};
     } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_BF16) {
         if (p.out2) store_bf16(p.out2, p.ldo2, y);
         gelu_erf_n(y);
