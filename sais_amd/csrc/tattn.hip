@@ -40,6 +40,18 @@ DEVINL f32x4 dot_tile(const float (&x)[24], const float (&y)[24]) {
     for (int s = 0; s < 24; ++s) acc = mfma4(x[s], y[s], acc);
     return acc;
 }
+// two tiles at once: the two accumulator chains are independent, so the MFMAs issue back to back (a single chain waits
+// out the 40-cycle dependent latency of the 32-cycle instruction)
+DEVINL void dot_tile2(const float (&x0)[24], const float (&y0)[24], const float (&x1)[24], const float (&y1)[24], f32x4& a0,
+                      f32x4& a1) {
+    a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 24; ++s) {
+        a0 = mfma4(x0[s], y0[s], a0);
+        a1 = mfma4(x1[s], y1[s], a1);
+    }
+}
 DEVINL float max4g(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
 DEVINL float sum4g(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
 
@@ -83,11 +95,20 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const float* qkv, const 
         f32x4 p[MAXT];
         float m = -INFINITY;
 #pragma unroll
+        for (int kt = 0; kt < MAXT; kt += 2) {           // two key tiles per pass: two independent accumulator chains
+            if (kt >= nt) break;
+            float kf[24], kg[24];
+            load24(sK + (16 * kt + li) * TLD, g, kf);
+            if (kt + 1 < nt) {
+                load24(sK + (16 * (kt + 1) + li) * TLD, g, kg);
+                dot_tile2(kf, qf, kg, qf, p[kt], p[kt + 1]);          // register r: key 16 kt + 4 g + r, query q
+            } else {
+                p[kt] = dot_tile(kf, qf);
+            }
+        }
+#pragma unroll
         for (int kt = 0; kt < MAXT; ++kt) {
             if (kt >= nt) break;
-            float kf[24];
-            load24(sK + (16 * kt + li) * TLD, g, kf);
-            p[kt] = dot_tile(kf, qf);                    // register r: key 16 kt + 4 g + r, query q
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * kt + 4 * g + r;
@@ -117,17 +138,24 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const float* qkv, const 
                 if (attn_avg && q < S && key < S) atomicAdd(attn_avg + ((size_t)b * S + q) * S + key, v * (1.0f / TH));
             }
         }
-        // ctx^T[d][query] = sum_key v[key][d] P^T[key][query]
+        // ctx^T[d][query] = sum_key v[key][d] P^T[key][query]: six independent accumulator chains (one per 16 features)
+        f32x4 acc[THD / 16];
 #pragma unroll
-        for (int dt = 0; dt < THD / 16; ++dt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < THD / 16; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < MAXT; ++kt) {
-                if (kt >= nt) break;
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt >= nt) break;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = mfma4(sV[(16 * kt + 4 * g + r) * TLD + 16 * dt + li], p[kt][r], acc);
+            for (int r = 0; r < 4; ++r) {
+                const float* vrow = sV + (16 * kt + 4 * g + r) * TLD + li;
+#pragma unroll
+                for (int dt = 0; dt < THD / 16; ++dt) acc[dt] = mfma4(vrow[16 * dt], p[kt][r], acc[dt]);
             }
-            if (q < S) *(f32x4*)(ctx + ((size_t)b * S + q) * D + h * THD + 16 * dt + 4 * g) = acc;
+        }
+        if (q < S) {
+#pragma unroll
+            for (int dt = 0; dt < THD / 16; ++dt)
+                *(f32x4*)(ctx + ((size_t)b * S + q) * D + h * THD + 16 * dt + 4 * g) = acc[dt];
         }
     }
 }
@@ -183,11 +211,10 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
 #pragma unroll
         for (int kt = 0; kt < MAXT; ++kt) {
             if (kt >= nt) break;
-            float kf[24];
+            float kf[24], vf[24];
             load24(sK + (16 * kt + li) * TLD, g, kf);
-            p[kt] = dot_tile(kf, qf);
-            load24(sV + (16 * kt + li) * TLD, g, kf);
-            dp[kt] = dot_tile(kf, gf);                   // dP'[query][key] = dctx_q . v_key, key 4 g + r on the registers
+            load24(sV + (16 * kt + li) * TLD, g, vf);
+            dot_tile2(kf, qf, vf, gf, p[kt], dp[kt]);    // scores^T and dP'[query][key] = dctx_q . v_key (key 4 g + r on the registers)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * kt + 4 * g + r;
@@ -227,16 +254,23 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
             for (int r = 0; r < 4; ++r) p[kt][r] = p[kt][r] * (dp[kt][r] - dot) * scale;      // dS^T[key][query]
         }
         // dq^T[d][query] = sum_key k[key][d] dS^T[key][query]
+        f32x4 acc[THD / 16];
 #pragma unroll
-        for (int dt = 0; dt < THD / 16; ++dt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < THD / 16; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < MAXT; ++kt) {
-                if (kt >= nt) break;
+        for (int kt = 0; kt < MAXT; ++kt) {
+            if (kt >= nt) break;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = mfma4(sK[(16 * kt + 4 * g + r) * TLD + 16 * dt + li], p[kt][r], acc);
+            for (int r = 0; r < 4; ++r) {
+                const float* krow = sK + (16 * kt + 4 * g + r) * TLD + li;
+#pragma unroll
+                for (int dt = 0; dt < THD / 16; ++dt) acc[dt] = mfma4(krow[16 * dt], p[kt][r], acc[dt]);
             }
-            if (q < S) *(f32x4*)(dqkv + ((size_t)b * S + q) * (3 * D) + h * THD + 16 * dt + 4 * g) = acc;
+        }
+        if (q < S) {
+#pragma unroll
+            for (int dt = 0; dt < THD / 16; ++dt)
+                *(f32x4*)(dqkv + ((size_t)b * S + q) * (3 * D) + h * THD + 16 * dt + 4 * g) = acc[dt];
         }
     }
     __syncthreads();
@@ -252,11 +286,11 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
 #pragma unroll
         for (int dt = 0; dt < THD / 16; ++dt) { adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         for (int qt = 0; qt < nt; ++qt) {
-            float xf[24];
+            float xf[24], yf[24];
             load24(sQ + (16 * qt + li) * TLD, g, xf, scale);
-            const f32x4 s = dot_tile(xf, kf);            // register r: query 16 qt + 4 g + r, key on the lane
-            load24(sG + (16 * qt + li) * TLD, g, xf);
-            const f32x4 dpp = dot_tile(xf, vf);          // dP'[query][key]
+            load24(sG + (16 * qt + li) * TLD, g, yf);
+            f32x4 s, dpp;                                // register r: query 16 qt + 4 g + r, key on the lane
+            dot_tile2(xf, kf, yf, vf, s, dpp);           // scores and dP'[query][key]
             const f32x4 m4 = *(const f32x4*)(sM + 16 * qt + 4 * g);
             const f32x4 i4 = *(const f32x4*)(sI + 16 * qt + 4 * g);
             const f32x4 d4 = *(const f32x4*)(sDot + 16 * qt + 4 * g);

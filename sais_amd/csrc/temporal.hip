@@ -38,27 +38,30 @@ __global__ void prepare_fwd_kernel(const float* x, long x_clip_stride, long x_fr
     }
 }
 
-// dz = dz32 + sum_z slabs[z] (either may be absent) ; dx[b,t] (+)= dz[b,1+t] ; dpos[t] += sum_b ; dcls += sum_b dz[b,0]
+// dz = dz32 + sum_z slabs[z] (either may be absent) ; dx[b,t] (+)= dz[b,1+t] ; dpos[t] += sum_b ; dcls += sum_b dz[b,0].
+// One thread per (sequence, token, 4 columns): every load of a thread is independent (a per-column loop over the sequences
+// was B x nslab dependent round trips: 16 us), the sums over the sequences are float atomics (B per element).
 __global__ void prepare_bwd_kernel(const float* dz32, const float* slabs, int nslab, long slab_stride, int B, int T,
                                    float* dx, long dx_clip_stride, long dx_frame_stride, int accumulate, float* dpos,
                                    float* dcls) {
     const int S = T + 1;
-    int i = blockIdx.x * 256 + threadIdx.x;            // over S*D
-    if (i >= S * D) return;
-    int s = i / D, c = i % D;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-        size_t idx = ((size_t)b * S + s) * D + c;
-        float v = dz32 ? dz32[idx] : 0.f;
-        for (int z = 0; z < nslab; ++z) v += slabs[(size_t)z * slab_stride + idx];
-        acc += v;
-        if (s > 0 && dx) {
-            float* o = dx + (size_t)b * dx_clip_stride + (size_t)(s - 1) * dx_frame_stride + c;
-            *o = accumulate ? *o + v : v;
-        }
+    const long i = blockIdx.x * 256L + threadIdx.x;            // over B * S * (D / 4)
+    if (i >= (long)B * S * (D / 4)) return;
+    const int c = 4 * (int)(i % (D / 4));
+    const long r = i / (D / 4);
+    const int b = (int)(r / S), s = (int)(r % S);
+    const size_t idx = (size_t)r * D + c;
+    f32x4 v = dz32 ? *(const f32x4*)(dz32 + idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < nslab; ++z) v += *(const f32x4*)(slabs + (size_t)z * slab_stride + idx);
+    if (s > 0 && dx) {
+        float* o = dx + (size_t)b * dx_clip_stride + (size_t)(s - 1) * dx_frame_stride + c;
+        f32x4 out = v;
+        if (accumulate) out += *(const f32x4*)o;
+        *(f32x4*)o = out;
     }
-    if (s == 0) atomicAdd(dcls + c, acc);
-    else atomicAdd(dpos + (size_t)(s - 1) * D + c, acc);
+    float* acc = s == 0 ? dcls + c : dpos + (size_t)(s - 1) * D + c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(acc + e, v[e]);
 }
 
 // (masked multi-head attention: tattn.hip)
@@ -87,13 +90,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const fl
     }
     __syncthreads();
     const bool second = useB && useB[b];
-    float a = (second ? biasB : bias)[tid];
-    const float* w = (second ? WB : W) + (size_t)tid * D;
-    for (int c = 0; c < D; c += 4) {
-        f32x4 t = *(const f32x4*)(w + c);
-        a += t[0] * sr[c] + t[1] * sr[c + 1] + t[2] * sr[c + 2] + t[3] * sr[c + 3];
+    const float* Ws = second ? WB : W;
+    const float* bs = second ? biasB : bias;
+    // one output per wave at a time, the 384 inputs across the lanes: every weight row is read as one contiguous 1.5-KB run
+    // (a thread per output walked 64 different rows per load instruction: 15 us for 8 clips)
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int o = wid; o < EMB; o += 4) {
+        const float* w = Ws + (size_t)o * D;
+        float a = 0.f;
+#pragma unroll
+        for (int c = lane; c < D; c += 64) a += w[c] * sr[c];
+        a = wave_sum(a);
+        if (lane == 0) emb[(size_t)b * EMB + o] = a + bs[o];
     }
-    emb[(size_t)b * EMB + tid] = a;
 }
 
 // demb [B,256] -> dz_rgb[b,s,0,:] / dz_flow[b,s,0,:] (one workgroup per clip), then dW += demb^T relu(rep) and
@@ -380,7 +389,9 @@ extern "C" int sais_temporal_prepare_bwd(const float* dz_f32, const float* slabs
                                          float* dcls, void* stream) {
     SAIS_ENTER();
     if ((!dz_f32 && !slabs) || (slabs && nslab <= 0) || !dpos || !dcls || B <= 0 || T <= 0) return SAIS_ERR_ARG;
-    hipLaunchKernelGGL(prepare_bwd_kernel, dim3(((T + 1) * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dz_f32,
+    if ((dx_clip_stride & 3) || (dx_frame_stride & 3) || (slab_stride & 3)) return SAIS_ERR_ARG;
+    const long nthr = (long)B * (T + 1) * (D / 4);
+    hipLaunchKernelGGL(prepare_bwd_kernel, dim3((int)((nthr + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dz_f32,
                        slabs, slabs ? nslab : 0, slab_stride, B, T, dx, dx_clip_stride, dx_frame_stride, accumulate, dpos,
                        dcls);
     return sais_check_launch();

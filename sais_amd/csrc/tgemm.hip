@@ -194,6 +194,28 @@ DEVINL void drop12(float (&v)[12], const unsigned long long* rng, unsigned site,
     }
 }
 
+// v = sum_z slabs[z][row] with FOUR slab rows in flight (a one-at-a-time loop is nslab dependent round trips: 8 us for 8 slabs)
+DEVINL void sum_slabs(const float* slabs, int nslab, long slab_stride, size_t row_off, int l32, float (&v)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = 0.f;
+    int s = 0;
+    for (; s + 4 <= nslab; s += 4) {
+        float t0[12], t1[12], t2[12], t3[12];
+        ld12(slabs + (size_t)s * slab_stride + row_off, l32, t0);
+        ld12(slabs + (size_t)(s + 1) * slab_stride + row_off, l32, t1);
+        ld12(slabs + (size_t)(s + 2) * slab_stride + row_off, l32, t2);
+        ld12(slabs + (size_t)(s + 3) * slab_stride + row_off, l32, t3);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] += (t0[i] + t1[i]) + (t2[i] + t3[i]);
+    }
+    for (; s < nslab; ++s) {
+        float t[12];
+        ld12(slabs + (size_t)s * slab_stride + row_off, l32, t);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] += t[i];
+    }
+}
+
 // y = resid + dropout(sum_z slab_z + bias) ;  z = LayerNorm(y).  One row per half-wave, 8 rows per workgroup.
 __global__ __launch_bounds__(256) void tln_fwd_kernel(const float* slabs, int nslab, long slab_stride, const float* bias,
                                                       const float* resid, int rows, float p_drop,
@@ -204,12 +226,7 @@ __global__ __launch_bounds__(256) void tln_fwd_kernel(const float* slabs, int ns
     const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (row >= rows) return;
     float v[12], t[12];
-    ld12(slabs + (size_t)row * D, l32, v);
-    for (int s = 1; s < nslab; ++s) {
-        ld12(slabs + (size_t)s * slab_stride + (size_t)row * D, l32, t);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] += t[i];
-    }
+    sum_slabs(slabs, nslab, slab_stride, (size_t)row * D, l32, v);
     if (bias) {
         ld12(bias, l32, t);
 #pragma unroll
@@ -257,13 +274,7 @@ __global__ __launch_bounds__(256) void tln_bwd_kernel(const float* slabs, int ns
     for (int i = 0; i < 12; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
     for (int row = blockIdx.x * 8 + hw; row < rows; row += gridDim.x * 8) {
         float dy[12], xv[12], t[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) dy[i] = 0.f;
-        for (int s = 0; s < nslab; ++s) {
-            ld12(slabs + (size_t)s * slab_stride + (size_t)row * D, l32, t);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) dy[i] += t[i];
-        }
+        sum_slabs(slabs, nslab, slab_stride, (size_t)row * D, l32, dy);
         if (add) {
             ld12(add + (size_t)row * D, l32, t);
 #pragma unroll
