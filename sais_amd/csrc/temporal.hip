@@ -85,23 +85,37 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* zr, const fl
             if (zf) vf += fmaxf(zf[(size_t)(b * ns + s) * clip_stride_f + c], 0.f);
         }
         const float v = vr * inv + vf * inv;
-        rep[(size_t)b * D + c] = v;
+        if (blockIdx.y == 0) rep[(size_t)b * D + c] = v;
         sr[c] = fmaxf(v, 0.f);
     }
     __syncthreads();
     const bool second = useB && useB[b];
     const float* Ws = second ? WB : W;
     const float* bs = second ? biasB : bias;
-    // one output per wave at a time, the 384 inputs across the lanes: every weight row is read as one contiguous 1.5-KB run
-    // (a thread per output walked 64 different rows per load instruction: 15 us for 8 clips)
+    // grid (B, 4): a workgroup owns 64 of the 256 outputs of its clip, a wave 16 of them, the 384 inputs across its lanes
+    // (every weight row is read as one contiguous 1.5-KB run; a thread per output walked 64 different rows per load
+    // instruction), EIGHT outputs per pass so that 48 independent loads are in flight (one output per pass is a chain of
+    // dependent round trips: 56 us measured)
     const int lane = tid & 63, wid = tid >> 6;
-    for (int o = wid; o < EMB; o += 4) {
-        const float* w = Ws + (size_t)o * D;
-        float a = 0.f;
+    float x[6];
 #pragma unroll
-        for (int c = lane; c < D; c += 64) a += w[c] * sr[c];
-        a = wave_sum(a);
-        if (lane == 0) emb[(size_t)b * EMB + o] = a + bs[o];
+    for (int i = 0; i < 6; ++i) x[i] = sr[lane + 64 * i];
+    const int obeg = 64 * blockIdx.y + 16 * wid;
+    for (int o0 = obeg; o0 < obeg + 16; o0 += 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* w = Ws + (size_t)(o0 + u) * D + lane;
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t += w[64 * i] * x[i];
+            a[u] = t;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = wave_sum(a[u]);
+            if (lane == 0) emb[(size_t)b * EMB + o0 + u] = t + bs[o0 + u];
+        }
     }
 }
 
@@ -403,7 +417,7 @@ extern "C" int sais_head_fwd(const float* z_rgb, const float* z_flow, long clip_
     SAIS_ENTER();
     if ((!z_rgb && !z_flow) || !W || !bias || !rep || !emb || B <= 0 || nsnippets <= 0) return SAIS_ERR_ARG;
     if (use_b && (!WB || !biasB)) return SAIS_ERR_ARG;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride,
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(B, 4), dim3(256), 0, (hipStream_t)stream, z_rgb, z_flow, clip_stride,
                        clip_stride_flow, nsnippets, W, bias, use_b, WB, biasB, rep, emb);
     return sais_check_launch();
 }
