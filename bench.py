@@ -366,19 +366,17 @@ def main():
     if rank == 0:
         summ = ops.TIMER.summary()
         ops.TIMER = None
-        fam = {}
-        for tag, v in summ.items():                          # tag = "<kernel>[shape]"; a kernel = all its shapes
-            f = fam.setdefault(tag.split("[")[0], dict(total_ms=0.0, launches=0, flops=0.0, bytes=0.0))
-            f["total_ms"] += v["total_ms"]
-            f["launches"] += v["launches"]
-            f["flops"] += v["flops"] * v["launches"]
-            f["bytes"] += v["bytes"] * v["launches"]
-        kern = max(fam, key=lambda k: fam[k]["total_ms"])
-        k = fam[kern]
-        avg_ms = k["total_ms"] / k["launches"]
-        flops, nbytes = k["flops"] / k["launches"], k["bytes"] / k["launches"]
+        # the dominant kernel = the (kernel, shape) tag with the largest total time; a kernel that runs several shapes has
+        # one launch duration per shape, so the shapes are not pooled
+        kern = max(summ, key=lambda t: summ[t]["total_ms"])
+        k = summ[kern]
+        avg_ms = k["avg_ms"]
+        flops, nbytes = k["flops"], k["bytes"]
         ach = flops / (avg_ms * 1e-3) / 1e12
-        pmc = (load_pmc("pmc_traffic.json") or {}).get(kern)
+        # key of the same kernel in profiles/pmc_traffic.json ("gemm_ln_bwd[N384,K1536]" -> "gemm_ln_bwd[K1536]")
+        base = kern.split("[")[0]
+        pmc_key = base + "[" + kern.split(",")[-1] if base in ("gemm_ln_fwd", "gemm_ln_bwd") else base
+        pmc = (load_pmc("pmc_traffic.json") or {}).get(pmc_key)
         roof = dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4),
                     traffic=(pmc or {}).get("hbm_bytes_per_launch"),
@@ -387,6 +385,7 @@ def main():
                     algorithmic_bytes=int(nbytes),
                     hbm_gbps_algorithmic=round(nbytes / (avg_ms * 1e-3) / 1e9, 1),
                     avg_launch_us=round(avg_ms * 1e3, 1), launches_per_step=k["launches"] // NPASS,
+                    hbm_frac_of_this_kernel=round(nbytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     timing="raw HIP-event interval per launch (includes ~4 us of event overhead; rocprofv3's kernel "
                            "durations in profiles/ are shorter by that much)",
                     all_kernels={n: dict(ms_per_step=round(v["total_ms"] / NPASS, 3), launches_per_step=v["launches"] // NPASS,
