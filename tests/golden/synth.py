@@ -194,3 +194,44 @@ def droppath_factors(seed, frames, depth=VIT_DEPTH, rate=0.1):
     rates = torch.linspace(0, rate, depth).repeat_interleave(2)
     keep = torch.rand((2 * depth, frames), generator=g) >= rates.view(-1, 1)
     return keep.float() / (1.0 - rates).view(-1, 1)
+
+
+# --------------------------------------------------------------------------- DINO pre-training (main_dino.py)
+HEAD_HID, HEAD_BOT = 2048, 256
+
+
+def dino_head_keys(out_dim):
+    """DINOHead(384, out_dim) parameter contract in named_parameters() order (vision_transformer.py:257-291):
+    mlp = Linear, GELU, Linear, GELU, Linear; last_layer = weight_norm(Linear(256, out_dim, bias=False))."""
+    return [("mlp.0.weight", (HEAD_HID, VIT_DIM), "w"), ("mlp.0.bias", (HEAD_HID,), "b"),
+            ("mlp.2.weight", (HEAD_HID, HEAD_HID), "w"), ("mlp.2.bias", (HEAD_HID,), "b"),
+            ("mlp.4.weight", (HEAD_BOT, HEAD_HID), "w"), ("mlp.4.bias", (HEAD_BOT,), "b"),
+            ("last_layer.weight_g", (out_dim, 1), "one"), ("last_layer.weight_v", (out_dim, HEAD_BOT), "w")]
+
+
+def dino_head_state_dict(seed, out_dim, w_std=0.04):
+    g = _gen(seed)
+    sd = {}
+    for name, shape, kind in dino_head_keys(out_dim):
+        if kind == "w":
+            t = torch.randn(shape, generator=g) * w_std
+        elif kind == "one":
+            t = torch.ones(shape)                           # weight_g.data.fill_(1), :278
+        else:
+            t = 0.05 * torch.randn(shape, generator=g)
+        sd[name] = t.float()
+    return sd
+
+
+def dino_crops(seed, B, n_local, gsize=224, lsize=96):
+    """The list DataAugmentationDINO.__call__ returns after collation: 2 global [B,3,224,224] + n_local [B,3,96,96]
+    normalised crops (main_dino.py:633-679).  Synthetic pixels: the PIL augmentations are outside the path."""
+    g = _gen(seed)
+    mean = torch.tensor(IMNET_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(IMNET_STD).view(1, 3, 1, 1)
+    out = []
+    for i in range(2 + n_local):
+        s = gsize if i < 2 else lsize
+        u8 = torch.randint(0, 256, (B, 3, s, s), generator=g, dtype=torch.uint8)
+        out.append((u8.float() / 255.0 - mean) / std)
+    return out
