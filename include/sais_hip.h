@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 6
+#define SAIS_ABI_VERSION 7
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -194,20 +194,23 @@ int sais_layernorm_bwd(const void* dy_bf16, long lddy16, const float* dy_f32, lo
 
 /* ---------------------------------------------------------------- ViT spatial attention (197 tokens, 6 heads x 64)
  * Attention.forward core, vision_transformer.py:83-90: softmax(q k^T / 8) v per (frame, head).
- * qkv bf16 [frames*197, 3*384] laid out as the qkv Linear writes it (q | k | v, head-major inside).
- * out bf16 [frames*197, 384]; lse f32 [frames,6,197] (saved for backward, optional);
- * probs f32 [frames,6,197,197] (optional: get_last_selfattention, :216-223).                      */
-int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, float* lse, float* probs,
+ * qkv bf16 [frames*ntok, 3*384] laid out as the qkv Linear writes it (q | k | v, head-major inside).
+ * out bf16 [frames*ntok, 384]; lse f32 [frames,6,ntok] (saved for backward, optional);
+ * probs f32 [frames,6,ntok,ntok] (optional: get_last_selfattention, :216-223).
+ * ntok = 197 (224 x 224 frames) or 37 (the 96 x 96 local crops of DINO pre-training, main_dino.py:658-663;
+ * prepare_tokens at that size, vision_transformer.py:196-207); anything else is SAIS_ERR_ARG.     */
+int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, int ntok, void* out, long ldo, float* lse, float* probs,
                       void* stream);
-/* dqkv bf16 [frames*197, 1152] from dout bf16 [frames*197, 384] and the saved forward output `out` (same shape:
+/* dqkv bf16 [frames*ntok, 1152] from dout bf16 [frames*ntok, 384] and the saved forward output `out` (same shape:
  * delta_q = sum_d dout[q,d] out[q,d] is the softmax-backward row term, computed in the kernel).  One single-pass
  * kernel: P is rebuilt once per (query, key) from lse.  delta_ws is unused since ABI 2 (may be NULL).              */
 int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout,
-                      const float* lse, float* delta_ws, int frames, void* dqkv, long lddqkv, void* stream);
+                      const float* lse, float* delta_ws, int frames, int ntok, void* dqkv, long lddqkv, void* stream);
 
 /* ---------------------------------------------------------------- ViT embedding glue
  * PatchEmbed + prepare_tokens, vision_transformer.py:116-131,196-207.                            */
-int sais_patchify(const float* frames_f32 /*[F,3,224,224]*/, int frames, void* patches_bf16 /*[F*196,768]*/, void* stream);
+int sais_patchify(const float* frames_f32 /*[F,3,side,side]*/, int frames, int side /* % 16 == 0 */,
+                  void* patches_bf16 /*[F*(side/16)^2,768]*/, void* stream);
 int sais_vit_cls_rows(const float* cls, const float* pos0, float* tokens, long frame_stride, int frames, int dim,
                       void* stream);
 /* dcls/dpos += reductions of dtokens f32 [F,ntok,dim]; dpatch_bf16 [F*(ntok-1), dim] = rows 1.. (dY of patch GEMM) */
@@ -335,6 +338,83 @@ int sais_importance_loss(const float* logits, const float* target, const unsigne
  * demb (written) and dprotos (accumulated), both scaled by loss_scale.                            */
 int sais_nce(const float* emb /*[B,256]*/, const float* protos /*[C,256]*/, const int* label_col, int B, int C,
              float* sim, float* probs, float* loss, float* demb, float* dprotos, float loss_scale, void* stream);
+
+/* ================================================================ DINO pre-training objective
+ * SAIS/scripts/dino-main/main_dino.py trains the ViT-S/16 encoder by self-distillation: train_one_epoch (:517-576) runs
+ * teacher(images[:2]) and student(images) through utils.MultiCropWrapper (utils.py:595-630; 2 global 224 x 224 crops + N
+ * local 96 x 96 crops), DINOHead (vision_transformer.py:257-291), DINOLoss (:579-630), utils.clip_gradients
+ * (utils.py:132-141), utils.cancel_gradients_last_layer (:144-149), AdamW on utils.get_params_groups (:633-645) and the
+ * EMA teacher update (:563-566).  The ViT and the head's nn.Linear layers run on the GEMM / attention entry points
+ * above (sais_vit_attn_* with ntok 197 / 37, sais_gemm_nt_f32, sais_gemm_tn_f32); the entries below are the rest.  */
+
+/* lse[r] = log sum_k exp((x[r][k] - center[k]) * scale), center may be NULL.  Teacher rows: scale = 1 / temp with the
+ * centre (F.softmax((teacher_output - self.center) / temp), :605); student rows: scale = 1 / student_temp, no centre
+ * (F.log_softmax(student_out[v]), :600,614).  n % 4 == 0.                                                            */
+int sais_dino_row_lse(const float* x, long ld, int rows, int n, float scale, const float* center, float* lse, void* stream);
+/* DINOLoss.forward (:596-619) and its gradient.  student f32 [ncrops*B, n] (row v*B + b = view v of sample b, the
+ * chunk(ncrops) layout), teacher f32 [2*B, n], s_lse / t_lse from sais_dino_row_lse.  Writes
+ *   loss[0]  = 1/n_terms sum_{iq < 2} sum_{v != iq} mean_b sum_k -q_iq[b,k] log_softmax(s_v[b] / student_temp)[k]
+ *   dlogits  = d loss / d student   (f32 [ncrops*B, n])
+ * partials: workspace of sais_dino_loss_partials(B, n) floats (fixed-order reduction, no atomics).                  */
+int sais_dino_loss_partials(int B, int n);
+int sais_dino_loss(const float* student, long lds, const float* teacher, long ldt, const float* center, const float* s_lse,
+                   const float* t_lse, int B, int ncrops, int n, float student_temp, float teacher_temp, float* dlogits,
+                   long ldd, float* partials, float* loss, void* stream);
+/* DINOLoss.update_center (:621-630) in two steps so that the data-parallel all-reduce of the [1, n] column sums
+ * (dist.all_reduce(batch_center), :627) sits between them:  out[k] = sum_r x[r][k];  then
+ * center = center * momentum + colsum * inv_count * (1 - momentum),  inv_count = 1 / (rows * world_size).           */
+int sais_dino_colsum(const float* x, long ld, int rows, int n, float* out, void* stream);
+int sais_dino_center_ema(float* center, const float* colsum, int n, float momentum, float inv_count, void* stream);
+
+/* DINOHead.forward pieces (vision_transformer.py:287-291): nn.GELU() between the MLP's Linear layers (f32 in / out; the
+ * backward is du = dh * gelu'(u)), F.normalize(x, dim=-1, p=2) (eps 1e-12) and nn.utils.weight_norm of the last layer
+ * (:277-281: w = g v / ||v||_row; _bwd ACCUMULATES dv and, when dg != NULL, dg).  One wave per row, dim <= 1024.      */
+int sais_gelu_fwd_f32(const float* u, float* h, long n, void* stream);
+int sais_gelu_bwd_f32(const float* dh, const float* u, float* du, long n, void* stream);
+int sais_l2norm_fwd(const float* z, int rows, int dim, float eps, float* out, float* inv, void* stream);
+int sais_l2norm_bwd(const float* dout, const float* out, const float* inv, int rows, int dim, float eps, float* dz, void* stream);
+int sais_weight_norm_fwd(const float* v, const float* g, int rows, int dim, float* w, float* inv, void* stream);
+int sais_weight_norm_bwd(const float* dw, const float* v, const float* g, const float* inv, int rows, int dim, float* dv,
+                         float* dg, void* stream);
+
+/* VisionTransformer.interpolate_pos_encoding (vision_transformer.py:174-194) for crops that are not 224 x 224: the
+ * bicubic resampling of the 14 x 14 positional grid is a fixed linear map Wm f32 [nout, nin] (built once per
+ * resolution by the host, sais_amd/vit.py); out [1 + nout, dim]: row 0 = pos row 0 (the CLS position, :179),
+ * rows 1.. = Wm . pos[1..].  _bwd ACCUMULATES the transpose into dpos [1 + nin, dim].                              */
+int sais_pos_interp_fwd(const float* Wm, int nout, int nin, const float* pos, int dim, float* out, void* stream);
+int sais_pos_interp_bwd(const float* Wm, int nout, int nin, const float* dout, int dim, float* dpos, void* stream);
+
+/* The optimizer tail of train_one_epoch over one flat parameter buffer (sais_amd/flat.py), cut by the host into chunks
+ * of <= sais_opt_chunk_elems() elements that never straddle a tensor ("segment").
+ * sais_grad_norms: norms[seg] = ||grad of tensor seg||_2 — what utils.clip_gradients computes per parameter (:135-136);
+ *   seg_first_chunk int [nseg + 1]; partial_ws f32 [nchunks].
+ * sais_adamw_ema_step, per element of every chunk, in this order:
+ *   clip   g *= min(1, clip / (norm + 1e-6))                       utils.py:137-140  (clip = 0: off, main_dino.py:547)
+ *   AdamW  p *= 1 - lr * wd (segments flagged SAIS_OPT_DECAY: the `regularized` group, utils.py:633-645; the others
+ *          decay 0);  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ *          p -= lr / bc1 * m / (sqrt(v) / sqrt_bc2 + eps)          torch.optim.AdamW, main_dino.py:446,556
+ *          bc1 = 1 - beta1^t, sqrt_bc2 = sqrt(1 - beta2^t) per step-count class: class 1 (SAIS_OPT_CLASS1) = the last
+ *          layer, whose step count lags while frozen1 != 0 (utils.cancel_gradients_last_layer, utils.py:144-149:
+ *          p.grad = None -> the optimizer skips the tensor entirely); SAIS_OPT_NO_GRAD: requires_grad False (weight_g)
+ *   EMA    teacher = teacher * ema_m + (1 - ema_m) * p              main_dino.py:563-566 (teacher may be NULL)
+ *   and the bf16 MFMA shadows of both (param16 / teacher16, may be NULL) are refreshed in the same pass.            */
+#define SAIS_OPT_DECAY 1
+#define SAIS_OPT_CLASS1 2
+#define SAIS_OPT_NO_GRAD 4
+typedef struct SaisOptChunk { long off; int len; int seg; } SaisOptChunk;
+typedef struct SaisAdamW {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;     /* flat f32 buffers, same layout   */
+    float* teacher; void* param16; void* teacher16;                         /* optional                        */
+    const SaisOptChunk* chunks; int nchunks;                                /* device table                    */
+    const int* seg_flags; const float* norms;                               /* device, per segment             */
+    float clip, lr, weight_decay, beta1, beta2, eps;
+    float bc1[2], sqrt_bc2[2]; int frozen1;
+    float ema_m;
+} SaisAdamW;
+int sais_opt_chunk_elems(void);
+int sais_grad_norms(const float* grad, const SaisOptChunk* chunks, int nchunks, const int* seg_first_chunk, int nseg,
+                    float* partial_ws, float* norms, void* stream);
+int sais_adamw_ema_step(const SaisAdamW* a, void* stream);
 
 #ifdef __cplusplus
 }

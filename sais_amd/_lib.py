@@ -44,6 +44,20 @@ class SaisGemmLn(ctypes.Structure):
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("rowscale", c_void_p), ("rowscale16", c_void_p)]
 
 
+class SaisOptChunk(ctypes.Structure):
+    _fields_ = [("off", c_long), ("len", c_int), ("seg", c_int)]
+
+
+class SaisAdamW(ctypes.Structure):
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("teacher", c_void_p), ("param16", c_void_p), ("teacher16", c_void_p),
+                ("chunks", c_void_p), ("nchunks", c_int), ("seg_flags", c_void_p), ("norms", c_void_p),
+                ("clip", c_float), ("lr", c_float), ("weight_decay", c_float), ("beta1", c_float), ("beta2", c_float),
+                ("eps", c_float), ("bc1", c_float * 2), ("sqrt_bc2", c_float * 2), ("frozen1", c_int), ("ema_m", c_float)]
+
+
+OPT_DECAY, OPT_CLASS1, OPT_NO_GRAD = 1, 2, 4
+
 EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
 EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
@@ -67,10 +81,10 @@ SIGNATURES = {
     "sais_layernorm_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p,
                            c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                            c_void_p, c_void_p, c_float, c_void_p, ctypes.c_uint, c_void_p],
-    "sais_vit_attn_fwd": [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
-    "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p,
+    "sais_vit_attn_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
+    "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
                           c_long, c_void_p],
-    "sais_patchify": [c_void_p, c_int, c_void_p, c_void_p],
+    "sais_patchify": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_vit_cls_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "sais_vit_embed_bwd": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "sais_sgd_step": [c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_void_p],
@@ -113,6 +127,24 @@ SIGNATURES = {
     "sais_importance_loss": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p],
     "sais_nce": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                  c_float, c_void_p],
+    # DINO pre-training objective
+    "sais_dino_row_lse": [c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "sais_dino_loss_partials": [c_int, c_int],
+    "sais_dino_loss": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                       c_float, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
+    "sais_dino_colsum": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p],
+    "sais_dino_center_ema": [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p],
+    "sais_gelu_fwd_f32": [c_void_p, c_void_p, c_long, c_void_p],
+    "sais_gelu_bwd_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
+    "sais_l2norm_fwd": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    "sais_l2norm_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],
+    "sais_weight_norm_fwd": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sais_weight_norm_bwd": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p],
+    "sais_pos_interp_fwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "sais_pos_interp_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "sais_opt_chunk_elems": [],
+    "sais_grad_norms": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "sais_adamw_ema_step": [ctypes.POINTER(SaisAdamW), c_void_p],
 }
 
 _lib = None

@@ -16,21 +16,29 @@
 #include "../../include/sais_hip.h"
 
 namespace {
-constexpr int NTOK = 197, HD = 64, NH = 6, DM = 384;
+constexpr int HD = 64, NH = 6, DM = 384;
 constexpr int ROWB = 160;                 // LDS row stride in bytes
-constexpr int NKT = 13;                   // 16-key tiles (208 >= 197)
-constexpr int NKS = 7;                    // 32-key k-steps (224)
-constexpr int TILE_ROWS = 224;
-constexpr int MAT_BYTES = TILE_ROWS * ROWB;   // 35840
 constexpr float LOG2E = 1.4426950408889634f;
 
+// Token-count geometry.  197 = 224 x 224 frames (the SAIS extraction / training path and DINO's global crops);
+// 37 = DINO's 96 x 96 local crops (main_dino.py:658-663 -> prepare_tokens, vision_transformer.py:196-207).
+template <int NTOK_>
+struct Geo {
+    static constexpr int NTOK = NTOK_;
+    static constexpr int NKT = (NTOK_ + 15) / 16;          // 16-key tiles            (197: 13, 37: 3)
+    static constexpr int NKS = (NKT + 1) / 2;              // 32-key k-steps          (197: 7,  37: 2)
+    static constexpr int TILE_ROWS = 32 * NKS;             //                         (197: 224, 37: 64)
+    static constexpr int MAT_BYTES = TILE_ROWS * ROWB;     //                         (197: 35840)
+};
+
 // stage rows [0,197) x 64 bf16 of a [M, ld] matrix (column offset applied by caller) into LDS, zero-fill pad rows
+template <class G>
 DEVINL void stage_matrix(char* lds, const bf16* src, long ld, int tid) {
     const int c = tid & 7, r0 = tid >> 3;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < G::NKS; ++i) {
         int r = r0 + 32 * i;
-        u32x4 v = r < NTOK ? *(const u32x4*)(src + (size_t)r * ld + c * 8) : u32x4{0, 0, 0, 0};
+        u32x4 v = r < G::NTOK ? *(const u32x4*)(src + (size_t)r * ld + c * 8) : u32x4{0, 0, 0, 0};
         *(u32x4*)(lds + r * ROWB + c * 16) = v;
     }
 }
@@ -46,10 +54,13 @@ DEVINL bf16x8 tr_frag(const char* lds, int s, int ct, int g, int li) {
 // flush to zero of results below 2^-126 is exactly what softmax wants)
 DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// 13 sixteen-row tiles over 4 waves: wave w takes tiles w, w+4, w+8; the 13th (5 real rows) rotates over the
-// waves with the (frame, head) index so no SIMD is systematically the last to finish
-DEVINL int tiles_of_wave(int wid, int extra) { return 3 + (wid == extra ? 1 : 0); }
-DEVINL int tile_id(int wid, int i) { return i < 3 ? wid + 4 * i : NKT - 1; }
+// NKT sixteen-row tiles over 4 waves: wave w takes tiles w, w+4, ... (NKT / 4 each); the NKT % 4 left-over tiles go to
+// the waves (w - extra) & 3 = 0, 1, ..: `extra` rotates with the (frame, head) index so no SIMD is systematically the last
+// to finish (197 tokens: the 13th tile, 5 real rows)
+template <class G> DEVINL int tiles_of_wave(int wid, int extra) { return G::NKT / 4 + ((((wid - extra) & 3) < G::NKT % 4) ? 1 : 0); }
+template <class G> DEVINL int tile_id(int wid, int i, int extra) {
+    return i < G::NKT / 4 ? wid + 4 * i : 4 * (G::NKT / 4) + ((wid - extra) & 3);
+}
 
 DEVINL float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
 DEVINL float group_sum(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
@@ -62,7 +73,9 @@ DEVINL bf16x8 pack_p(const f32x4& a, const f32x4& b) {
 }
 
 // S^T strip for one 16-query tile: s[t][r] = score(key 16 t + 4 g + r, query q0 + li), masked to -inf past 197
-DEVINL void score_strip(const char* sK, const bf16x8 (&fq)[2], int g, int li, f32x4 (&s)[NKT]) {
+template <class G>
+DEVINL void score_strip(const char* sK, const bf16x8 (&fq)[2], int g, int li, f32x4 (&s)[G::NKT]) {
+    constexpr int NKT = G::NKT;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         f32x4 a = {0, 0, 0, 0};
@@ -72,37 +85,41 @@ DEVINL void score_strip(const char* sK, const bf16x8 (&fq)[2], int g, int li, f3
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (192 + 4 * g + r >= NTOK) s[NKT - 1][r] = -INFINITY;
+        if (16 * (NKT - 1) + 4 * g + r >= G::NTOK) s[NKT - 1][r] = -INFINITY;
 }
 
+template <class G>
 DEVINL void load_q_frags(const bf16* base, long ld, int q, int g, bf16x8 (&f)[2]) {
-    const bf16* p = base + (size_t)(q < NTOK ? q : NTOK - 1) * ld + 8 * g;
+    const bf16* p = base + (size_t)(q < G::NTOK ? q : G::NTOK - 1) * ld + 8 * g;
     f[0] = *(const bf16x8*)p;
     f[1] = *(const bf16x8*)(p + 32);
 }
 
 // ------------------------------------------------------------------------------------------ forward
+template <class G>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq, bf16* out, long ldo, float* lse,
                                                        float* probs, float scale) {
+    constexpr int NTOK = G::NTOK, NKT = G::NKT, NKS = G::NKS, MAT_BYTES = G::MAT_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sK = smem;
     char* sV = smem + MAT_BYTES;
     const int h = blockIdx.x, f = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
-    stage_matrix(sK, base + DM, ldq, tid);
-    stage_matrix(sV, base + 2 * DM, ldq, tid);
+    stage_matrix<G>(sK, base + DM, ldq, tid);
+    stage_matrix<G>(sV, base + 2 * DM, ldq, tid);
     __syncthreads();
     const float c = scale * LOG2E;
-    const int nmine = tiles_of_wave(wid, (f * NH + h) & 3);
+    const int extra = (f * NH + h) & 3;
+    const int nmine = tiles_of_wave<G>(wid, extra);
     bf16x8 fq[2], fq_next[2];
-    load_q_frags(base, ldq, tile_id(wid, 0) * 16 + li, g, fq);
+    load_q_frags<G>(base, ldq, tile_id<G>(wid, 0, extra) * 16 + li, g, fq);
     for (int it = 0; it < nmine; ++it) {
-        const int qt = tile_id(wid, it);
+        const int qt = tile_id<G>(wid, it, extra);
         const int q = qt * 16 + li;
-        if (it + 1 < nmine) load_q_frags(base, ldq, tile_id(wid, it + 1) * 16 + li, g, fq_next);   // prefetch
+        if (it + 1 < nmine) load_q_frags<G>(base, ldq, tile_id<G>(wid, it + 1, extra) * 16 + li, g, fq_next);   // prefetch
         f32x4 s[NKT];
-        score_strip(sK, fq, g, li, s);
+        score_strip<G>(sK, fq, g, li, s);
         fq[0] = fq_next[0]; fq[1] = fq_next[1];
         float m = -INFINITY;
 #pragma unroll
@@ -163,12 +180,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
 // delta_q = sum_d dO O is computed while staging.  Five MFMA products per (query, key) tile instead of seven, one
 // exponential instead of two, every operand staged once (the two-kernel version re-staged K, V, Q, dO: 470 vs 348 MB).
 constexpr int SROW = 96;                                   // bytes per key row of the dS image (32 queries bf16 + pad)
-constexpr int S_BYTES = TILE_ROWS * SROW;                  // 21504
-constexpr int BWD_LDS = 3 * MAT_BYTES + 2 * TILE_ROWS * 4 + 2 * S_BYTES;     // 152320
+template <class G> constexpr int bwd_lds() {               // 197 tokens: 152320
+    return 3 * G::MAT_BYTES + 2 * G::TILE_ROWS * 4 + 2 * G::TILE_ROWS * SROW;
+}
 
+template <class G>
 __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
                                                         const bf16* out, long ldout, const float* lse, int nprob,
                                                         bf16* dqkv, long lddq, float scale) {
+    constexpr int NTOK = G::NTOK, NKT = G::NKT, NKS = G::NKS, TILE_ROWS = G::TILE_ROWS, MAT_BYTES = G::MAT_BYTES;
+    constexpr int S_BYTES = TILE_ROWS * SROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sQ = smem;
     char* const sO = smem + MAT_BYTES;
@@ -217,8 +238,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
         const int key = kt * 16 + li;
         bf16x8 fk[2], fv[2];
         if (kt < NKT) {
-            load_q_frags(base + DM, ldq, key, g, fk);
-            load_q_frags(base + 2 * DM, ldq, key, g, fv);
+            load_q_frags<G>(base + DM, ldq, key, g, fk);
+            load_q_frags<G>(base + 2 * DM, ldq, key, g, fv);
         }
         f32x4 dk[4], dv[4];
 #pragma unroll
@@ -257,14 +278,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
                     dv[dt] = mfma16(tr_frag(sO, qs, dt, g, li), pf, dv[dt]);            // dV^T[d][key]
                     dk[dt] = mfma16(tr_frag(sQ, qs, dt, g, li), dsf, dk[dt]);           // dK^T[d][key]
                 }
-            } else {                                        // rows 208..223 of the dS image belong to no key tile
+            } else if constexpr (NKT & 1) {                 // the last 16 rows of the dS image belong to no key tile
                 if (qs < 2) {
                     for (int i = lane + 64 * (wid - NKT); i < 16 * SROW / 8; i += 64 * (16 - NKT))
                         *(u32x2*)(sS + qs * S_BYTES + NKT * 16 * SROW + i * 8) = u32x2{0, 0};
                 }
             }
             __syncthreads();                                // dS of this query step is complete
-            if (wid >= 8) {                                 // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]
+            if (wid >= 8) {                                 // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  (uniform branch)
                 const int w = wid - 8, qt = w >> 2, dt = w & 3;
                 f32x4 o = {0, 0, 0, 0};
 #pragma unroll
@@ -297,11 +318,11 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
     }
 }
 
-constexpr int FWD_LDS = 2 * MAT_BYTES;
+template <class G> constexpr int fwd_lds() { return 2 * G::MAT_BYTES; }
 
 // raise the dynamic-LDS limit of a kernel once per process and device (not per call: keeps the launch
 // path free of runtime-API calls so it can be captured into a hipGraph); the limit only ever grows.
-template <typename K>
+template <class Tag, typename K>          // Tag: one `granted` table per kernel INSTANCE (K alone is only the signature)
 int set_lds(K kernel, int bytes) {
     static thread_local int granted[16] = {0};
     int dev = 0;
@@ -312,30 +333,47 @@ int set_lds(K kernel, int bytes) {
     granted[dev] = bytes;
     return SAIS_OK;
 }
-}  // namespace
 
-extern "C" int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, float* lse,
-                                 float* probs, void* stream) {
-    SAIS_ENTER();
-    if (!qkv || !out || frames <= 0 || (ldqkv & 7) || (ldo & 3)) return SAIS_ERR_ARG;
-    if (set_lds(attn_fwd_kernel, FWD_LDS)) return SAIS_ERR_LAUNCH;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(NH, frames), dim3(256), FWD_LDS, (hipStream_t)stream, (const bf16*)qkv,
-                       ldqkv, (bf16*)out, ldo, lse, probs, 0.125f);
+template <class G>
+int launch_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, float* lse, float* probs, void* stream) {
+    if (set_lds<G>(attn_fwd_kernel<G>, fwd_lds<G>())) return SAIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(attn_fwd_kernel<G>, dim3(NH, frames), dim3(256), fwd_lds<G>(), (hipStream_t)stream,
+                       (const bf16*)qkv, ldqkv, (bf16*)out, ldo, lse, probs, 0.125f);
     return sais_check_launch();
 }
 
+template <class G>
+int launch_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout, const float* lse,
+               int frames, void* dqkv, long lddqkv, void* stream) {
+    if (set_lds<G>(attn_bwd_kernel<G>, bwd_lds<G>())) return SAIS_ERR_LAUNCH;
+    const int nprob = frames * NH;
+    // short sequences leave most of the LDS free: several workgroups per CU
+    const int cap = 256 * (160 * 1024 / bwd_lds<G>() > 2 ? 2 : 1);
+    hipLaunchKernelGGL(attn_bwd_kernel<G>, dim3(nprob < cap ? nprob : cap), dim3(1024), bwd_lds<G>(), (hipStream_t)stream,
+                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, nprob,
+                       (bf16*)dqkv, lddqkv, 0.125f);
+    return sais_check_launch();
+}
+}  // namespace
+
+extern "C" int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, int ntok, void* out, long ldo, float* lse,
+                                 float* probs, void* stream) {
+    SAIS_ENTER();
+    if (!qkv || !out || frames <= 0 || (ldqkv & 7) || (ldo & 3)) return SAIS_ERR_ARG;
+    if (ntok == 197) return launch_fwd<Geo<197>>(qkv, ldqkv, frames, out, ldo, lse, probs, stream);
+    if (ntok == 37) return launch_fwd<Geo<37>>(qkv, ldqkv, frames, out, ldo, lse, probs, stream);
+    return SAIS_ERR_ARG;
+}
+
 extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout,
-                                 const float* lse, float* delta_ws, int frames, void* dqkv, long lddqkv,
+                                 const float* lse, float* delta_ws, int frames, int ntok, void* dqkv, long lddqkv,
                                  void* stream) {
     SAIS_ENTER();
     (void)delta_ws;      // the single-pass kernel computes delta = rowsum(dO * O) while staging; kept in the ABI
     if (!qkv || !dout || !out || !lse || !dqkv || frames <= 0 || (ldqkv & 7) || (lddo & 7) ||
         (ldout & 7) || (lddqkv & 3))
         return SAIS_ERR_ARG;
-    if (set_lds(attn_bwd_kernel, BWD_LDS)) return SAIS_ERR_LAUNCH;
-    const int nprob = frames * NH;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(nprob < 256 ? nprob : 256), dim3(1024), BWD_LDS, (hipStream_t)stream,
-                       (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, nprob,
-                       (bf16*)dqkv, lddqkv, 0.125f);
-    return sais_check_launch();
+    if (ntok == 197) return launch_bwd<Geo<197>>(qkv, ldqkv, dout, lddo, out, ldout, lse, frames, dqkv, lddqkv, stream);
+    if (ntok == 37) return launch_bwd<Geo<37>>(qkv, ldqkv, dout, lddo, out, ldout, lse, frames, dqkv, lddqkv, stream);
+    return SAIS_ERR_ARG;
 }

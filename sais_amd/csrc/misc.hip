@@ -8,18 +8,20 @@ namespace {
 // PatchEmbed (vision_transformer.py:116-131): Conv2d(3->384, k=16, s=16) over NON-overlapping patches
 // is a GEMM on the [F*196, 768] patch matrix; column order = (c, py, px) = conv weight flatten.
 // One thread = one 16-pixel patch row segment (64-B f32 read, 32-B bf16 write).
-__global__ __launch_bounds__(256) void patchify_kernel(const float* img, bf16* out, int frames) {
-    const long total = (long)frames * 196 * 48;          // 48 = 3 channels * 16 rows
+// side = frame height = width in pixels (224: 14 x 14 patches; 96: DINO's local crops, 6 x 6).
+__global__ __launch_bounds__(256) void patchify_kernel(const float* img, bf16* out, int frames, int side) {
+    const int G = side >> 4;
+    const long total = (long)frames * G * G * 48;        // 48 = 3 channels * 16 rows
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         // consecutive threads walk px-segments of one image row: idx -> (f, c, y, gx)
         long t = i;
-        const int gx = t % 14; t /= 14;
-        const int y = t % 224; t /= 224;
+        const int gx = t % G; t /= G;
+        const int y = t % side; t /= side;
         const int c = t % 3;
         const int f = t / 3;
-        const float* src = img + (((size_t)f * 3 + c) * 224 + y) * 224 + gx * 16;
+        const float* src = img + (((size_t)f * 3 + c) * side + y) * side + gx * 16;
         const int gy = y >> 4, py = y & 15;
-        bf16* dst = out + ((size_t)f * 196 + gy * 14 + gx) * 768 + c * 256 + py * 16;
+        bf16* dst = out + ((size_t)f * G * G + gy * G + gx) * 768 + c * 256 + py * 16;
         bf16x8 lo, hi;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -234,11 +236,11 @@ static thread_local int g_last_hip_error = 0;
 extern "C" void sais_set_last_error(int e) { g_last_hip_error = e; }
 extern "C" const char* sais_last_error(void) { return hipGetErrorString((hipError_t)g_last_hip_error); }
 
-extern "C" int sais_patchify(const float* frames_f32, int frames, void* patches_bf16, void* stream) {
+extern "C" int sais_patchify(const float* frames_f32, int frames, int side, void* patches_bf16, void* stream) {
     SAIS_ENTER();
-    if (!frames_f32 || !patches_bf16 || frames <= 0) return SAIS_ERR_ARG;
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)frames * 196 * 48)), dim3(256), 0, (hipStream_t)stream,
-                       frames_f32, (bf16*)patches_bf16, frames);
+    if (!frames_f32 || !patches_bf16 || frames <= 0 || side < 16 || (side & 15)) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)frames * (side >> 4) * (side >> 4) * 48)), dim3(256), 0,
+                       (hipStream_t)stream, frames_f32, (bf16*)patches_bf16, frames, side);
     return sais_check_launch();
 }
 

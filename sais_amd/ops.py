@@ -237,32 +237,33 @@ def layernorm_bwd(x, ldx, mean, rstd, gamma, rows, dy16=None, dy32=None, dres=No
            0 if drop is None else int(drop[2]), _stream())
 
 
-def vit_attn_fwd(qkv, frames, out, lse=None, probs=None):
+def vit_attn_fwd(qkv, frames, out, lse=None, probs=None, ntok=197):
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out")
-    _timed("vit_attn_fwd", 4.0 * frames * 6 * 197 * 197 * 64, 2 * frames * 197 * 384 * 4,
-           lambda: L.call("sais_vit_attn_fwd", _p(qkv), qkv.stride(0), frames, _p(out), out.stride(0), _p(lse),
+    _timed("vit_attn_fwd", 4.0 * frames * 6 * ntok * ntok * 64, 2 * frames * ntok * 384 * 4,
+           lambda: L.call("sais_vit_attn_fwd", _p(qkv), qkv.stride(0), frames, ntok, _p(out), out.stride(0), _p(lse),
                           _p(probs), _stream()))
 
 
-def vit_attn_bwd(qkv, dout, out, lse, delta_ws, frames, dqkv):
-    """out = the forward attention output (bf16 [frames*197, 384]) saved by vit_attn_fwd."""
+def vit_attn_bwd(qkv, dout, out, lse, delta_ws, frames, dqkv, ntok=197):
+    """out = the forward attention output (bf16 [frames*ntok, 384]) saved by vit_attn_fwd."""
     _chk(out, BF16, "out")
-    _timed("vit_attn_bwd", 10.0 * frames * 6 * 197 * 197 * 64, 2 * frames * 197 * 384 * 9,
+    _timed("vit_attn_bwd", 10.0 * frames * 6 * ntok * ntok * 64, 2 * frames * ntok * 384 * 9,
            lambda: L.call("sais_vit_attn_bwd", _p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(out), out.stride(0),
-                          _p(lse), _p(delta_ws), frames, _p(dqkv), dqkv.stride(0), _stream()))
+                          _p(lse), _p(delta_ws), frames, ntok, _p(dqkv), dqkv.stride(0), _stream()))
 
 
 def patchify(frames_f32, patches):
+    """frames f32 [F,3,side,side] -> bf16 [F*(side/16)^2, 768]."""
     _chk(frames_f32, F32, "frames")
-    L.call("sais_patchify", _p(frames_f32), frames_f32.shape[0], _p(patches), _stream())
+    L.call("sais_patchify", _p(frames_f32), frames_f32.shape[0], frames_f32.shape[-1], _p(patches), _stream())
 
 
-def vit_cls_rows(cls, pos0, tokens, frames):
-    L.call("sais_vit_cls_rows", _p(cls), _p(pos0), _p(tokens), 197 * 384, frames, 384, _stream())
+def vit_cls_rows(cls, pos0, tokens, frames, ntok=197):
+    L.call("sais_vit_cls_rows", _p(cls), _p(pos0), _p(tokens), ntok * 384, frames, 384, _stream())
 
 
-def vit_embed_bwd(dtokens, frames, dcls, dpos, dpatch):
-    L.call("sais_vit_embed_bwd", _p(dtokens), frames, 197, 384, _p(dcls), _p(dpos), _p(dpatch), _stream())
+def vit_embed_bwd(dtokens, frames, dcls, dpos, dpatch, ntok=197):
+    L.call("sais_vit_embed_bwd", _p(dtokens), frames, ntok, 384, _p(dcls), _p(dpos), _p(dpatch), _stream())
 
 
 def sgd_step(param, grad, shadow, lr, grad_scale=1.0):
@@ -410,3 +411,84 @@ def nce(emb, protos, label_col, sim=None, probs=None, loss=None, demb=None, dpro
     B, C = emb.shape[0], protos.shape[0]
     L.call("sais_nce", _p(emb), _p(protos), _p(label_col), B, C, _p(sim), _p(probs), _p(loss), _p(demb), _p(dprotos),
            loss_scale, _stream())
+
+
+# --------------------------------------------------------------------------- DINO pre-training objective (dino.hip)
+def dino_row_lse(x, scale, center=None, out=None):
+    """lse[r] = log sum_k exp((x[r, k] - center[k]) * scale); x f32 [rows, n]."""
+    _chk(x, F32, "x"); _chk(center, F32, "center")
+    out = torch.empty(x.shape[0], dtype=F32, device=x.device) if out is None else out
+    L.call("sais_dino_row_lse", _p(x), x.stride(0), x.shape[0], x.shape[1], float(scale), _p(center), _p(out), _stream())
+    return out
+
+
+def dino_loss(student, teacher, center, s_lse, t_lse, B, ncrops, student_temp, teacher_temp, dlogits, loss, partials=None):
+    _chk(student, F32, "student"); _chk(teacher, F32, "teacher"); _chk(center, F32, "center"); _chk(dlogits, F32, "dlogits")
+    n = student.shape[1]
+    if tuple(student.shape) != (ncrops * B, n) or tuple(teacher.shape) != (2 * B, n) or dlogits.shape != student.shape:
+        raise L.SaisHipError(f"dino_loss: student {tuple(student.shape)} / teacher {tuple(teacher.shape)} do not match "
+                             f"B={B}, ncrops={ncrops}")
+    if partials is None:
+        partials = torch.empty(L.load().sais_dino_loss_partials(B, n), dtype=F32, device=student.device)
+    L.call("sais_dino_loss", _p(student), student.stride(0), _p(teacher), teacher.stride(0), _p(center), _p(s_lse),
+           _p(t_lse), B, ncrops, n, float(student_temp), float(teacher_temp), _p(dlogits), dlogits.stride(0), _p(partials),
+           _p(loss), _stream())
+
+
+def dino_colsum(x, out):
+    _chk(x, F32, "x"); _chk(out, F32, "out")
+    L.call("sais_dino_colsum", _p(x), x.stride(0), x.shape[0], x.shape[1], _p(out), _stream())
+
+
+def dino_center_ema(center, colsum, momentum, inv_count):
+    _chk(center, F32, "center"); _chk(colsum, F32, "colsum")
+    L.call("sais_dino_center_ema", _p(center), _p(colsum), center.numel(), float(momentum), float(inv_count), _stream())
+
+
+def gelu_fwd_f32(u, h):
+    _chk(u, F32, "u"); _chk(h, F32, "h")
+    L.call("sais_gelu_fwd_f32", _p(u), _p(h), u.numel(), _stream())
+
+
+def gelu_bwd_f32(dh, u, du):
+    _chk(dh, F32, "dh"); _chk(u, F32, "u"); _chk(du, F32, "du")
+    L.call("sais_gelu_bwd_f32", _p(dh), _p(u), _p(du), u.numel(), _stream())
+
+
+def l2norm_fwd(z, out, inv, eps=1e-12):
+    _chk(z, F32, "z"); _chk(out, F32, "out")
+    L.call("sais_l2norm_fwd", _p(z), z.shape[0], z.shape[1], eps, _p(out), _p(inv), _stream())
+
+
+def l2norm_bwd(dout, out, inv, dz, eps=1e-12):
+    _chk(dout, F32, "dout"); _chk(out, F32, "out"); _chk(dz, F32, "dz")
+    L.call("sais_l2norm_bwd", _p(dout), _p(out), _p(inv), out.shape[0], out.shape[1], eps, _p(dz), _stream())
+
+
+def weight_norm_fwd(v, g, w, inv):
+    _chk(v, F32, "v"); _chk(g, F32, "g"); _chk(w, F32, "w")
+    L.call("sais_weight_norm_fwd", _p(v), _p(g), v.shape[0], v.shape[1], _p(w), _p(inv), _stream())
+
+
+def weight_norm_bwd(dw, v, g, inv, dv, dg=None):
+    _chk(dw, F32, "dw"); _chk(v, F32, "v"); _chk(dv, F32, "dv")
+    L.call("sais_weight_norm_bwd", _p(dw), _p(v), _p(g), _p(inv), v.shape[0], v.shape[1], _p(dv), _p(dg), _stream())
+
+
+def pos_interp_fwd(Wm, pos, out):
+    """out [1 + nout, dim] from pos [1 + nin, dim] through the fixed map Wm f32 [nout, nin]."""
+    _chk(Wm, F32, "Wm"); _chk(pos, F32, "pos"); _chk(out, F32, "out")
+    L.call("sais_pos_interp_fwd", _p(Wm), Wm.shape[0], Wm.shape[1], _p(pos), pos.shape[-1], _p(out), _stream())
+
+
+def pos_interp_bwd(Wm, dout, dpos):
+    _chk(Wm, F32, "Wm"); _chk(dout, F32, "dout"); _chk(dpos, F32, "dpos")
+    L.call("sais_pos_interp_bwd", _p(Wm), Wm.shape[0], Wm.shape[1], _p(dout), dout.shape[-1], _p(dpos), _stream())
+
+
+def grad_norms(grad, chunks, nchunks, seg_first, nseg, partial, norms):
+    L.call("sais_grad_norms", _p(grad), _p(chunks), nchunks, _p(seg_first), nseg, _p(partial), _p(norms), _stream())
+
+
+def adamw_ema_step(desc):
+    L.call("sais_adamw_ema_step", ctypes.byref(desc), _stream())

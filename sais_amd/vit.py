@@ -11,12 +11,16 @@ Backward is hand-written too (dX GEMMs on pre-transposed bf16 weight shadows, dW
 transposed LDS reads, recompute-from-LSE attention backward); parameter gradients are accumulated
 by the kernels directly into the flat gradient buffer that p.grad views.
 
-Deliberate differences from the reference (documented in DESIGN.md): only the ViT-S/16 @224
-geometry is supported.  DropPath (stochastic depth, vision_transformer.py:27-46: train() only, per-sample keep with
+Deliberate differences from the reference (documented in DESIGN.md): only the ViT-S/16 geometry is supported, at
+224 x 224 (197 tokens: every SAIS path and DINO's global crops) and 96 x 96 (37 tokens: DINO's local crops,
+main_dino.py:658-663, with interpolate_pos_encoding :174-194 as a fixed bicubic map applied by a HIP kernel).  DropPath (stochastic depth, vision_transformer.py:27-46: train() only, per-sample keep with
 rates linspace(0, drop_path_rate, depth); SAIS itself only ever runs the ViT in eval(), extract_representations.py:
 279,340,362) is applied in the epilogues of the residual GEMMs as a per-row scale; the keep draws come from Philox
 (`drop_path_seed`, this library's stream, not torch's): `last_droppath_scales` holds what a forward used.
 """
+import math
+
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -25,6 +29,38 @@ from . import ops
 from .flat import FlatParams
 
 D, NTOK, HEADS, HID, PATCH_K = 384, 197, 6, 1536, 768
+SIDES = {224: 197, 96: 37}          # supported frame sizes -> tokens (the attention kernels are instantiated per count)
+
+
+def _cubic_taps(t, A=-0.75):
+    """The four Keys cubic-convolution weights (A = -0.75, what F.interpolate(mode='bicubic') uses) of the taps at
+    floor(x) - 1 .. floor(x) + 2 for fractional offsets t = x - floor(x); t: [n] -> [n, 4]."""
+    def near(x):           # |x| <= 1
+        return ((A + 2) * x - (A + 3)) * x * x + 1
+    def far(x):            # 1 < |x| < 2
+        return ((A * x - 5 * A) * x + 8 * A) * x - 4 * A
+    return np.stack([far(t + 1), near(t), near(1 - t), far(2 - t)], axis=1)
+
+
+def pos_interp_matrix(side_in, w, h, patch=16):
+    """interpolate_pos_encoding (vision_transformer.py:174-194) as a matrix: [w0 * h0, side_in^2] with
+    patch_pos(w, h) = M @ patch_pos(224).  Per axis: F.interpolate(scale_factor=(n0 + 0.1) / side_in, mode='bicubic',
+    align_corners=False) samples at (dst + 0.5) / scale - 0.5 with border-clamped taps; the 2-D map is their Kronecker
+    product (first axis = the first index of the 14 x 14 grid)."""
+    def axis(n0):
+        scale = (n0 + 0.1) / side_in
+        n_out = int(math.floor(side_in * scale))
+        if n_out != n0:
+            raise ValueError(f"interpolate_pos_encoding: {n_out} != {n0} (vision_transformer.py:191)")
+        x = (np.arange(n_out) + 0.5) / scale - 0.5
+        x0 = np.floor(x)
+        taps = _cubic_taps(x - x0)
+        M = np.zeros((n_out, side_in))
+        for k in range(4):
+            idx = np.clip(x0.astype(np.int64) + k - 1, 0, side_in - 1)
+            np.add.at(M, (np.arange(n_out), idx), taps[:, k])
+        return M
+    return np.kron(axis(w // patch), axis(h // patch))
 
 
 class _Attention(nn.Module):
@@ -112,6 +148,7 @@ class VisionTransformer(nn.Module):
         self.flat = None
         self._sig = None
         self._anchor = None
+        self._interp = {}                            # frame side -> device f32 [ntok - 1, 196] bicubic map
         self.grad_ready_hook = None                  # callable(lo, hi): flat-grad slice [lo,hi) is final
         self._t_names = []
         for i in range(depth):
@@ -169,26 +206,41 @@ class VisionTransformer(nn.Module):
     def _check_input(self, x):
         if not x.is_cuda:
             raise L.SaisHipError("VisionTransformer.forward needs a device tensor: the HIP path has no CPU fallback")
-        if x.dim() != 4 or tuple(x.shape[1:]) != (3, 224, 224):
-            raise ValueError(f"expected [F,3,224,224], got {tuple(x.shape)}")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] not in SIDES:
+            raise ValueError(f"expected [F,3,S,S] with S in {sorted(SIDES)}, got {tuple(x.shape)}")
         return x.contiguous().float()
+
+    def _pos_table(self, side, dev):
+        """(positional table f32 [ntok, 384], interpolation map or None) for frames of this side."""
+        pos = self.flat.w32("pos_embed").view(NTOK, D)
+        if side == 224:
+            return pos, None
+        Wm = self._interp.get(side)
+        if Wm is None or Wm.device != dev:
+            Wm = torch.from_numpy(pos_interp_matrix(14, side, side).astype(np.float32)).to(dev)
+            self._interp[side] = Wm
+        out = torch.empty(SIDES[side], D, dtype=torch.float32, device=dev)
+        ops.pos_interp_fwd(Wm, pos, out)
+        return out, Wm
 
     # ------------------------------------------------------------------ forward kernels
     def _forward_kernels(self, img, save, want_last_attn=False):
         f = self.flat
         dev = img.device
-        Fr = img.shape[0]
-        M = Fr * NTOK
+        Fr, side = img.shape[0], img.shape[-1]
+        ntok = SIDES[side]
+        M = Fr * ntok
         e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        patches = e16(Fr * 196, PATCH_K)
+        patches = e16(Fr * (ntok - 1), PATCH_K)
         ops.patchify(img, patches)
-        x = e32(Fr, NTOK, D)
+        x = e32(Fr, ntok, D)
+        pos, interp = self._pos_table(side, dev)
         ops.gemm_nt(patches, f.w("patch_embed.proj.weight").view(D, PATCH_K), L.EPI_PATCH_F32, x,
-                    bias=f.w32("patch_embed.proj.bias"), aux=f.w32("pos_embed").view(NTOK, D), grp=(196, 197, 1))
-        ops.vit_cls_rows(f.w32("cls_token"), f.w32("pos_embed"), x, Fr)
+                    bias=f.w32("patch_embed.proj.bias"), aux=pos, grp=(ntok - 1, ntok, 1))
+        ops.vit_cls_rows(f.w32("cls_token"), pos, x, Fr, ntok)
         x = x.view(M, D)
-        saved = {"patches": patches, "blocks": [], "Fr": Fr} if save else None
+        saved = {"patches": patches, "blocks": [], "Fr": Fr, "ntok": ntok, "interp": interp} if save else None
         # Large M (training step, big extraction batches): the N = 384 GEMMs run on the row-owning kernel with the
         # FOLLOWING LayerNorm in their epilogue (sais_gemm_ln_fwd): proj -> norm2, fc2 -> the next block's norm1.
         # Only block 0's norm1 and the final norm remain stand-alone launches.
@@ -202,7 +254,7 @@ class VisionTransformer(nn.Module):
                 rates = torch.linspace(0, self.drop_path_rate, self.depth).repeat_interleave(2)      # :150
                 self._dp_rates = rates.to(dev, torch.float32)
             ops.rng_advance(self._rng)
-            dp = ops.droppath_scales(self._dp_rates, Fr, NTOK, self._rng)
+            dp = ops.droppath_scales(self._dp_rates, Fr, ntok, self._rng)
             self.last_droppath_scales = dp
         if saved is not None:
             saved["dp"] = dp
@@ -220,9 +272,9 @@ class VisionTransformer(nn.Module):
                 ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
                                   rstd=rstd1)
             ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
-            lse = e32(Fr, HEADS, NTOK) if save else None
-            probs = e32(Fr, HEADS, NTOK, NTOK) if last_attn else None
-            ops.vit_attn_fwd(qkv, Fr, ao, lse, probs)
+            lse = e32(Fr, HEADS, ntok) if save else None
+            probs = e32(Fr, HEADS, ntok, ntok) if last_attn else None
+            ops.vit_attn_fwd(qkv, Fr, ao, lse, probs, ntok=ntok)
             if last_attn:
                 return probs, None
             x_mid = e32(M, D) if save else x
@@ -261,7 +313,7 @@ class VisionTransformer(nn.Module):
         reps = e32(Fr, D)
         meanN = e32(Fr) if save else None
         rstdN = e32(Fr) if save else None
-        ops.layernorm_fwd(x, Fr, NTOK * D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN,
+        ops.layernorm_fwd(x, Fr, ntok * D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN,
                           rstd=rstdN)
         if save:
             saved.update(x_final=x, meanN=meanN, rstdN=rstdN)
@@ -272,13 +324,13 @@ class VisionTransformer(nn.Module):
         f = self.flat
         f.attach_grads()
         dev = dreps.device
-        Fr = saved["Fr"]
-        M = Fr * NTOK
+        Fr, ntok = saved["Fr"], saved["ntok"]
+        M = Fr * ntok
         e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         dxa, dxb = e16(M, D), e16(M, D)            # bf16 copies of the residual-stream gradient (block input / mid)
-        ops.layernorm_bwd(saved["x_final"], NTOK * D, saved["meanN"], saved["rstdN"], f.w32("norm.weight"), Fr,
-                          dy32=dreps, dx32=dx, lddx32=NTOK * D, dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
+        ops.layernorm_bwd(saved["x_final"], ntok * D, saved["meanN"], saved["rstdN"], f.w32("norm.weight"), Fr,
+                          dy32=dreps, dx32=dx, lddx32=ntok * D, dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
         dp = saved.get("dp")
         # with DropPath the gradient that enters a branch is s dx (the residual stream keeps dx): the bf16 copies carry the
         # NEXT branch's scale — dxa feeds an MLP branch (2i + 1), dxb an attention branch (2i)
@@ -288,7 +340,7 @@ class VisionTransformer(nn.Module):
             ops.cast_bf16_rows(dx, dp[2 * (self.depth - 1) + 1], dxa)
         fused = M >= ops.ROW_GEMM_MIN_M
         dxn, dao, du, dqkv = (None if fused else e16(M, D)), e16(M, D), e16(M, HID), e16(M, 3 * D)
-        delta = torch.empty(Fr, HEADS, NTOK, dtype=torch.float32, device=dev)
+        delta = torch.empty(Fr, HEADS, ntok, dtype=torch.float32, device=dev)
         if self.grad_ready_hook:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
         for i in reversed(range(self.depth)):
@@ -309,7 +361,7 @@ class VisionTransformer(nn.Module):
                                   rowscale16=rs_attn)
             # attention branch
             ops.gemm_nt(dxb, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
-            ops.vit_attn_bwd(s["qkv"], dao, s["ao"], s["lse"], delta, Fr, dqkv)
+            ops.vit_attn_bwd(s["qkv"], dao, s["ao"], s["lse"], delta, Fr, dqkv, ntok=ntok)
             # all four weight / bias gradients of the block in one launch.  (A side stream for this launch was measured
             # in round 1: 20.4 vs 19.6 ms/step — both kernels fill the chip — and removed.)
             ops.gemm_tn_grouped([
@@ -329,8 +381,13 @@ class VisionTransformer(nn.Module):
             saved["blocks"][i] = None
             if self.grad_ready_hook:                  # the block's gradient slice is final: DP all-reduce may start
                 self.grad_ready_hook(*self.block_grad_range(i))
-        dpatch = e16(Fr * 196, D)
-        ops.vit_embed_bwd(dx, Fr, f.g("cls_token"), f.g("pos_embed"), dpatch)
+        dpatch = e16(Fr * (ntok - 1), D)
+        if saved["interp"] is None:
+            ops.vit_embed_bwd(dx, Fr, f.g("cls_token"), f.g("pos_embed"), dpatch)
+        else:                                       # through the transpose of the bicubic map (autograd of :174-194)
+            dpos = torch.zeros(ntok, D, dtype=torch.float32, device=dev)
+            ops.vit_embed_bwd(dx, Fr, f.g("cls_token"), dpos, dpatch, ntok=ntok)
+            ops.pos_interp_bwd(saved["interp"], dpos, f.g("pos_embed").view(NTOK, D))
         ops.gemm_tn(dpatch, saved["patches"], f.g("patch_embed.proj.weight").view(D, PATCH_K),
                     f.g("patch_embed.proj.bias"))
         if self.grad_ready_hook:

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib.sais_abi_version.restype = ctypes.c_int
-    assert lib.sais_abi_version() == 6
+    assert lib.sais_abi_version() == 7
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -37,8 +37,19 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert [lib.sais_tgemm_nsplit(264, 384, k) for k in (384, 1152, 2048)] == [3, 6, 8]
     assert lib.sais_tgemm_nsplit(264, 2048, 384) == 1 and lib.sais_tgemm_nsplit(0, 384, 384) == 1
     assert lib.sais_layernorm_fwd(None, 384, 4, 384, None, None, 1e-6, None, 384, None, 384, None, None, None) == -1
-    assert lib.sais_vit_attn_fwd(None, 1152, 1, None, 384, None, None, None) == -1
+    assert lib.sais_vit_attn_fwd(None, 1152, 1, 197, None, 384, None, None, None) == -1
     assert lib.sais_temporal_attn_fwd(None, None, 1, 1000, None, None, 0.0, None, 0, None) == -1
     assert lib.sais_dropout_f32(None, None, None, 10, 0.1, None, 0, None) == -1 and lib.sais_rng_advance(None, None) == -1
     assert lib.sais_preprocess_plan_create(0, 10, 0.8, 0.8, None, None, None) == -1
     assert lib.sais_preprocess_run(None, None, 1, None, None) == -1
+    # DINO objective entries
+    assert lib.sais_vit_attn_fwd(ctypes.c_void_p(16), 1152, 1, 50, ctypes.c_void_p(16), 384, None, None, None) == -1   # ntok
+    assert lib.sais_patchify(ctypes.c_void_p(16), 1, 100, ctypes.c_void_p(16), None) == -1                            # side % 16
+    assert lib.sais_dino_row_lse(None, 8, 1, 8, 1.0, None, None, None) == -1
+    assert lib.sais_dino_loss(None, 8, None, 8, None, None, None, 1, 2, 8, 0.1, 0.04, None, 8, None, None, None) == -1
+    assert lib.sais_dino_loss_partials(64, 65536) == 64 * 64 and lib.sais_dino_loss_partials(2, 1000) == 2
+    assert lib.sais_opt_chunk_elems() == 8192
+    assert lib.sais_adamw_ema_step(None, None) == -1 and lib.sais_adamw_ema_step(ctypes.byref(_lib.SaisAdamW()), None) == -1
+    assert lib.sais_grad_norms(None, None, 0, None, 0, None, None, None) == -1
+    assert lib.sais_weight_norm_fwd(None, None, 1, 256, None, None, None) == -1
+    assert lib.sais_pos_interp_fwd(None, 36, 196, None, 384, None, None) == -1

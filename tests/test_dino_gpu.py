@@ -1,0 +1,413 @@
+"""DINO pre-training objective on a real MI355X (sais_amd/dino.py + csrc/dino.hip through the C ABI) against
+  * the vectors the reference itself produced (tests/golden/dino_step.npz, dino_loss.npz: main_dino.DINOLoss, the body
+    of train_one_epoch with torch AdamW, DINOHead, MultiCropWrapper with 96 x 96 crops), and
+  * the pinned oracle (oracle/dino_oracle.py, fp64) on seeded inputs at sizes the goldens do not cover.
+Tolerances: fp32 streaming kernels ~1e-6 relative; anything that crosses the ViT's bf16 MFMA operands keeps the bars
+of tests/test_model_gpu.py (features 2 % of max |ref|, gradients 2 % relative L2 per tensor)."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+from parity import parity_log  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from sais_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def gstep():
+    return np.load(os.path.join(HERE, "golden", "dino_step.npz"))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+# ------------------------------------------------------------------ DINOLoss kernels
+@pytest.mark.parametrize("epoch", [0, 5])
+def test_dino_loss_65536_vs_reference_golden(ops, epoch):
+    """The reference's DINOLoss at its default out_dim = 65536, ncrops = 10, non-zero centre."""
+    from oracle import dino_oracle as do
+    g = np.load(os.path.join(HERE, "golden", "dino_loss.npz"))
+    n, B, ncrops = 65536, 2, 10
+    gen = synth._gen(410)
+    s = (torch.randn(ncrops * B, n, generator=gen) * 0.3).to(DEV)
+    t = (torch.randn(2 * B, n, generator=gen) * 0.3).to(DEV)
+    c = (torch.randn(1, n, generator=gen) * 0.05).to(DEV)
+    temp = float(do.teacher_temp_schedule(0.04, 0.07, 3, 10)[epoch])
+    t_lse = ops.dino_row_lse(t, 1.0 / temp, c.view(-1))
+    s_lse = ops.dino_row_lse(s, 10.0)
+    ref_s = torch.logsumexp(s.double() * 10.0, -1)
+    ref_t = torch.logsumexp((t.double() - c.double()) / temp, -1)
+    assert (s_lse.double() - ref_s).abs().max().item() < 2e-5 and (t_lse.double() - ref_t).abs().max().item() < 2e-5
+    dl = torch.full_like(s, float("nan"))
+    loss = torch.empty((), device=DEV)
+    ops.dino_loss(s, t, c.view(-1), s_lse, t_lse, B, ncrops, 0.1, temp, dl, loss)
+    ref = float(g[f"e{epoch}/loss"])
+    parity_log("dino_loss_rel", abs(loss.item() - ref) / ref, 2e-5)
+    assert abs(loss.item() - ref) < 2e-5 * ref
+    gc = g[f"e{epoch}/grad_cols"]
+    assert np.abs(dl[:, ::257].cpu().numpy() - gc).max() < 2e-5 * np.abs(gc).max()
+    np.testing.assert_allclose(dl.double().abs().sum(1).cpu().numpy(), g[f"e{epoch}/grad_abs_sum"], rtol=3e-5)
+    # centre update (world size 1)
+    colsum = torch.empty(n, device=DEV)
+    ops.dino_colsum(t, colsum)
+    center = c.clone().view(-1)
+    ops.dino_center_ema(center, colsum, 0.9, 1.0 / (2 * B))
+    assert np.abs(center.cpu().numpy() - g[f"e{epoch}/center_after"][0]).max() < 1e-7
+    # bit-reproducible (fixed-order reductions, no float atomics)
+    dl2, loss2 = torch.empty_like(dl), torch.empty((), device=DEV)
+    ops.dino_loss(s, t, c.view(-1), s_lse, t_lse, B, ncrops, 0.1, temp, dl2, loss2)
+    assert torch.equal(dl, dl2) and loss.item() == loss2.item()
+
+
+@pytest.mark.parametrize("B,ncrops,n", [(3, 2, 1024), (5, 7, 4096), (64, 10, 8192)])
+def test_dino_loss_shapes_vs_oracle(ops, B, ncrops, n):
+    """ncrops = 2 (--local_crops_number 0), odd batch sizes, the benchmark's B = 64 with 2 + 8 crops."""
+    from oracle import dino_oracle as do
+    s, t, c = rnd(ncrops * B, n, seed=1, scale=0.4), rnd(2 * B, n, seed=2, scale=0.4), rnd(1, n, seed=3, scale=0.05)
+    sd = s.double().cpu().requires_grad_(True)
+    ref = do.dino_loss(sd, t.double().cpu(), c.double().cpu(), 0.05, ncrops)
+    ref.backward()
+    dl, loss = torch.empty_like(s), torch.empty((), device=DEV)
+    ops.dino_loss(s, t, c.view(-1), ops.dino_row_lse(s, 10.0), ops.dino_row_lse(t, 20.0, c.view(-1)), B, ncrops, 0.1, 0.05,
+                  dl, loss)
+    assert abs(loss.item() - float(ref)) < 1e-5 * float(ref)
+    assert rel(dl, sd.grad) < 2e-5
+    c2 = do.center_update(c.double().cpu(), t.double().cpu(), world_size=4)
+    colsum = torch.empty(n, device=DEV)
+    ops.dino_colsum(t, colsum)
+    cc = c.clone().view(-1)
+    ops.dino_center_ema(cc, colsum, 0.9, 1.0 / (2 * B * 4))
+    assert (cc.double().cpu() - c2[0]).abs().max().item() < 1e-7
+
+
+# ------------------------------------------------------------------ DINOHead pieces
+def test_gelu_l2norm_weightnorm_vs_torch(ops):
+    import torch.nn.functional as F
+    u = rnd(40, 2048, seed=5, scale=2.0)
+    h, du = torch.empty_like(u), torch.empty_like(u)
+    ops.gelu_fwd_f32(u, h)
+    ud = u.double().cpu().requires_grad_(True)
+    ref = F.gelu(ud)
+    assert (h.double().cpu() - ref).abs().max().item() < 1e-6
+    dh = rnd(40, 2048, seed=6)
+    ref.backward(dh.double().cpu())
+    ops.gelu_bwd_f32(dh, u, du)
+    assert (du.double().cpu() - ud.grad).abs().max().item() < 3e-6
+    # F.normalize
+    z = rnd(37, 256, seed=7, scale=3.0)
+    z[5] = 0.0                                                       # the eps branch
+    out, inv, dz = torch.empty_like(z), torch.empty(37, device=DEV), torch.empty_like(z)
+    ops.l2norm_fwd(z, out, inv)
+    zd = z.double().cpu().requires_grad_(True)
+    ref = F.normalize(zd, dim=-1, p=2)
+    assert (out.double().cpu() - ref).abs().max().item() < 1e-6
+    dout = rnd(37, 256, seed=8)
+    ref.backward(dout.double().cpu())
+    ops.l2norm_bwd(dout, out, inv, dz)
+    keep = [i for i in range(37) if i != 5]
+    assert rel(dz[keep], zd.grad[keep]) < 1e-5
+    # weight_norm
+    v, g = rnd(1024, 256, seed=9, scale=0.05), (1.0 + 0.1 * rnd(1024, seed=10))
+    w, winv = torch.empty_like(v), torch.empty(1024, device=DEV)
+    ops.weight_norm_fwd(v, g, w, winv)
+    vd, gd = v.double().cpu().requires_grad_(True), g.double().cpu().requires_grad_(True)
+    ref = gd.view(-1, 1) * vd / vd.norm(dim=1, keepdim=True)
+    assert rel(w, ref) < 1e-6
+    dw = rnd(1024, 256, seed=11)
+    ref.backward(dw.double().cpu())
+    dv, dg = torch.ones_like(v), torch.ones_like(g)                  # accumulate on top of existing values
+    ops.weight_norm_bwd(dw, v, g, winv, dv, dg)
+    assert rel(dv - 1.0, vd.grad) < 1e-5 and rel(dg - 1.0, gd.grad) < 1e-5
+
+
+def test_pos_interp_kernels(ops):
+    from sais_amd import vit
+    Wm = torch.from_numpy(vit.pos_interp_matrix(14, 96, 96).astype(np.float32)).to(DEV)
+    pos = rnd(197, 384, seed=12)
+    out = torch.empty(37, 384, device=DEV)
+    ops.pos_interp_fwd(Wm, pos, out)
+    ref = torch.cat([pos[:1].double(), Wm.double() @ pos[1:].double()])
+    assert (out.double() - ref).abs().max().item() < 1e-5
+    dout, dpos = rnd(37, 384, seed=13), torch.ones(197, 384, device=DEV)
+    ops.pos_interp_bwd(Wm, dout, dpos)
+    refb = torch.cat([dout[:1].double(), Wm.double().t() @ dout[1:].double()]) + 1.0
+    assert (dpos.double() - refb).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------ 37-token ViT
+def test_attention_37_tokens(ops):
+    frames = 70                                                      # 420 problems: more than one pass of the backward
+    qkv = (rnd(frames * 37, 1152, seed=30, scale=1.5)).to(torch.bfloat16)
+    out = torch.empty(frames * 37, 384, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(frames, 6, 37, device=DEV)
+    probs = torch.empty(frames, 6, 37, 37, device=DEV)
+    ops.vit_attn_fwd(qkv, frames, out, lse, probs, ntok=37)
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = qr.view(frames, 37, 3, 6, 64).permute(2, 0, 3, 1, 4)
+    p = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    ref = (p @ v).transpose(1, 2).reshape(frames * 37, 384)
+    assert (probs - p).abs().max().item() < 4e-3
+    assert rel(out.float(), ref) < 1e-2
+    dout = rnd(frames * 37, 384, seed=31).to(torch.bfloat16)
+    ref.backward(dout.float())
+    dqkv = torch.full((frames * 37, 1152), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.vit_attn_bwd(qkv, dout, out, lse, None, frames, dqkv, ntok=37)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert rel(dqkv[:, 384 * i:384 * (i + 1)].float(), qr.grad[:, 384 * i:384 * (i + 1)]) <= 1.5e-2, name
+    again = torch.full_like(dqkv, float("nan"))
+    ops.vit_attn_bwd(qkv, dout, out, lse, None, frames, again, ntok=37)
+    assert torch.equal(again, dqkv)
+
+
+def test_backbone_at_96_vs_reference_golden(gstep):
+    from sais_amd import vit
+    model = vit.vit_small(patch_size=16)
+    model.load_state_dict(synth.vit_state_dict(seed=20))
+    model = model.to(DEV).eval()
+    x = synth.dino_crops(seed=300, B=2, n_local=1)[2].to(DEV)
+    with torch.no_grad():
+        got = model(x).cpu().numpy()
+    ref = gstep["cls_96"]
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    parity_log("dino_cls96_rel_max", err, 2e-2)
+    assert err < 2e-2
+
+
+def test_backbone_gradients_at_96_vs_oracle():
+    """fwd + bwd of the 37-token path incl. the transposed bicubic map into pos_embed's gradient, depth 2, fp64 oracle."""
+    from oracle import dino_oracle as do
+    from sais_amd import vit
+    sd = synth.vit_state_dict(seed=22, depth=2)
+    model = vit.vit_small(patch_size=16, depth=2)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    x = synth.dino_crops(seed=301, B=6, n_local=1)[2].to(DEV)
+    wv = rnd(6, 384, seed=14)
+    model.zero_grad()
+    rep = model(x)
+    (rep * wv).sum().backward()
+    leaves = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    ref = do.vit_forward_res(leaves, x.double().cpu(), depth=2)
+    (ref * wv.double().cpu()).sum().backward()
+    assert (rep.detach().double().cpu() - ref.detach()).abs().max().item() < 2e-2 * ref.abs().max().item()
+    worst = 0.0
+    for n, p in model.named_parameters():
+        e = rel(p.grad, leaves[n].grad)
+        worst = max(worst, e)
+        assert e < 2e-2, (n, e)
+    parity_log("dino_vit96_grad_rel_l2", worst, 2e-2)
+
+
+# ------------------------------------------------------------------ optimizer tail
+def test_adamw_clip_ema_vs_oracle():
+    """Four steps of the fused clip + AdamW + EMA kernel on a small two-buffer model against oracle.adamw_update /
+    clip_coef / ema (fp64), with a frozen class-1 tensor in the first two steps and a requires_grad=False tensor."""
+    import torch.nn as nn
+    from oracle import dino_oracle as do
+    from sais_amd import dino
+    from sais_amd.flat import FlatParams
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(300, 70)                              # weight 21000 (3 chunks), bias 70
+            self.norm = nn.LayerNorm(52)
+            self.last_layer = nn.Linear(33, 9, bias=False)           # 297 elements: padded to 300
+            self.g = nn.Parameter(torch.ones(12, 1), requires_grad=False)
+
+    torch.manual_seed(3)
+    student, teacher = Toy(), Toy()
+    teacher.load_state_dict(student.state_dict())
+    sf, tf = FlatParams(student, DEV), FlatParams(teacher, DEV)
+    sf.refresh_shadows([]), tf.refresh_shadows([])
+    part = dino._FlatAdamW(sf, tf, "head.", ("last_layer.weight",))
+    st = {n: p.detach().double().cpu().clone() for n, p in student.named_parameters()}
+    tt = {n: v.clone() for n, v in st.items()}
+    m = {n: torch.zeros_like(v) for n, v in st.items()}
+    v2 = {n: torch.zeros_like(v) for n, v in st.items()}
+    steps = {n: 0 for n in st}
+    counts = [0, 0]
+    clip, betas, eps = 0.5, (0.9, 0.999), 1e-8
+    for it in range(4):
+        frozen = it < 2
+        lr, wd, mom = 1e-3 * (it + 1), 0.05 * (it + 1), 0.9 + 0.02 * it
+        gen = torch.Generator().manual_seed(100 + it)
+        sf.grad.zero_()
+        grads = {}
+        for n, p in student.named_parameters():
+            if p.requires_grad:
+                grads[n] = torch.randn(p.shape, generator=gen) * (0.3 if "a." in n else 0.01)
+                sf.g(n).copy_(grads[n])
+        norms = part.grad_norms()
+        counts[0] += 1
+        counts[1] += 0 if frozen else 1
+        part.step(clip, lr, wd, betas, eps, counts, frozen, mom, with_shadow=True)
+        for i, (n, p) in enumerate(student.named_parameters()):
+            if p.requires_grad:
+                g = grads[n].double()
+                nrm, c = do.clip_coef(g, clip)
+                assert abs(norms[i].item() - float(nrm)) < 1e-5 * float(nrm) + 1e-9
+                if not ("last_layer" in n and frozen):
+                    steps[n] += 1
+                    st[n], m[n], v2[n] = do.adamw_update(st[n], g * c, m[n], v2[n], steps[n], lr,
+                                                         wd if do.is_regularized(n, p.shape) else 0.0)
+            tt[n] = do.ema(tt[n], st[n], mom)
+        for n, p in student.named_parameters():
+            assert (p.detach().double().cpu() - st[n]).abs().max().item() < 2e-6, (it, n)
+            assert (dict(teacher.named_parameters())[n].detach().double().cpu() - tt[n]).abs().max().item() < 2e-6, (it, n)
+            assert torch.equal(sf.w(n).float().cpu(), p.detach().to(torch.bfloat16).float().cpu())
+    assert steps["last_layer.weight"] == 2 and float(student.g.min()) == 1.0
+
+
+# ------------------------------------------------------------------ the whole step vs the reference's own run
+def _student_sd(out_dim):
+    sd = {"backbone." + k: v for k, v in synth.vit_state_dict(seed=20).items()}
+    sd.update({"head." + k: v for k, v in synth.dino_head_state_dict(seed=21, out_dim=out_dim).items()})
+    return sd
+
+
+def sample(t):
+    t = t.detach().reshape(-1)
+    return (t[::97] if t.numel() > 20000 else t).double().cpu().numpy()
+
+
+def test_train_steps_vs_reference_golden(gstep):
+    """Four iterations of train_one_epoch's body (main_dino.py:521-566) on the reference's own inputs: teacher / student
+    logits, loss, centre, per-parameter gradient norms (clipping active), frozen last layer in epoch 0, AdamW, EMA."""
+    from sais_amd import dino
+    c = {k: float(v) for k, v in zip(gstep["cfg_keys"], gstep["cfg_vals"])}
+    out_dim, n_local, B = int(c["out_dim"]), int(c["n_local"]), int(c["B"])
+    student, teacher = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=0.0, device=DEV)
+    student.load_state_dict(_student_sd(out_dim))
+    teacher.load_state_dict(student.state_dict())
+    loss_mod = dino.DINOLoss(out_dim, n_local + 2, c["warmup_teacher_temp"], c["teacher_temp"],
+                             int(c["warmup_teacher_temp_epochs"]), int(c["epochs"])).to(DEV)
+    opt = dino.DINOOptimizer(student, teacher)
+    lr_s, wd_s, mom_s = gstep["lr_schedule"], gstep["wd_schedule"], gstep["momentum_schedule"]
+    track = sorted({k.split("/", 2)[2] for k in gstep.files if k.startswith("it0/student/")})
+    P, T = dict(student.named_parameters()), dict(teacher.named_parameters())
+    for it in range(int(c["iters"])):
+        epoch = it // int(c["niter_per_ep"])
+        images = [t.to(DEV) for t in synth.dino_crops(seed=300 + it, B=B, n_local=n_local)]
+        if it == 0:                                                  # logits before anything moved: the tightest check
+            with torch.no_grad():
+                t_out = teacher(images[:2])
+                s_out = student(images)
+            k = "it0/"
+            e_t = np.abs(t_out.cpu().numpy() - gstep[k + "teacher_out"]).max()
+            e_s = np.abs(s_out.cpu().numpy() - gstep[k + "student_out"]).max()
+            parity_log("dino_logits_max_abs", max(e_t, e_s), 1e-2)
+            assert e_t < 1e-2 and e_s < 1e-2                          # cosines in [-1, 1] behind 12 bf16 blocks
+        loss, norms = dino.train_step(student, teacher, loss_mod, opt, images, it, epoch, lr_s, wd_s, mom_s,
+                                      clip_grad=c["clip_grad"], freeze_last_layer=int(c["freeze_last_layer"]))
+        k = f"it{it}/"
+        ref_loss = float(gstep[k + "loss"])
+        parity_log("dino_step_loss_rel", abs(loss.item() - ref_loss) / ref_loss, 2e-3)
+        assert abs(loss.item() - ref_loss) < 2e-3 * ref_loss, (it, loss.item(), ref_loss)
+        cen = loss_mod.center.cpu().numpy()
+        assert np.abs(cen - gstep[k + "center_after"]).max() < 2e-3
+        ref_n = gstep[k + "norms"]
+        got_n = norms.cpu().numpy()
+        assert got_n.shape == ref_n.shape
+        nerr = np.abs(got_n - ref_n) / np.maximum(ref_n, 1e-12)
+        parity_log("dino_grad_norm_rel", float(nerr.max()), 5e-2)
+        assert nerr.max() < 5e-2, (it, list(gstep[k + "norm_names"][nerr > 5e-2]))
+        lr = float(lr_s[it])
+        for n in track:
+            for who, sd in (("student", P), ("teacher", T)):
+                ref = gstep[k + who + "/" + n]
+                d = np.abs(sample(sd[n]) - ref)
+                # AdamW moves every element by ~lr per step whatever the gradient's size; where the gradient's SIGN
+                # differs (elements whose gradient is rounding noise) the two runs part by up to 2 lr per step
+                assert d.max() < 2.2 * 2e-4 * (it + 1) + 1e-6, (it, who, n, d.max())
+                assert np.median(d) < 0.25 * max(lr, 2e-4) + 1e-6, (it, who, n, float(np.median(d)))
+    assert opt.steps == [4, 2]
+    # checkpoint round trip in the reference's format
+    ck = dino.checkpoint_dict(student, teacher, opt, loss_mod, epoch=2)
+    assert set(ck["optimizer"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    s2, t2 = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=0.0, device=DEV)
+    l2 = dino.DINOLoss(out_dim, n_local + 2, 0.04, 0.07, 2, 3).to(DEV)
+    images = [t.to(DEV) for t in synth.dino_crops(seed=300, B=B, n_local=n_local)]
+    with torch.no_grad():
+        s2(images), t2(images[:2])                                   # builds the flat buffers
+    o2 = dino.DINOOptimizer(s2, t2)
+    assert dino.load_checkpoint(ck, s2, t2, o2, l2) == 2
+    with torch.no_grad():
+        assert torch.equal(s2(images), student(images)) and torch.equal(t2(images[:2]), teacher(images[:2]))
+    assert o2.steps == [4, 2] and torch.equal(l2.center, loss_mod.center)
+    for (pa, _), (pb, _) in zip(o2._parts, opt._parts):
+        assert torch.equal(pa.exp_avg, pb.exp_avg) and torch.equal(pa.exp_avg_sq, pb.exp_avg_sq)
+
+
+def test_train_step_gradients_vs_oracle_with_droppath():
+    """One step at the reference's default multi-crop shape (2 global + 8 local crops), out_dim 4096, depth 2, B = 3, with
+    DropPath 0.1 on the student: the HIP step's pre-clip gradients against the fp64 oracle fed the SAME DropPath draws."""
+    from oracle import dino_oracle as do
+    from sais_amd import dino
+    out_dim, n_local, B, depth = 4096, 8, 3, 2
+    sd = {"backbone." + k: v for k, v in synth.vit_state_dict(seed=23, depth=depth).items()}
+    sd.update({"head." + k: v for k, v in synth.dino_head_state_dict(seed=24, out_dim=out_dim).items()})
+    student, teacher = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=0.1, device=DEV, depth=depth)
+    student.load_state_dict(sd)
+    teacher.load_state_dict(student.state_dict())
+    student.train()
+    loss_mod = dino.DINOLoss(out_dim, n_local + 2, 0.04, 0.07, 3, 10).to(DEV)
+    loss_mod.center = (torch.randn(1, out_dim, generator=synth._gen(5)) * 0.02).to(DEV)
+    c0 = loss_mod.center.clone()
+    images = [t.to(DEV) for t in synth.dino_crops(seed=320, B=B, n_local=n_local)]
+    with torch.no_grad():
+        t_out = teacher.forward_kernels(images[:2], save=False)[0]
+        scales = []
+        bb = student.backbone
+        s_out, saved = student.forward_kernels(images, save=True)
+        for sv in saved[0]:                                           # the draws each resolution group used
+            ntok, Fr = sv["ntok"], sv["Fr"]
+            scales.append(sv["dp"].view(2 * depth, Fr, ntok)[:, :, 0].double().cpu())
+        loss = loss_mod(s_out, t_out, 1)
+        student.backbone.flat.grad.zero_(); student.head.flat.grad.zero_()
+        student.backward_kernels(saved, loss_mod.dlogits)
+    assert any((s == 0).any() for s in scales)                        # some branches really dropped
+    st = do.TrainState(sd)
+    leaves = {k: v.clone().requires_grad_(k != "head.last_layer.weight_g") for k, v in st.student.items()}
+    crops = [t.double().cpu() for t in images]
+    with torch.no_grad():
+        t_ref = do.multicrop_forward(st.teacher, crops[:2], depth)
+    s_ref = do.multicrop_forward(leaves, crops, depth, droppath=scales)
+    ref = do.dino_loss(s_ref, t_ref, c0.double().cpu(), float(loss_mod.teacher_temp_schedule[1]), n_local + 2)
+    ref.backward()
+    assert abs(loss.item() - float(ref)) < 2e-3 * float(ref)
+    c1 = do.center_update(c0.double().cpu(), t_ref)
+    assert (loss_mod.center.double().cpu() - c1).abs().max().item() < 1e-3
+    worst = 0.0
+    for who, mod in (("backbone.", student.backbone), ("head.", student.head)):
+        for n, p in mod.named_parameters():
+            if not p.requires_grad:
+                continue
+            e = rel(mod.flat.g(n), leaves[who + n].grad)
+            worst = max(worst, e)
+            assert e < 3e-2, (who + n, e)
+    parity_log("dino_step_grad_rel_l2", worst, 3e-2)

@@ -1,0 +1,94 @@
+"""CPU-only host logic of the DINO pre-training path (sais_amd/dino.py, sais_amd/vit.py): schedules, parameter groups,
+state-dict names, the bicubic positional map.  No HIP compute."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import synth  # noqa: E402
+
+from sais_amd import dino, vit  # noqa: E402
+
+G = np.load(os.path.join(HERE, "golden", "dino_step.npz"))
+CFG = {k: float(v) for k, v in zip(G["cfg_keys"], G["cfg_vals"])}
+
+
+def test_pos_interp_matrix_is_torch_bicubic():
+    """vision_transformer.py:174-194 uses F.interpolate(scale_factor=(n0 + 0.1) / 14, mode='bicubic')."""
+    pos = torch.randn(1, 196, 8, dtype=torch.float64)
+    for side in (96, 112, 160, 208):
+        n0 = side // 16
+        ref = F.interpolate(pos.reshape(1, 14, 14, 8).permute(0, 3, 1, 2), scale_factor=((n0 + 0.1) / 14, (n0 + 0.1) / 14),
+                            mode="bicubic").permute(0, 2, 3, 1).reshape(-1, 8)
+        M = vit.pos_interp_matrix(14, side, side)
+        assert M.shape == (n0 * n0, 196)
+        assert np.abs(M @ pos[0].numpy() - ref.numpy()).max() < 1e-12, side
+    # the reference's own output at 96 x 96 (golden)
+    p = synth.vit_state_dict(seed=20)["pos_embed"][0].double().numpy()
+    got = np.concatenate([p[:1], vit.pos_interp_matrix(14, 96, 96) @ p[1:]])
+    assert np.abs(got - G["pos_embed_96"]).max() < 2e-6
+
+
+def test_schedules_match_reference():
+    c = CFG
+    lr = dino.cosine_scheduler(c["lr"] * c["B"] / 256.0, c["min_lr"], int(c["epochs"]), int(c["niter_per_ep"]),
+                               warmup_epochs=int(c["warmup_epochs"]))
+    wd = dino.cosine_scheduler(c["weight_decay"], c["weight_decay_end"], int(c["epochs"]), int(c["niter_per_ep"]))
+    mom = dino.cosine_scheduler(c["momentum_teacher"], 1, int(c["epochs"]), int(c["niter_per_ep"]))
+    np.testing.assert_allclose(lr, G["lr_schedule"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(wd, G["wd_schedule"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(mom, G["momentum_schedule"], rtol=0, atol=1e-15)
+    loss = dino.DINOLoss(1024, 4, c["warmup_teacher_temp"], c["teacher_temp"], int(c["warmup_teacher_temp_epochs"]),
+                         int(c["epochs"]))
+    np.testing.assert_allclose(loss.teacher_temp_schedule, G["teacher_temp_schedule"], rtol=0, atol=1e-15)
+    assert list(loss.state_dict()) == ["center"] and loss.center.shape == (1, 1024)
+
+
+def test_parameter_contract_and_groups():
+    student = dino.MultiCropWrapper(vit.vit_small(patch_size=16, drop_path_rate=0.1), dino.DINOHead(384, 1024))
+    names = [n for n, _ in student.named_parameters()]
+    assert names == list(G["param_names"])                       # the reference's named_parameters() order
+    assert list(student.state_dict()) == names
+    sd = {"backbone." + k: v for k, v in synth.vit_state_dict(seed=20).items()}
+    sd.update({"head." + k: v for k, v in synth.dino_head_state_dict(seed=21, out_dim=1024).items()})
+    student.load_state_dict(sd, strict=True)
+    groups = dino.get_params_groups(student)
+    reg = {id(p) for p in groups[0]["params"]}
+    assert [id(p) in reg for _, p in student.named_parameters()] == [bool(x) for x in G["regularized"]]
+    assert groups[1]["weight_decay"] == 0.0 and "weight_decay" not in groups[0]
+    assert [p.requires_grad for _, p in student.named_parameters()] == [bool(x) for x in G["requires_grad"]]
+    opt = dino.DINOOptimizer(student, None)
+    osd = opt.state_dict()
+    assert osd["state"] == {} and [len(g["params"]) for g in osd["param_groups"]] == [len(groups[0]["params"]),
+                                                                                     len(groups[1]["params"])]
+    # default construction follows the reference's initialisers
+    head = dino.DINOHead(384, 1024, norm_last_layer=False)
+    assert head.last_layer.weight_g.requires_grad and float(head.last_layer.weight_g.detach().min()) == 1.0
+    assert float(head.mlp[0].bias.detach().abs().max()) == 0.0
+    assert abs(float(head.mlp[2].weight.detach().std()) - 0.02) < 5e-4           # trunc_normal_(std=.02), cut at +-2
+    assert float(head.last_layer.weight_v.detach().abs().max()) <= 1 / 16 + 1e-6  # kaiming_uniform(a=sqrt 5), fan_in 256
+
+
+def test_checkpoint_keys_are_what_the_extraction_script_strips():
+    """extract_representations.loadModel (:190-199): list(sd['student'].items())[:-8], name.split('.')[2:]."""
+    student = dino.MultiCropWrapper(vit.vit_small(patch_size=16, depth=1), dino.DINOHead(384, 128))
+    teacher = dino.MultiCropWrapper(vit.vit_small(patch_size=16, depth=1), dino.DINOHead(384, 128))
+    ck = dino.checkpoint_dict(student, teacher, dino.DINOOptimizer(student, teacher), dino.DINOLoss(128, 4, .04, .04, 0, 2), 3)
+    items = list(ck["student"].items())
+    assert all(k.startswith("module.head.") for k, _ in items[-8:]) and all(k.startswith("module.backbone.") for k, _ in items[:-8])
+    stripped = {".".join(k.split(".")[2:]): v for k, v in items[:-8]}
+    assert list(stripped) == [k for k, _, _ in synth.vit_keys(depth=1)]
+    assert ck["epoch"] == 3 and list(ck["dino_loss"]) == ["center"] and not any(k.startswith("module.") for k in ck["teacher"])
+
+
+def test_no_cpu_fallback():
+    import pytest
+    from sais_amd._lib import SaisHipError
+    with pytest.raises(SaisHipError):
+        dino.DINOHead(384, 128)(torch.zeros(2, 384))
+    with pytest.raises(SaisHipError):
+        dino.DINOLoss(128, 4, .04, .04, 0, 2)(torch.zeros(8, 128), torch.zeros(4, 128), 0)
