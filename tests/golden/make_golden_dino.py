@@ -178,9 +178,31 @@ def golden_loss(main_dino, out):
     np.savez_compressed(os.path.join(out, "dino_loss.npz"), **g)
 
 
+def golden_args(main_dino, out):
+    """Every flag of main_dino.get_args_parser() with its default and type: the CLI contract."""
+    import json
+    hub_list, torch.hub.list = torch.hub.list, lambda *a, **k: []      # main_dino.py:53 lists xcit archs over the network
+    try:
+        parser = main_dino.get_args_parser()
+    finally:
+        torch.hub.list = hub_list
+    spec = {}
+    for a in parser._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        d = a.default
+        spec[a.option_strings[0]] = dict(dest=a.dest, default=list(d) if isinstance(d, tuple) else d,
+                                         nargs=a.nargs, type=getattr(a.type, "__name__", None),
+                                         store_true=type(a).__name__ == "_StoreTrueAction")
+    with open(os.path.join(out, "dino_args.json"), "w") as f:
+        json.dump(spec, f, indent=1, sort_keys=True)
+    print("dino_args.json:", len(spec), "flags")
+
+
 def main():
     torch.set_num_threads(8)
     main_dino, utils, vits = import_reference()
+    golden_args(main_dino, HERE)
     init_dist()
     golden_loss(main_dino, HERE)
     golden_step(main_dino, utils, vits, HERE)

@@ -411,3 +411,118 @@ def test_train_step_gradients_vs_oracle_with_droppath():
             worst = max(worst, e)
             assert e < 3e-2, (who + n, e)
     parity_log("dino_step_grad_rel_l2", worst, 3e-2)
+
+
+# ------------------------------------------------------------------ data parallel (one process per GPU)
+DP_CFG = dict(out_dim=1024, n_local=2, B=2, depth=2)
+
+
+def _dp_build(dev):
+    from sais_amd import dino
+    c = DP_CFG
+    sd = {"backbone." + k: v for k, v in synth.vit_state_dict(seed=25, depth=c["depth"]).items()}
+    sd.update({"head." + k: v for k, v in synth.dino_head_state_dict(seed=26, out_dim=c["out_dim"]).items()})
+    student, teacher = dino.build_student_teacher(out_dim=c["out_dim"], drop_path_rate=0.0, device=dev, depth=c["depth"])
+    student.load_state_dict(sd)
+    teacher.load_state_dict(student.state_dict())
+    loss_mod = dino.DINOLoss(c["out_dim"], c["n_local"] + 2, 0.04, 0.07, 3, 10).to(dev)
+    return student, teacher, loss_mod, dino.DINOOptimizer(student, teacher)
+
+
+def _dp_step(dev, images):
+    from sais_amd import dino
+    student, teacher, loss_mod, opt = _dp_build(dev)
+    lr_s, wd_s, mom_s = np.full(4, 1e-4), np.full(4, 0.05), np.full(4, 0.9)
+    loss, norms = dino.train_step(student, teacher, loss_mod, opt, images, 0, 1, lr_s, wd_s, mom_s, clip_grad=0.05,
+                                  freeze_last_layer=0)
+    torch.cuda.synchronize()
+    return dict(loss=loss.item(), norms=norms.cpu(), center=loss_mod.center.cpu(),
+                gb=student.backbone.flat.grad.cpu(), gh=student.head.flat.grad.cpu(),
+                pb=student.backbone.flat.flat.cpu(), tb=teacher.backbone.flat.flat.cpu())
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = DP_CFG["B"]
+    crops = synth.dino_crops(seed=330, B=world * B, n_local=DP_CFG["n_local"])
+    r = _dp_step(dev, [t[rank * B:(rank + 1) * B].to(dev) for t in crops])
+    losses = [None] * world
+    dist.all_gather_object(losses, r["loss"])
+    if rank == 0:
+        r["loss"] = sum(losses) / world
+        torch.save(r, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_dino_step_equals_single_process(tmp_path):
+    """2 ranks x B crops-sets: after DDP-style gradient averaging and the centre all-reduce (main_dino.py:413,627) the
+    step equals the single-process step on the concatenated 2B batch (the loss is a mean over samples)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dino_dp.pt")
+    mp.spawn(_dp_worker, args=(2, 29700 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    got = torch.load(out)
+    dev = torch.device("cuda", 0)
+    crops = synth.dino_crops(seed=330, B=2 * DP_CFG["B"], n_local=DP_CFG["n_local"])
+    ref = _dp_step(dev, [t.to(dev) for t in crops])
+    assert abs(got["loss"] - ref["loss"]) < 1e-5 * ref["loss"]
+    assert (got["center"] - ref["center"]).abs().max().item() < 1e-6
+    assert rel(got["gb"], ref["gb"]) < 3e-3 and rel(got["gh"], ref["gh"]) < 3e-3       # summation order only
+    assert ((got["norms"] - ref["norms"]).abs() / ref["norms"].clamp_min(1e-12)).max().item() < 5e-3
+    # after AdamW both runs moved (almost) every element by the same +-lr; sign flips only where the gradient is noise
+    d = (got["pb"] - ref["pb"]).abs()
+    assert d.max().item() <= 2.1e-4 and (d > 1e-6).float().mean().item() < 2e-2
+    assert (got["tb"] - ref["tb"]).abs().max().item() <= 2.1e-5
+
+
+# ------------------------------------------------------------------ the command line, end to end
+def test_main_dino_cli_trains_resumes_and_feeds_the_extraction_loader(tmp_path):
+    """SAIS/scripts/dino-main/main_dino.py on 8 synthetic frames: 2 epochs, then a second invocation that resumes from
+    checkpoint.pth; the checkpoint loads through the extraction script's loader (extract_representations.loadModel's
+    'student' branch, :190-199)."""
+    import json
+    import subprocess
+    import pandas as pd
+    from PIL import Image
+    root = os.path.dirname(HERE)
+    rng = np.random.default_rng(1)
+    frames = tmp_path / "frames" / "Images" / "vidA"
+    frames.mkdir(parents=True)
+    (tmp_path / "paths").mkdir()
+    rows = []
+    for i in range(8):
+        Image.fromarray(rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)).save(frames / f"frames_{i:08d}.jpg")
+        rows.append((f"Images\\vidA\\frames_{i:08d}.jpg", "vidA"))
+    pd.DataFrame(rows, columns=["path", "label"]).to_csv(tmp_path / "paths" / "VUA_Paths.csv")
+    out = tmp_path / "out"
+    cmd = [sys.executable, os.path.join(root, "SAIS", "scripts", "dino-main", "main_dino.py"), "--data_path", str(tmp_path),
+           "--frames_root", str(tmp_path / "frames"), "--datasets", "VUA", "--output_dir", str(out), "--batch_size_per_gpu", "4",
+           "--local_crops_number", "2", "--out_dim", "1024", "--warmup_epochs", "1", "--num_workers", "0",
+           "--saveckp_freq", "1", "--lr", "0.01"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd + ["--epochs", "2"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Starting DINO training" in r.stdout and os.path.exists(out / "checkpoint0001.pth")
+    log = [json.loads(l) for l in open(out / "log.txt")]
+    assert [l["epoch"] for l in log] == [0, 1] and all(math.isfinite(l["train_loss"]) and l["train_loss"] > 0 for l in log)
+    ck = torch.load(out / "checkpoint.pth", map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 2 and set(ck) >= {"student", "teacher", "optimizer", "epoch", "args", "dino_loss"}
+    r = subprocess.run(cmd + ["--epochs", "3"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "resumed from" in r.stdout and "at epoch 2" in r.stdout
+    assert [json.loads(l)["epoch"] for l in open(out / "log.txt")] == [0, 1, 2]
+    from sais_amd.model_io import load_vit
+    vit = load_vit(str(out / "checkpoint.pth"), device=DEV)
+    with torch.no_grad():
+        rep = vit(torch.randn(2, 3, 224, 224, device=DEV))
+    assert tuple(rep.shape) == (2, 384) and torch.isfinite(rep).all()
+    # the trained weights differ from the initial ones and student != teacher (EMA lag)
+    ck3 = torch.load(out / "checkpoint.pth", map_location="cpu", weights_only=False)
+    k = "backbone.blocks.0.attn.qkv.weight"
+    assert not torch.equal(ck3["student"]["module." + k], ck3["teacher"][k])

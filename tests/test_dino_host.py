@@ -92,3 +92,71 @@ def test_no_cpu_fallback():
         dino.DINOHead(384, 128)(torch.zeros(2, 384))
     with pytest.raises(SaisHipError):
         dino.DINOLoss(128, 4, .04, .04, 0, 2)(torch.zeros(8, 128), torch.zeros(4, 128), 0)
+
+
+# ------------------------------------------------------------------ CLI + data pipeline
+def _load_cli():
+    import importlib.util
+    path = os.path.join(os.path.dirname(HERE), "SAIS", "scripts", "dino-main", "main_dino.py")
+    spec = importlib.util.spec_from_file_location("sais_main_dino", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_cli_flags_are_the_reference_parser():
+    """tests/golden/dino_args.json = main_dino.get_args_parser() of the reference, dumped by make_golden_dino.py."""
+    import json
+    ref = json.load(open(os.path.join(HERE, "golden", "dino_args.json")))
+    mod = _load_cli()
+    mine = {a.option_strings[0]: a for a in mod.get_args_parser()._actions if a.option_strings}
+    extra = set(mine) - set(ref)
+    assert extra == {"--datasets", "--frames_root"} and not set(ref) - set(mine)
+    for flag, spec in ref.items():
+        a = mine[flag]
+        d = list(a.default) if isinstance(a.default, tuple) else a.default
+        assert a.dest == spec["dest"] and d == spec["default"], flag
+        assert (type(a).__name__ == "_StoreTrueAction") == spec["store_true"], flag
+        assert a.nargs == spec["nargs"], flag
+        if spec["type"] is not None:
+            assert getattr(a.type, "__name__", None) == spec["type"], flag
+    ns = mod.get_args_parser().parse_args(["--norm_last_layer", "false", "--global_crops_scale", "0.14", "1"])
+    assert ns.norm_last_layer is False and ns.global_crops_scale == [0.14, 1.0] and ns.use_fp16 is True
+
+
+def test_augmentation_and_dataset(tmp_path):
+    from PIL import Image
+    import pandas as pd
+    from sais_amd.dino_data import DataAugmentationDINO, SurgDataset, random_resized_crop
+    import random
+    rng = np.random.default_rng(0)
+    root = tmp_path / "frames"
+    (root / "Images" / "vidA").mkdir(parents=True)
+    (tmp_path / "paths").mkdir()
+    rows = []
+    for i in range(5):
+        arr = rng.integers(0, 256, (270, 480, 3), dtype=np.uint8)
+        Image.fromarray(arr).save(root / "Images" / "vidA" / f"frames_{i:08d}.jpg", quality=95)
+        rows.append((f"Images\\vidA\\frames_{i:08d}.jpg", "vidA"))                # Windows separators, as in the CSVs
+    pd.DataFrame(rows, columns=["path", "label"]).to_csv(tmp_path / "paths" / "VUA_Paths.csv")
+    aug = DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), 3, seed=1)
+    ds = SurgDataset(str(tmp_path), ["VUA"], aug, frames_root=str(root))
+    assert len(ds) == 5
+    crops, label, name = ds[2]
+    assert [tuple(c.shape) for c in crops] == [(3, 224, 224)] * 2 + [(3, 96, 96)] * 3 and label == "vidA" and name == "VUA"
+    assert all(c.dtype == torch.float32 and torch.isfinite(c).all() for c in crops)
+    lo, hi = (0 - 0.485) / 0.229, (1 - 0.406) / 0.225
+    assert min(float(c.min()) for c in crops) >= lo - 1e-4 and max(float(c.max()) for c in crops) <= hi + 1e-4
+    # same seed -> same crops; the crop box statistics follow RandomResizedCrop's contract
+    again = DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), 3, seed=1)
+    ds2 = SurgDataset(str(tmp_path), ["VUA"], again, frames_root=str(root))
+    assert all(torch.equal(a, b) for a, b in zip(ds2[2][0], SurgDataset(str(tmp_path), ["VUA"], DataAugmentationDINO(
+        (0.4, 1.0), (0.05, 0.4), 3, seed=1), frames_root=str(root))[2][0]))
+    img = Image.fromarray(rng.integers(0, 256, (216, 384, 3), dtype=np.uint8))
+    assert random_resized_crop(img, 96, (0.05, 0.4), random.Random(3)).size == (96, 96)
+    assert ds.crop_fracs() == (0.8, 0.8)
+    ds.dataset = "VUA_Gronau"
+    assert ds.crop_fracs() == (0.8, 0.7)
+    mod = _load_cli()
+    crops_b, labels, names = mod.collate([ds[0], ds[1]])
+    assert [tuple(c.shape) for c in crops_b] == [(2, 3, 224, 224)] * 2 + [(2, 3, 96, 96)] * 3 and len(labels) == 2
