@@ -54,6 +54,12 @@ def parse_args():
     ap.add_argument("--vit-drop-path", type=float, default=0.1,
                     help="stochastic-depth rate of the ViT in train mode (the reference constructs it with 0.1: "
                          "extract_representations.py:201, main_dino.py:57)")
+    ap.add_argument("--workload", choices=("train", "dino"), default="train",
+                    help="train = the headline step above (BASELINE.json); dino = one DINO pre-training step "
+                         "(SURVEY §8f-4: main_dino.py defaults, 64 images per GPU, 2 x 224 + 8 x 96 crops, out_dim 65536)")
+    ap.add_argument("--dino-batch", type=int, default=64, help="--workload dino: images per GPU (batch_size_per_gpu)")
+    ap.add_argument("--dino-local-crops", type=int, default=8)
+    ap.add_argument("--dino-out-dim", type=int, default=65536)
     ap.add_argument("--sustain-seconds", type=float, default=20.0,
                     help="after the timed region, keep replaying the step for this long and report the settled rate "
                          "(clock under sustained MFMA load); 0 = skip")
@@ -206,6 +212,111 @@ def cpu_baseline(T, C, threads):
                 variants=variants)
 
 
+def dino_cpu_baseline(args, threads, sample=2):
+    """The oracle's DINO step (oracle/dino_oracle.py, fp32 torch on the host cores) on `sample` images with the same
+    crop counts and out_dim; value = sample / time of one step (the second of two)."""
+    import numpy as np
+    import torch
+    import synth
+    from oracle import dino_oracle as do
+    torch.set_num_threads(threads)
+    sd = {"backbone." + k: v for k, v in synth.vit_state_dict(seed=20).items()}
+    sd.update({"head." + k: v for k, v in synth.dino_head_state_dict(seed=21, out_dim=args.dino_out_dim).items()})
+    st = do.TrainState(sd, dtype=torch.float32)
+    crops = synth.dino_crops(seed=1, B=sample, n_local=args.dino_local_crops)
+    sched = np.full(4, 1e-4)
+    dt = 0.0
+    for it in range(2):
+        t0 = time.perf_counter()
+        do.train_step(st, crops, it, 1, sched, sched, np.full(4, 0.996), np.full(4, 0.04), 3.0, 1, args.dino_local_crops)
+        dt = time.perf_counter() - t0
+    return dict(value=round(sample / dt, 3), unit="images/s", cores=threads, kind="port", cpu=cpu_model_name(),
+                sample=f"one step on {sample} images (2 x 224 + {args.dino_local_crops} x 96 crops each), out_dim "
+                       f"{args.dino_out_dim}, fp32, second of two steps, torch {torch.__version__} CPU oracle")
+
+
+def dino_main(args):
+    """--workload dino: K steps of sais_amd.dino.train_step (teacher forward on the 2 global crops, student forward +
+    backward on all crops, DINOLoss + centre, per-parameter clipping, AdamW, EMA teacher) on synthetic crops resident in
+    HBM; one rank per GPU, gradients and the [1, out_dim] centre all-reduced over RCCL when N > 1 (weak scaling)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from sais_amd import dino, ops
+    B, nl, out_dim = args.dino_batch, args.dino_local_crops, args.dino_out_dim
+    torch.manual_seed(0)                                             # same initial weights on every rank
+    student, teacher = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=args.vit_drop_path, device=dev)
+    loss_mod = dino.DINOLoss(out_dim, nl + 2, 0.04, 0.04, 0, 100).to(dev)
+    opt = dino.DINOOptimizer(student, teacher)
+    n = args.warmup + args.steps + 2
+    lr_s = dino.cosine_scheduler(0.0005 * B * world / 256.0, 1e-6, 100, n)
+    wd_s = dino.cosine_scheduler(0.04, 0.4, 100, n)
+    mom_s = dino.cosine_scheduler(0.996, 1, 100, n)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    images = [torch.randn(B, 3, 224, 224, device=dev, generator=g) for _ in range(2)] + \
+             [torch.randn(B, 3, 96, 96, device=dev, generator=g) for _ in range(nl)]
+
+    def step(it):
+        return dino.train_step(student, teacher, loss_mod, opt, images, it, 1, lr_s, wd_s, mom_s, clip_grad=3.0,
+                               freeze_last_layer=1)[0]
+
+    for it in range(args.warmup):
+        loss = step(it)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        loss = step(args.warmup + it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ms = dt.item() / args.steps * 1e3
+    lv = loss.item()
+    ops.TIMER = ops.KernelTimer()                                    # instrumented pass after the timed region
+    step(args.warmup + args.steps)
+    torch.cuda.synchronize()
+    summ, ops.TIMER = ops.TIMER.summary(), None
+    top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
+    tf = top[1]["flops"] / (top[1]["avg_ms"] * 1e-3) / 1e12
+    if rank == 0:
+        crops = f"2 x 224 + {nl} x 96"
+        out = {"metric": "dino_pretrain_images_per_s", "value": round(B * world / (ms * 1e-3), 1), "unit": "images/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"DINO ViT-S/16 pre-training step (main_dino.py defaults): {B} images per GPU, "
+                                      f"{crops} crops, out_dim {out_dim}, drop_path {args.vit_drop_path}, clip 3.0, AdamW, "
+                                      f"EMA teacher", "parallelism": f"dp{world}",
+                          "student_token_rows_per_gpu": B * (2 * 197 + nl * 37), "teacher_token_rows_per_gpu": B * 2 * 197},
+               "loss": round(lv, 4), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+               "roofline": {"kernel": top[0], "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(tf / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                            "launches_per_step": top[1]["launches"], "avg_us": round(top[1]["avg_ms"] * 1e3, 1)},
+               "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in
+                                       sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]}}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            out["cpu_baseline"] = dino_cpu_baseline(args, max(1, min(avail, 32)))    # see the note in main()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def load_pmc(name):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
@@ -225,6 +336,8 @@ def main():
             sys.exit(spawn_ranks(args))
     elif int(os.environ["WORLD_SIZE"]) != args.gpus and not force_dist:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if args.workload == "dino":
+        return dino_main(args)
 
     import torch
     import torch.distributed as dist

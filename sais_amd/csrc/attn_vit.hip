@@ -29,6 +29,10 @@ struct Geo {
     static constexpr int NKS = (NKT + 1) / 2;              // 32-key k-steps          (197: 7,  37: 2)
     static constexpr int TILE_ROWS = 32 * NKS;             //                         (197: 224, 37: 64)
     static constexpr int MAT_BYTES = TILE_ROWS * ROWB;     //                         (197: 35840)
+    // backward workgroup: 16 waves for 197 tokens (13 own a key tile, 8 of them also do the dQ products); 4 waves for
+    // 37 tokens (3 key tiles, the 8 dQ products shared two per wave) so that 3 workgroups fit a CU: these problems are
+    // a few microseconds of latency each, and independent problems in flight are what hides it
+    static constexpr int BWD_THREADS = NKT > 4 ? 1024 : 256;
 };
 
 // stage rows [0,197) x 64 bf16 of a [M, ld] matrix (column offset applied by caller) into LDS, zero-fill pad rows
@@ -185,11 +189,14 @@ template <class G> constexpr int bwd_lds() {               // 197 tokens: 152320
 }
 
 template <class G>
-__global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+__global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
                                                         const bf16* out, long ldout, const float* lse, int nprob,
                                                         bf16* dqkv, long lddq, float scale) {
     constexpr int NTOK = G::NTOK, NKT = G::NKT, NKS = G::NKS, TILE_ROWS = G::TILE_ROWS, MAT_BYTES = G::MAT_BYTES;
     constexpr int S_BYTES = TILE_ROWS * SROW;
+    constexpr int NWAVES = G::BWD_THREADS / 64, RPP = G::BWD_THREADS / 8;      // RPP: rows staged per pass
+    constexpr int DQ_FIRST = NWAVES >= 16 ? 8 : 0, DQ_WAVES = NWAVES - DQ_FIRST;
+    static_assert(NKT <= NWAVES, "one key tile per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const sQ = smem;
     char* const sO = smem + MAT_BYTES;
@@ -209,8 +216,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
         {
             const int cch = tid & 7, r0 = tid >> 3;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = r0 + 128 * i;
+            for (int i = 0; i < (TILE_ROWS + RPP - 1) / RPP; ++i) {
+                const int r = r0 + RPP * i;
                 if (r < TILE_ROWS) {
                     const bool ok = r < NTOK;
                     const u32x4 z = {0, 0, 0, 0};
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
             }
         }
         // this wave's key tile: K and V fragments in registers (key on the lane)
-        const int kt = wid;                                // waves 13..15 own no key tile
+        const int kt = wid;                                // waves >= NKT own no key tile
         const int key = kt * 16 + li;
         bf16x8 fk[2], fv[2];
         if (kt < NKT) {
@@ -280,13 +287,14 @@ __global__ __launch_bounds__(1024) void attn_bwd_kernel(const bf16* qkv, long ld
                 }
             } else if constexpr (NKT & 1) {                 // the last 16 rows of the dS image belong to no key tile
                 if (qs < 2) {
-                    for (int i = lane + 64 * (wid - NKT); i < 16 * SROW / 8; i += 64 * (16 - NKT))
+                    for (int i = lane + 64 * (wid - NKT); i < 16 * SROW / 8; i += 64 * (NWAVES - NKT))
                         *(u32x2*)(sS + qs * S_BYTES + NKT * 16 * SROW + i * 8) = u32x2{0, 0};
                 }
             }
             __syncthreads();                                // dS of this query step is complete
-            if (wid >= 8) {                                 // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  (uniform branch)
-                const int w = wid - 8, qt = w >> 2, dt = w & 3;
+            if (wid >= DQ_FIRST)                            // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  (uniform branch)
+            for (int w = wid - DQ_FIRST; w < 8; w += DQ_WAVES) {
+                const int qt = w >> 2, dt = w & 3;
                 f32x4 o = {0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
@@ -348,8 +356,10 @@ int launch_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const v
     if (set_lds<G>(attn_bwd_kernel<G>, bwd_lds<G>())) return SAIS_ERR_LAUNCH;
     const int nprob = frames * NH;
     // short sequences leave most of the LDS free: several workgroups per CU
-    const int cap = 256 * (160 * 1024 / bwd_lds<G>() > 2 ? 2 : 1);
-    hipLaunchKernelGGL(attn_bwd_kernel<G>, dim3(nprob < cap ? nprob : cap), dim3(1024), bwd_lds<G>(), (hipStream_t)stream,
+    int per_cu = 160 * 1024 / bwd_lds<G>();                       // resident workgroups per CU (LDS-limited)
+    per_cu = G::BWD_THREADS == 1024 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int cap = 256 * per_cu;
+    hipLaunchKernelGGL(attn_bwd_kernel<G>, dim3(nprob < cap ? nprob : cap), dim3(G::BWD_THREADS), bwd_lds<G>(), (hipStream_t)stream,
                        (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse, nprob,
                        (bf16*)dqkv, lddqkv, 0.125f);
     return sais_check_launch();

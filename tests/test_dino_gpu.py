@@ -363,15 +363,20 @@ def test_train_steps_vs_reference_golden(gstep):
         assert torch.equal(pa.exp_avg, pb.exp_avg) and torch.equal(pa.exp_avg_sq, pb.exp_avg_sq)
 
 
-def test_train_step_gradients_vs_oracle_with_droppath():
-    """One step at the reference's default multi-crop shape (2 global + 8 local crops), out_dim 4096, depth 2, B = 3, with
-    DropPath 0.1 on the student: the HIP step's pre-clip gradients against the fp64 oracle fed the SAME DropPath draws."""
+@pytest.mark.parametrize("n_local,norm_last_layer", [(8, True), (0, False)])
+def test_train_step_gradients_vs_oracle_with_droppath(n_local, norm_last_layer):
+    """One step at the reference's default multi-crop shape (2 global + 8 local crops) and at `--local_crops_number 0
+    --norm_last_layer false` (weight_g trainable), out_dim 4096, depth 2, B = 3, with DropPath 0.1 on the student: the HIP
+    step's pre-clip gradients against the fp64 oracle fed the SAME DropPath draws."""
     from oracle import dino_oracle as do
     from sais_amd import dino
-    out_dim, n_local, B, depth = 4096, 8, 3, 2
+    out_dim, B, depth = 4096, 3, 2
     sd = {"backbone." + k: v for k, v in synth.vit_state_dict(seed=23, depth=depth).items()}
     sd.update({"head." + k: v for k, v in synth.dino_head_state_dict(seed=24, out_dim=out_dim).items()})
-    student, teacher = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=0.1, device=DEV, depth=depth)
+    student, teacher = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=0.1, norm_last_layer=norm_last_layer,
+                                                  device=DEV, depth=depth)
+    if not norm_last_layer:
+        sd["head.last_layer.weight_g"] = 1.0 + 0.2 * torch.randn(out_dim, 1, generator=synth._gen(6))
     student.load_state_dict(sd)
     teacher.load_state_dict(student.state_dict())
     student.train()
@@ -390,9 +395,9 @@ def test_train_step_gradients_vs_oracle_with_droppath():
         loss = loss_mod(s_out, t_out, 1)
         student.backbone.flat.grad.zero_(); student.head.flat.grad.zero_()
         student.backward_kernels(saved, loss_mod.dlogits)
-    assert any((s == 0).any() for s in scales)                        # some branches really dropped
+    assert n_local == 0 or any((s == 0).any() for s in scales)        # some branches really dropped
     st = do.TrainState(sd)
-    leaves = {k: v.clone().requires_grad_(k != "head.last_layer.weight_g") for k, v in st.student.items()}
+    leaves = {k: v.clone().requires_grad_(k != "head.last_layer.weight_g" or not norm_last_layer) for k, v in st.student.items()}
     crops = [t.double().cpu() for t in images]
     with torch.no_grad():
         t_ref = do.multicrop_forward(st.teacher, crops[:2], depth)
@@ -410,6 +415,7 @@ def test_train_step_gradients_vs_oracle_with_droppath():
             e = rel(mod.flat.g(n), leaves[who + n].grad)
             worst = max(worst, e)
             assert e < 3e-2, (who + n, e)
+    assert student.head.last_layer.weight_g.requires_grad == (not norm_last_layer)
     parity_log("dino_step_grad_rel_l2", worst, 3e-2)
 
 
