@@ -386,9 +386,11 @@ int sais_pos_interp_bwd(const float* Wm, int nout, int nin, const float* dout, i
 
 /* The optimizer tail of train_one_epoch over one flat parameter buffer (sais_amd/flat.py), cut by the host into chunks
  * of <= sais_opt_chunk_elems() elements that never straddle a tensor ("segment").
- * sais_grad_norms: norms[seg] = ||grad of tensor seg||_2 — what utils.clip_gradients computes per parameter (:135-136);
- *   seg_first_chunk int [nseg + 1]; partial_ws f32 [nchunks].
+ * sais_grad_norms: norms[seg] = scale * ||grad of tensor seg||_2 — what utils.clip_gradients computes per parameter
+ *   (:135-136); seg_first_chunk int [nseg + 1]; partial_ws f32 [nchunks].  scale / SaisAdamW.grad_scale = 1 / world_size
+ *   when `grad` holds the all-reduced SUM over the data-parallel ranks (DDP averages, main_dino.py:413), else 1.
  * sais_adamw_ema_step, per element of every chunk, in this order:
+ *   scale  g *= grad_scale
  *   clip   g *= min(1, clip / (norm + 1e-6))                       utils.py:137-140  (clip = 0: off, main_dino.py:547)
  *   AdamW  p *= 1 - lr * wd (segments flagged SAIS_OPT_DECAY: the `regularized` group, utils.py:633-645; the others
  *          decay 0);  m = lerp(m, g, 1 - beta1);  v = beta2 v + (1 - beta2) g^2;
@@ -410,10 +412,11 @@ typedef struct SaisAdamW {
     float clip, lr, weight_decay, beta1, beta2, eps;
     float bc1[2], sqrt_bc2[2]; int frozen1;
     float ema_m;
+    float grad_scale;
 } SaisAdamW;
 int sais_opt_chunk_elems(void);
 int sais_grad_norms(const float* grad, const SaisOptChunk* chunks, int nchunks, const int* seg_first_chunk, int nseg,
-                    float* partial_ws, float* norms, void* stream);
+                    float scale, float* partial_ws, float* norms, void* stream);
 int sais_adamw_ema_step(const SaisAdamW* a, void* stream);
 
 #ifdef __cplusplus

@@ -53,7 +53,7 @@ class SaisAdamW(ctypes.Structure):
                 ("teacher", c_void_p), ("param16", c_void_p), ("teacher16", c_void_p),
                 ("chunks", c_void_p), ("nchunks", c_int), ("seg_flags", c_void_p), ("norms", c_void_p),
                 ("clip", c_float), ("lr", c_float), ("weight_decay", c_float), ("beta1", c_float), ("beta2", c_float),
-                ("eps", c_float), ("bc1", c_float * 2), ("sqrt_bc2", c_float * 2), ("frozen1", c_int), ("ema_m", c_float)]
+                ("eps", c_float), ("bc1", c_float * 2), ("sqrt_bc2", c_float * 2), ("frozen1", c_int), ("ema_m", c_float), ("grad_scale", c_float)]
 
 
 OPT_DECAY, OPT_CLASS1, OPT_NO_GRAD = 1, 2, 4
@@ -143,7 +143,7 @@ SIGNATURES = {
     "sais_pos_interp_fwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "sais_pos_interp_bwd": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "sais_opt_chunk_elems": [],
-    "sais_grad_norms": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "sais_grad_norms": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "sais_adamw_ema_step": [ctypes.POINTER(SaisAdamW), c_void_p],
 }
 

@@ -300,13 +300,14 @@ __global__ __launch_bounds__(256) void seg_sqnorm_partial_kernel(const float* gr
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 // norms[seg] = sqrt(sum of the tensor's chunk partials), one wave per tensor, fixed order, double accumulation
-__global__ __launch_bounds__(64) void seg_sqnorm_final_kernel(const float* partial, const int* seg_first_chunk, float* norms) {
+__global__ __launch_bounds__(64) void seg_sqnorm_final_kernel(const float* partial, const int* seg_first_chunk, float scale,
+                                                              float* norms) {
     const int seg = blockIdx.x, c0 = seg_first_chunk[seg], c1 = seg_first_chunk[seg + 1];
     double s = 0.0;
     for (int c = c0 + threadIdx.x; c < c1; c += 64) s += (double)partial[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (threadIdx.x == 0) norms[seg] = (float)sqrt(s);
+    if (threadIdx.x == 0) norms[seg] = (float)sqrt(s) * scale;
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(SaisAdamW a) {
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(SaisAdamW a) {
         const long o = ch.off + i;
         f32x4 p = *(const f32x4*)(a.param + o);
         if (update) {
-            const f32x4 g = *(const f32x4*)(a.grad + o) * coef;
+            const f32x4 g = *(const f32x4*)(a.grad + o) * (coef * a.grad_scale);
             f32x4 m = *(const f32x4*)(a.exp_avg + o), v = *(const f32x4*)(a.exp_avg_sq + o);
             p *= decay;
             m += (g - m) * om1;
@@ -468,11 +469,11 @@ extern "C" int sais_pos_interp_bwd(const float* Wm, int nout, int nin, const flo
 extern "C" int sais_opt_chunk_elems(void) { return CHUNK; }
 
 extern "C" int sais_grad_norms(const float* grad, const SaisOptChunk* chunks, int nchunks, const int* seg_first_chunk,
-                               int nseg, float* partial_ws, float* norms, void* stream) {
+                               int nseg, float scale, float* partial_ws, float* norms, void* stream) {
     SAIS_ENTER();
     if (!grad || !chunks || !seg_first_chunk || !partial_ws || !norms || nchunks <= 0 || nseg <= 0) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(seg_sqnorm_partial_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, grad, chunks, partial_ws);
-    hipLaunchKernelGGL(seg_sqnorm_final_kernel, dim3(nseg), dim3(64), 0, (hipStream_t)stream, partial_ws, seg_first_chunk, norms);
+    hipLaunchKernelGGL(seg_sqnorm_final_kernel, dim3(nseg), dim3(64), 0, (hipStream_t)stream, partial_ws, seg_first_chunk, scale, norms);
     return sais_check_launch();
 }
 

@@ -221,12 +221,24 @@ class MultiCropWrapper(nn.Module):
         logits, hsaved = self.head.forward_kernels(feat, save)
         return logits, (saved, hsaved, [t.shape[0] for t in feats]) if save else None
 
-    def backward_kernels(self, saved, dlogits):
+    def backward_kernels(self, saved, dlogits, sync=None):
+        """sync (sais_amd.parallel.GradSync, data parallel): every slice of the two flat gradient buffers is handed to an
+        asynchronous all-reduce the moment it is final — the head's right after the head backward, the backbone's block by
+        block during the LAST resolution group's backward (the groups accumulate into the same buffer) — so that the
+        exchange overlaps the remaining backward kernels; the caller joins with sync.wait() before the optimizer."""
         bsaved, hsaved, rows = saved
+        bb = self.backbone
         dfeat = self.head.backward_kernels(hsaved, dlogits)
+        if sync is not None:
+            sync._reduce(self.head.flat.grad)
         lo = 0
-        for sv, r in zip(bsaved, rows):
-            self.backbone._backward_kernels(sv, dfeat[lo:lo + r].contiguous())
+        for gi, (sv, r) in enumerate(zip(bsaved, rows)):
+            if sync is not None and gi == len(rows) - 1:
+                bb.grad_ready_hook = lambda a, b: sync._reduce(bb.flat.grad[a:b])
+            try:
+                bb._backward_kernels(sv, dfeat[lo:lo + r].contiguous())
+            finally:
+                bb.grad_ready_hook = None
             lo += r
 
 
@@ -313,11 +325,11 @@ class _FlatAdamW:
         self.norms = torch.zeros(self.nseg, dtype=F32, device=dev)
         self.flags = flags
 
-    def grad_norms(self):
-        ops.grad_norms(self.flat.grad, self.chunks, self.nchunks, self.seg_first, self.nseg, self.partial, self.norms)
+    def grad_norms(self, scale=1.0):
+        ops.grad_norms(self.flat.grad, self.chunks, self.nchunks, self.seg_first, self.nseg, self.partial, self.norms, scale)
         return self.norms
 
-    def step(self, clip, lr, wd, betas, eps, steps, frozen1, ema_m, with_shadow):
+    def step(self, clip, lr, wd, betas, eps, steps, frozen1, ema_m, with_shadow, grad_scale=1.0):
         a = L.SaisAdamW()
         f, t = self.flat, self.teacher_flat
         a.param, a.grad = f.flat.data_ptr(), f.grad.data_ptr()
@@ -333,7 +345,7 @@ class _FlatAdamW:
             s = max(steps[c], 1)
             a.bc1[c] = 1.0 - betas[0] ** s
             a.sqrt_bc2[c] = math.sqrt(1.0 - betas[1] ** s)
-        a.frozen1, a.ema_m = int(frozen1), float(ema_m)
+        a.frozen1, a.ema_m, a.grad_scale = int(frozen1), float(ema_m), float(grad_scale)
         ops.adamw_ema_step(a)
 
 
@@ -350,6 +362,7 @@ class DINOOptimizer:
                              dict(params=groups[1]['params'], lr=1e-3, weight_decay=0., betas=betas, eps=eps)]
         self.steps = [0, 0]                  # class 0: everything but the last layer; class 1: head.last_layer.*
         self._parts = None
+        self.grad_scale = 1.0                # 1 / world when the flat gradients hold the all-reduced SUM over the ranks
 
     def _build(self):
         sb, sh = self.student.backbone, self.student.head
@@ -374,7 +387,7 @@ class DINOOptimizer:
             self._build()
         out = []
         for part, _ in self._parts:
-            norms = part.grad_norms()
+            norms = part.grad_norms(self.grad_scale)
             keep = [i for i, fl in enumerate(part.flags) if not fl & L.OPT_NO_GRAD]
             out.append(norms[keep])
         return torch.cat(out)
@@ -390,7 +403,7 @@ class DINOOptimizer:
             self.steps[1] += 1
         for part, shadow in self._parts:
             part.step(clip_grad, lr, wd, self.betas, self.eps, self.steps, frozen_last_layer,
-                      1.0 if ema_momentum is None else ema_momentum, shadow)
+                      1.0 if ema_momentum is None else ema_momentum, shadow, self.grad_scale)
         for mod in (self.student, self.teacher):
             if mod is None:
                 continue
@@ -472,13 +485,6 @@ def build_student_teacher(out_dim=65536, drop_path_rate=0.1, norm_last_layer=Tru
     return student, teacher
 
 
-def _sync_grads(student, world):
-    """DistributedDataParallel's gradient averaging (main_dino.py:413) on the two flat gradient buffers."""
-    for m in (student.backbone, student.head):
-        dist.all_reduce(m.flat.grad)
-        ops.scale_(m.flat.grad, 1.0 / world)
-
-
 def train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_schedule, wd_schedule, momentum_schedule,
                clip_grad=3.0, freeze_last_layer=1, want_norms=False):
     """One iteration of train_one_epoch's loop body (main_dino.py:521-566).  Returns (loss 0-dim device tensor,
@@ -492,9 +498,17 @@ def train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_sch
         student_output, saved = student.forward_kernels(images, save=True)           # :536
         loss = dino_loss(student_output, teacher_output, epoch)                      # :537
         optimizer.zero_grad()                                                        # :544
-        student.backward_kernels(saved, dino_loss.dlogits)                           # :547
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            _sync_grads(student, dist.get_world_size())
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        sync = None
+        if world > 1:                        # DistributedDataParallel's gradient averaging (:413): SUM here, 1 / world
+            sync = getattr(optimizer, "_sync", None)                                 # inside the optimizer kernels
+            if sync is None or sync.world != world:
+                from .parallel import GradSync
+                sync = optimizer._sync = GradSync(world)
+        optimizer.grad_scale = 1.0 / world
+        student.backward_kernels(saved, dino_loss.dlogits, sync)                     # :547
+        if sync is not None:
+            sync.wait()
         norms = None
         if clip_grad or want_norms:
             norms = clip_gradients(optimizer, clip_grad)                             # :548-549

@@ -486,8 +486,8 @@ def pos_interp_bwd(Wm, dout, dpos):
     L.call("sais_pos_interp_bwd", _p(Wm), Wm.shape[0], Wm.shape[1], _p(dout), dout.shape[-1], _p(dpos), _stream())
 
 
-def grad_norms(grad, chunks, nchunks, seg_first, nseg, partial, norms):
-    L.call("sais_grad_norms", _p(grad), _p(chunks), nchunks, _p(seg_first), nseg, _p(partial), _p(norms), _stream())
+def grad_norms(grad, chunks, nchunks, seg_first, nseg, partial, norms, scale=1.0):
+    L.call("sais_grad_norms", _p(grad), _p(chunks), nchunks, _p(seg_first), nseg, float(scale), _p(partial), _p(norms), _stream())
 
 
 def adamw_ema_step(desc):
