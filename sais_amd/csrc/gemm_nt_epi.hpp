@@ -62,11 +62,16 @@ DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], cons
     float y[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) y[i] = v[i] + b[i];
-    auto store_bf16 = [&](void* base, int ld, const float (&z)[8]) {
+#ifndef SAIS_NT_STORE
+#define SAIS_NT_STORE 0          // experiment switch: 1 = GELU' (read again only in backward) non-temporal, 2 = every bf16 output
+#endif
+    auto store_bf16 = [&](void* base, int ld, const float (&z)[8], int level = 2) {
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = (bf16)z[i];
-        *(bf16x8*)((bf16*)base + (size_t)m * ld + n) = o;
+        bf16x8* dst = (bf16x8*)((bf16*)base + (size_t)m * ld + n);
+        if (SAIS_NT_STORE >= level) __builtin_nontemporal_store(o, dst);
+        else *dst = o;
     };
     auto store_f32 = [&](void* base, int ld, const float (&z)[8]) {
         float* o = (float*)base + (size_t)m * ld + n;
@@ -100,7 +105,7 @@ DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], cons
     } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) {
         float d[8];
         gelu_and_grad_n(y, d);
-        store_bf16(p.out2, p.ldo2, d);
+        store_bf16(p.out2, p.ldo2, d, 1);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
 #pragma unroll

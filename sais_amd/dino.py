@@ -209,37 +209,30 @@ class MultiCropWrapper(nn.Module):
         return self.forward_kernels(x, save=False)[0]
 
     def forward_kernels(self, x, save):
+        """All resolution groups go through the backbone in ONE pass (rows stacked: sais_amd.vit._forward_kernels), the
+        features come back in crop order, exactly the concatenation utils.py:626 builds."""
         bb = self.backbone
-        feats, saved = [], []
-        for g in self._groups(x):
-            g = bb._check_input(g)
-            bb._engine(g.device)
-            rep, sv = bb._forward_kernels(g, save=save)
-            feats.append(rep)
-            saved.append(sv)
-        feat = torch.cat(feats) if len(feats) > 1 else feats[0]
+        groups = [bb._check_input(g) for g in self._groups(x)]
+        bb._engine(groups[0].device)
+        feat, bsaved = bb._forward_kernels(groups if len(groups) > 1 else groups[0], save=save)
         logits, hsaved = self.head.forward_kernels(feat, save)
-        return logits, (saved, hsaved, [t.shape[0] for t in feats]) if save else None
+        return logits, (bsaved, hsaved) if save else None
 
     def backward_kernels(self, saved, dlogits, sync=None):
         """sync (sais_amd.parallel.GradSync, data parallel): every slice of the two flat gradient buffers is handed to an
         asynchronous all-reduce the moment it is final — the head's right after the head backward, the backbone's block by
-        block during the LAST resolution group's backward (the groups accumulate into the same buffer) — so that the
-        exchange overlaps the remaining backward kernels; the caller joins with sync.wait() before the optimizer."""
-        bsaved, hsaved, rows = saved
+        block (last block first) — so that the exchange overlaps the remaining backward kernels; the caller joins with
+        sync.wait() before the optimizer."""
+        bsaved, hsaved = saved
         bb = self.backbone
         dfeat = self.head.backward_kernels(hsaved, dlogits)
         if sync is not None:
             sync._reduce(self.head.flat.grad)
-        lo = 0
-        for gi, (sv, r) in enumerate(zip(bsaved, rows)):
-            if sync is not None and gi == len(rows) - 1:
-                bb.grad_ready_hook = lambda a, b: sync._reduce(bb.flat.grad[a:b])
-            try:
-                bb._backward_kernels(sv, dfeat[lo:lo + r].contiguous())
-            finally:
-                bb.grad_ready_hook = None
-            lo += r
+            bb.grad_ready_hook = lambda a, b: sync._reduce(bb.flat.grad[a:b])
+        try:
+            bb._backward_kernels(bsaved, dfeat)
+        finally:
+            bb.grad_ready_hook = None
 
 
 # --------------------------------------------------------------------------- DINOLoss

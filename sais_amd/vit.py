@@ -225,22 +225,36 @@ class VisionTransformer(nn.Module):
 
     # ------------------------------------------------------------------ forward kernels
     def _forward_kernels(self, img, save, want_last_attn=False):
+        """img: one [F,3,S,S] tensor, or a LIST of them with different S (DINO's multi-crop student, utils.py:611-630):
+        the groups are then stacked along the token-row axis and every GEMM / LayerNorm of a block runs ONCE over all rows
+        (only attention, the embedding glue and the final CLS gather are per group) — 44 160 rows in one launch fill the
+        chip where 25 216 + 18 944 in two launches leave workgroup slots empty.  Returns reps f32 [sum F, 384] in group
+        order."""
         f = self.flat
-        dev = img.device
-        Fr, side = img.shape[0], img.shape[-1]
-        ntok = SIDES[side]
-        M = Fr * ntok
+        imgs = list(img) if isinstance(img, (list, tuple)) else [img]
+        dev = imgs[0].device
         e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         e32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-        patches = e16(Fr * (ntok - 1), PATCH_K)
-        ops.patchify(img, patches)
-        x = e32(Fr, ntok, D)
-        pos, interp = self._pos_table(side, dev)
-        ops.gemm_nt(patches, f.w("patch_embed.proj.weight").view(D, PATCH_K), L.EPI_PATCH_F32, x,
-                    bias=f.w32("patch_embed.proj.bias"), aux=pos, grp=(ntok - 1, ntok, 1))
-        ops.vit_cls_rows(f.w32("cls_token"), pos, x, Fr, ntok)
-        x = x.view(M, D)
-        saved = {"patches": patches, "blocks": [], "Fr": Fr, "ntok": ntok, "interp": interp} if save else None
+        groups, off, poff, foff = [], 0, 0, 0          # per group: frames, tokens, row / patch-row / frame offsets, interp map
+        for im in imgs:
+            Fr, ntok = im.shape[0], SIDES[im.shape[-1]]
+            groups.append(dict(Fr=Fr, ntok=ntok, off=off, poff=poff, foff=foff, interp=None))
+            off, poff, foff = off + Fr * ntok, poff + Fr * (ntok - 1), foff + Fr
+        M, NP, Ftot = off, poff, foff
+        if want_last_attn and len(groups) > 1:
+            raise ValueError("get_last_selfattention takes one resolution")
+        patches = e16(NP, PATCH_K)
+        x = e32(M, D)
+        for im, g in zip(imgs, groups):
+            Fr, ntok = g["Fr"], g["ntok"]
+            pg = patches[g["poff"]:g["poff"] + Fr * (ntok - 1)]
+            xg = x[g["off"]:g["off"] + Fr * ntok].view(Fr, ntok, D)
+            ops.patchify(im, pg)
+            pos, g["interp"] = self._pos_table(im.shape[-1], dev)
+            ops.gemm_nt(pg, f.w("patch_embed.proj.weight").view(D, PATCH_K), L.EPI_PATCH_F32, xg,
+                        bias=f.w32("patch_embed.proj.bias"), aux=pos, grp=(ntok - 1, ntok, 1))
+            ops.vit_cls_rows(f.w32("cls_token"), pos, xg, Fr, ntok)
+        saved = {"patches": patches, "blocks": [], "groups": groups, "M": M, "Ftot": Ftot} if save else None
         # Large M (training step, big extraction batches): the N = 384 GEMMs run on the row-owning kernel with the
         # FOLLOWING LayerNorm in their epilogue (sais_gemm_ln_fwd): proj -> norm2, fc2 -> the next block's norm1.
         # Only block 0's norm1 and the final norm remain stand-alone launches.
@@ -253,8 +267,11 @@ class VisionTransformer(nn.Module):
                 self._rng = ops.rng_state(self.drop_path_seed, dev)
                 rates = torch.linspace(0, self.drop_path_rate, self.depth).repeat_interleave(2)      # :150
                 self._dp_rates = rates.to(dev, torch.float32)
-            ops.rng_advance(self._rng)
-            dp = ops.droppath_scales(self._dp_rates, Fr, ntok, self._rng)
+            parts = []
+            for g in groups:                             # one advance + draw per group (what separate passes would do)
+                ops.rng_advance(self._rng)
+                parts.append(ops.droppath_scales(self._dp_rates, g["Fr"], g["ntok"], self._rng))
+            dp = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
             self.last_droppath_scales = dp
         if saved is not None:
             saved["dp"] = dp
@@ -272,9 +289,13 @@ class VisionTransformer(nn.Module):
                 ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
                                   rstd=rstd1)
             ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
-            lse = e32(Fr, HEADS, ntok) if save else None
-            probs = e32(Fr, HEADS, ntok, ntok) if last_attn else None
-            ops.vit_attn_fwd(qkv, Fr, ao, lse, probs, ntok=ntok)
+            lse, probs = [], None
+            for g in groups:
+                Fr, ntok, lo = g["Fr"], g["ntok"], g["off"]
+                lg = e32(Fr, HEADS, ntok) if save else None
+                probs = e32(Fr, HEADS, ntok, ntok) if last_attn else None
+                ops.vit_attn_fwd(qkv[lo:lo + Fr * ntok], Fr, ao[lo:lo + Fr * ntok], lg, probs, ntok=ntok)
+                lse.append(lg)
             if last_attn:
                 return probs, None
             x_mid = e32(M, D) if save else x
@@ -310,11 +331,14 @@ class VisionTransformer(nn.Module):
             if save:
                 saved["blocks"].append(blk)
             x = x_out
-        reps = e32(Fr, D)
-        meanN = e32(Fr) if save else None
-        rstdN = e32(Fr) if save else None
-        ops.layernorm_fwd(x, Fr, ntok * D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN,
-                          rstd=rstdN)
+        reps = e32(Ftot, D)
+        meanN = e32(Ftot) if save else None
+        rstdN = e32(Ftot) if save else None
+        for g in groups:                                 # final norm on the CLS rows only (row stride = ntok * 384)
+            Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
+            ops.layernorm_fwd(x[lo:lo + Fr * ntok], Fr, ntok * D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6,
+                              y32=reps[fo:fo + Fr], mean=None if meanN is None else meanN[fo:fo + Fr],
+                              rstd=None if rstdN is None else rstdN[fo:fo + Fr])
         if save:
             saved.update(x_final=x, meanN=meanN, rstdN=rstdN)
         return reps, saved
@@ -324,13 +348,16 @@ class VisionTransformer(nn.Module):
         f = self.flat
         f.attach_grads()
         dev = dreps.device
-        Fr, ntok = saved["Fr"], saved["ntok"]
-        M = Fr * ntok
+        groups, M = saved["groups"], saved["M"]
         e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         dxa, dxb = e16(M, D), e16(M, D)            # bf16 copies of the residual-stream gradient (block input / mid)
-        ops.layernorm_bwd(saved["x_final"], ntok * D, saved["meanN"], saved["rstdN"], f.w32("norm.weight"), Fr,
-                          dy32=dreps, dx32=dx, lddx32=ntok * D, dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
+        for g in groups:
+            Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
+            ops.layernorm_bwd(saved["x_final"][lo:lo + Fr * ntok], ntok * D, saved["meanN"][fo:fo + Fr],
+                              saved["rstdN"][fo:fo + Fr], f.w32("norm.weight"), Fr, dy32=dreps[fo:fo + Fr],
+                              dx32=dx[lo:lo + Fr * ntok], lddx32=ntok * D, dgamma=f.g("norm.weight"),
+                              dbeta=f.g("norm.bias"))
         dp = saved.get("dp")
         # with DropPath the gradient that enters a branch is s dx (the residual stream keeps dx): the bf16 copies carry the
         # NEXT branch's scale — dxa feeds an MLP branch (2i + 1), dxb an attention branch (2i)
@@ -340,7 +367,6 @@ class VisionTransformer(nn.Module):
             ops.cast_bf16_rows(dx, dp[2 * (self.depth - 1) + 1], dxa)
         fused = M >= ops.ROW_GEMM_MIN_M
         dxn, dao, du, dqkv = (None if fused else e16(M, D)), e16(M, D), e16(M, HID), e16(M, 3 * D)
-        delta = torch.empty(Fr, HEADS, ntok, dtype=torch.float32, device=dev)
         if self.grad_ready_hook:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
         for i in reversed(range(self.depth)):
@@ -361,7 +387,10 @@ class VisionTransformer(nn.Module):
                                   rowscale16=rs_attn)
             # attention branch
             ops.gemm_nt(dxb, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
-            ops.vit_attn_bwd(s["qkv"], dao, s["ao"], s["lse"], delta, Fr, dqkv, ntok=ntok)
+            for g, lg in zip(groups, s["lse"]):
+                Fr, ntok, lo = g["Fr"], g["ntok"], g["off"]
+                hi = lo + Fr * ntok
+                ops.vit_attn_bwd(s["qkv"][lo:hi], dao[lo:hi], s["ao"][lo:hi], lg, None, Fr, dqkv[lo:hi], ntok=ntok)
             # all four weight / bias gradients of the block in one launch.  (A side stream for this launch was measured
             # in round 1: 20.4 vs 19.6 ms/step — both kernels fill the chip — and removed.)
             ops.gemm_tn_grouped([
@@ -381,13 +410,16 @@ class VisionTransformer(nn.Module):
             saved["blocks"][i] = None
             if self.grad_ready_hook:                  # the block's gradient slice is final: DP all-reduce may start
                 self.grad_ready_hook(*self.block_grad_range(i))
-        dpatch = e16(Fr * (ntok - 1), D)
-        if saved["interp"] is None:
-            ops.vit_embed_bwd(dx, Fr, f.g("cls_token"), f.g("pos_embed"), dpatch)
-        else:                                       # through the transpose of the bicubic map (autograd of :174-194)
-            dpos = torch.zeros(ntok, D, dtype=torch.float32, device=dev)
-            ops.vit_embed_bwd(dx, Fr, f.g("cls_token"), dpos, dpatch, ntok=ntok)
-            ops.pos_interp_bwd(saved["interp"], dpos, f.g("pos_embed").view(NTOK, D))
+        dpatch = e16(saved["patches"].shape[0], D)
+        for g in groups:
+            Fr, ntok, lo, po = g["Fr"], g["ntok"], g["off"], g["poff"]
+            dxg, dpg = dx[lo:lo + Fr * ntok], dpatch[po:po + Fr * (ntok - 1)]
+            if g["interp"] is None:
+                ops.vit_embed_bwd(dxg, Fr, f.g("cls_token"), f.g("pos_embed"), dpg)
+            else:                                   # through the transpose of the bicubic map (autograd of :174-194)
+                dpos = torch.zeros(ntok, D, dtype=torch.float32, device=dev)
+                ops.vit_embed_bwd(dxg, Fr, f.g("cls_token"), dpos, dpg, ntok=ntok)
+                ops.pos_interp_bwd(g["interp"], dpos, f.g("pos_embed").view(NTOK, D))
         ops.gemm_tn(dpatch, saved["patches"], f.g("patch_embed.proj.weight").view(D, PATCH_K),
                     f.g("patch_embed.proj.bias"))
         if self.grad_ready_hook:
