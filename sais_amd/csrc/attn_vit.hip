@@ -183,7 +183,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
 // dQ^T = K^T dS^T for the 32 queries of the step — complete over all keys, so dQ goes straight to HBM.
 // delta_q = sum_d dO O is computed while staging.  Five MFMA products per (query, key) tile instead of seven, one
 // exponential instead of two, every operand staged once (the two-kernel version re-staged K, V, Q, dO: 470 vs 348 MB).
-constexpr int SROW = 96;                                   // bytes per key row of the dS image (32 queries bf16 + pad)
+#ifndef SAIS_ATTN_SROW
+#define SAIS_ATTN_SROW 96
+#endif
+constexpr int SROW = SAIS_ATTN_SROW;                       // bytes per key row of the dS image (32 queries bf16 + pad)
 template <class G> constexpr int bwd_lds() {               // 197 tokens: 152320
     return 3 * G::MAT_BYTES + 2 * G::TILE_ROWS * 4 + 2 * G::TILE_ROWS * SROW;
 }
