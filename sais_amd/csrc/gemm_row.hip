@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_row_kernel(RowParams p) {
         for (int j = 0; j < NA; ++j) {
             const int r = 8 * (NA * (SPEC ? wq : wid) + j) + sub;    // LDS row of the slot
             const int rt = 112 * (r >> 7) + (r & 127);               // tile row (LDS rows 112..127 of a half are never read)
-            int m = (r & 127) < 112 ? m0 + rt : m0;
+            int m = ((r & 127) < 112 && rt < p.rows_per_tile) ? m0 + rt : m0;   // rows past the tile: one L2-hot row
             m = m < p.M ? m : p.M - 1;                               // clamp: rows outside the tile are never stored
             aoff[j] = ((unsigned)m * (unsigned)p.lda + schunk * 8) * 2u;
         }
@@ -533,7 +533,10 @@ int rows_per_tile(int M) {
     constexpr int cap = 112 * (NW / 4), slots = NW == 4 ? 512 : 256;
     const int rounds = (M + slots * cap - 1) / (slots * cap);
     int rows = (M + slots * rounds - 1) / (slots * rounds);
-    if (rows < cap / 2 + 8) rows = cap;
+    // few rows per workgroup waste MFMA row tiles (all RMT are always computed); many-row tiles leave workgroup slots
+    // empty.  SAIS_ROW_MINROWS overrides the switch-over for A/B measurements.
+    static const int minrows = [] { const char* e = getenv("SAIS_ROW_MINROWS"); return e ? atoi(e) : 0; }();
+    if (rows < (minrows > 0 ? minrows : cap / 2 + 8)) rows = cap;
     return rows;
 }
 
