@@ -247,11 +247,15 @@ def dino_main(args):
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # SAIS_BENCH_FORCE_DIST=1 under torchrun --nproc-per-node 1: RCCL with a world of one, every all-reduce of the DP path issued
+    force = os.environ.get("SAIS_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    dist_on = world > 1 or force
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from sais_amd import dino, ops
+    dino.FORCE_SYNC = force
     B, nl, out_dim = args.dino_batch, args.dino_local_crops, args.dino_out_dim
     torch.manual_seed(0)                                             # same initial weights on every rank
     student, teacher = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=args.vit_drop_path, device=dev)
@@ -271,20 +275,21 @@ def dino_main(args):
 
     for it in range(args.warmup):
         loss = step(it)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(args.steps):
         loss = step(args.warmup + it)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ms = dt.item() / args.steps * 1e3
     lv = loss.item()
+    comm_bytes = 4 * (student.backbone.flat.numel + student.head.flat.numel) if dist_on else 0
     ops.TIMER = ops.KernelTimer()                                    # instrumented pass after the timed region
     step(args.warmup + args.steps)
     torch.cuda.synchronize()
@@ -306,14 +311,19 @@ def dino_main(args):
                             "launches_per_step": top[1]["launches"], "avg_us": round(top[1]["avg_ms"] * 1e3, 1)},
                "kernels_ms_per_step": {k: round(v["total_ms"], 3) for k, v in
                                        sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:12]}}
-        if world == 1 and not args.no_cpu_baseline:
+        if dist_on:
+            sync = getattr(opt, "_sync", None)
+            out["comm"] = {"backend": "nccl (RCCL)", "world": world, "allreduce_bytes_per_step": comm_bytes,
+                           "overlapped_with_backward": True, "centre_allreduce_bytes": 4 * out_dim,
+                           "grad_sync": type(sync).__name__ if sync is not None else None}
+        if world == 1 and not dist_on and not args.no_cpu_baseline:
             try:
                 avail = len(os.sched_getaffinity(0))
             except AttributeError:
                 avail = os.cpu_count() or 1
             out["cpu_baseline"] = dino_cpu_baseline(args, max(1, min(avail, 32)))    # see the note in main()
         print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -29,6 +29,7 @@ from .flat import FlatParams
 from .vit import VisionTransformer, _trunc_normal_, vit_small
 
 F32 = torch.float32
+FORCE_SYNC = False        # bench.py / tests: issue the data-parallel all-reduces even with a world of one
 
 
 # --------------------------------------------------------------------------- schedules / groups (utils.py)
@@ -409,8 +410,6 @@ class DINOOptimizer:
 
     # torch.optim.AdamW-compatible checkpoint (main_dino.py:485-491: 'optimizer': optimizer.state_dict())
     def state_dict(self):
-        sb, sh = self.student.backbone, self.student.head
-        named = [("backbone." + n, p) for n, p in sb.named_parameters()] + [("head." + n, p) for n, p in sh.named_parameters()]
         index, state = {}, {}
         order = self.param_groups[0]["params"] + self.param_groups[1]["params"]
         for i, p in enumerate(order):
@@ -433,7 +432,6 @@ class DINOOptimizer:
             groups.append(dict(lr=g["lr"], betas=self.betas, eps=self.eps, weight_decay=g["weight_decay"], amsgrad=False,
                                maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
                                params=list(range(0 if gi == 0 else n0, n0 if gi == 0 else n0 + len(g["params"])))))
-        del named
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
@@ -493,11 +491,11 @@ def train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_sch
         optimizer.zero_grad()                                                        # :544
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         sync = None
-        if world > 1:                        # DistributedDataParallel's gradient averaging (:413): SUM here, 1 / world
+        if world > 1 or (FORCE_SYNC and dist.is_initialized()):   # DistributedDataParallel's gradient averaging (:413): SUM here, 1 / world
             sync = getattr(optimizer, "_sync", None)                                 # inside the optimizer kernels
             if sync is None or sync.world != world:
                 from .parallel import GradSync
-                sync = optimizer._sync = GradSync(world)
+                sync = optimizer._sync = GradSync(world, active=True)
         optimizer.grad_scale = 1.0 / world
         student.backward_kernels(saved, dino_loss.dlogits, sync)                     # :547
         if sync is not None:

@@ -573,3 +573,26 @@ def test_main_dino_cli_trains_resumes_and_feeds_the_extraction_loader(tmp_path):
     ck3 = torch.load(out / "checkpoint.pth", map_location="cpu", weights_only=False)
     k = "backbone.blocks.0.attn.qkv.weight"
     assert not torch.equal(ck3["student"]["module." + k], ck3["teacher"][k])
+
+
+def test_bench_dino_over_rccl_world_of_one():
+    """`bench.py --workload dino` under torchrun with SAIS_BENCH_FORCE_DIST=1: RCCL process group with one rank, the
+    overlapped gradient all-reduces (head buffer + per-block backbone slices from the backward hook) and the centre
+    all-reduce are really issued on the NCCL backend; the JSON line carries the exchange volume."""
+    import json
+    import subprocess
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(HERE)
+    port = 29900 + (os.getpid() % 900)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--workload", "dino", "--gpus", "1", "--steps", "2", "--warmup", "1", "--dino-batch", "4",
+                        "--dino-local-crops", "2", "--dino-out-dim", "1024"],
+                       capture_output=True, text=True, cwd=root, timeout=900,
+                       env=dict(os.environ, SAIS_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["metric"] == "dino_pretrain_images_per_s" and line["value"] > 0 and math.isfinite(line["loss"])
+    assert line["comm"]["world"] == 1 and line["comm"]["grad_sync"] == "GradSync"
+    assert line["comm"]["allreduce_bytes_per_step"] > 80e6                # 21.7 M backbone + 5.3 M head parameters, fp32

@@ -16,6 +16,8 @@ python bench.py --two-stream --no-cpu-baseline --sustain-seconds 0 > $O/bench_tw
 # the distributed branch of bench.py over RCCL with a world of one: the step INCLUDING its all-reduces is one hipGraph
 SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --sustain-seconds 0 > $O/force_dist_world1.log 2>&1; tail -c 2500 $O/force_dist_world1.log | head -c 300; echo
+SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 \
+    bench.py --workload dino --gpus 1 --steps 10 --warmup 3 > $O/force_dist_world1_dino.log 2>&1; tail -c 1200 $O/force_dist_world1_dino.log | head -c 400; echo
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dino -- python3 $R/bench.py --workload dino --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_dino.log 2>&1
