@@ -370,6 +370,10 @@ int sais_dino_center_ema(float* center, const float* colsum, int n, float moment
  * backward is du = dh * gelu'(u)), F.normalize(x, dim=-1, p=2) (eps 1e-12) and nn.utils.weight_norm of the last layer
  * (:277-281: w = g v / ||v||_row; _bwd ACCUMULATES dv and, when dg != NULL, dg).  One wave per row, dim <= 1024.      */
 int sais_gelu_fwd_f32(const float* u, float* h, long n, void* stream);
+/* bf16x3 operand image of an f32 matrix [rows, cols] for sais_gemm_nt: dst bf16 [rows, 3 * cols] = [hi | hi | lo] (A side,
+ * b_side = 0) or [hi | lo | hi] (B side), hi = bf16(x), lo = bf16(x - hi): one bf16 GEMM over K' = 3 K then sums the
+ * three products of the "bf16x3" arithmetic in fp32.  Used for the head's 256 -> 65536 last layer (the logits).        */
+int sais_split_bf16x3(const float* src, long ld, int rows, int cols, void* dst_bf16, int b_side, void* stream);
 int sais_gelu_bwd_f32(const float* dh, const float* u, float* du, long n, void* stream);
 int sais_l2norm_fwd(const float* z, int rows, int dim, float eps, float* out, float* inv, void* stream);
 int sais_l2norm_bwd(const float* dout, const float* out, const float* inv, int rows, int dim, float eps, float* dz, void* stream);

@@ -135,6 +135,7 @@ SIGNATURES = {
     "sais_dino_colsum": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p],
     "sais_dino_center_ema": [c_void_p, c_void_p, c_int, c_float, c_float, c_void_p],
     "sais_gelu_fwd_f32": [c_void_p, c_void_p, c_long, c_void_p],
+    "sais_split_bf16x3": [c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p],
     "sais_gelu_bwd_f32": [c_void_p, c_void_p, c_void_p, c_long, c_void_p],
     "sais_l2norm_fwd": [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     "sais_l2norm_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p],

@@ -161,6 +161,28 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dh, const fl
     }
 }
 
+// bf16x3 operand images for the bf16 MFMA GEMM (the 65536-wide last layer): x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+// A side [hi | hi | lo], B side [hi | lo | hi] along K, so that ONE bf16 GEMM with K' = 3 K accumulates hi.hi + hi.lo + lo.hi
+// in fp32 — the three products of sais_gemm_nt_f32 on the tuned 128 x 128 bf16 kernel instead of the small-M fp32 one.
+__global__ __launch_bounds__(256) void split3_kernel(const float* src, long ld, int rows, int K, bf16* dst, int b_side) {
+    const int k4 = K >> 2;
+    const long total = (long)rows * k4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / k4), c = 4 * (int)(i - (long)r * k4);
+        const f32x4 v = *(const f32x4*)(src + (size_t)r * ld + c);
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (bf16)v[e];
+            lo[e] = (bf16)(v[e] - (float)hi[e]);
+        }
+        bf16* d = dst + (size_t)r * 3 * K + c;
+        *(bf16x4*)d = hi;
+        *(bf16x4*)(d + K) = b_side ? lo : hi;
+        *(bf16x4*)(d + 2 * K) = b_side ? hi : lo;
+    }
+}
+
 // one wave per row of a [rows, dim] matrix (dim % 4 == 0, dim <= 1024: <= 4 float4 per lane)
 constexpr int ROWV = 4;
 DEVINL int load_row(const float* p, int dim, int lane, f32x4 (&v)[ROWV]) {
@@ -420,6 +442,14 @@ extern "C" int sais_gelu_bwd_f32(const float* dh, const float* u, float* du, lon
     SAIS_ENTER();
     if (!dh || !u || !du || n <= 0 || (n & 3)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dh, u, du, n / 4);
+    return sais_check_launch();
+}
+
+extern "C" int sais_split_bf16x3(const float* src, long ld, int rows, int cols, void* dst_bf16, int b_side, void* stream) {
+    SAIS_ENTER();
+    if (!src || !dst_bf16 || rows <= 0 || cols <= 0 || (cols & 3) || (ld & 3)) return SAIS_ERR_ARG;
+    hipLaunchKernelGGL(split3_kernel, dim3(ew_grid((long)rows * cols / 4)), dim3(256), 0, (hipStream_t)stream, src, ld, rows,
+                       cols, (bf16*)dst_bf16, b_side);
     return sais_check_launch();
 }
 

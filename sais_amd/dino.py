@@ -110,22 +110,26 @@ class DINOHead(nn.Module):
         self._sig = None
         return r
 
-    def _refresh_last_layer(self):
-        """w = g v / ||v|| and its transpose, once per parameter version (forward and dX both read them)."""
+    def _refresh_last_layer(self, need_backward=True):
+        """w = g v / ||v||, its transpose (dX) and its bf16x3 image [hi | lo | hi] (the logits GEMM), once per parameter
+        version."""
         f, dev = self.flat, self.flat.device
         if self._what is None or self._what[0].device != dev:
             self._what = (torch.empty(self.out_dim, self.bottleneck_dim, dtype=F32, device=dev),
                           torch.empty(self.bottleneck_dim, self.out_dim, dtype=F32, device=dev),
-                          torch.empty(self.out_dim, dtype=F32, device=dev))
-        w, wt, inv = self._what
+                          torch.empty(self.out_dim, dtype=F32, device=dev),
+                          torch.empty(self.out_dim, 3 * self.bottleneck_dim, dtype=torch.bfloat16, device=dev))
+        w, wt, inv, w3 = self._what
         ops.weight_norm_fwd(f.w32("last_layer.weight_v"), f.w32("last_layer.weight_g").view(-1), w, inv)
-        ops.transpose_f32(w, self.out_dim, self.bottleneck_dim, wt)
+        if need_backward:
+            ops.transpose_f32(w, self.out_dim, self.bottleneck_dim, wt)
+        ops.split_bf16x3(w, w3, True)
 
     def after_optimizer_step(self, need_backward=True):
         if need_backward:
             self.flat._transposes(self._t_names)
         self.flat.epoch += 1
-        self._refresh_last_layer()
+        self._refresh_last_layer(need_backward)
         self._sig = self.flat.signature(self._sentinels)
 
     def forward(self, x):
@@ -146,8 +150,11 @@ class DINOHead(nn.Module):
         z, zn, inv = e(R, self.bottleneck_dim), e(R, self.bottleneck_dim), e(R)
         ops.gemm_nt_f32(h2, f.w32("mlp.4.weight"), L.EPI_BIAS_F32, z, bias=f.w32("mlp.4.bias"))
         ops.l2norm_fwd(z, zn, inv)
+        # 256 -> out_dim: bf16x3 as ONE bf16 GEMM over K' = 768 ([hi | hi | lo] . [hi | lo | hi]^T, fp32 accumulation)
+        zn3 = torch.empty(R, 3 * self.bottleneck_dim, dtype=torch.bfloat16, device=dev)
+        ops.split_bf16x3(zn, zn3, False)
         logits = e(R, self.out_dim)
-        ops.gemm_nt_f32(zn, self._what[0], L.EPI_BIAS_F32, logits)
+        ops.gemm_nt(zn3, self._what[3], L.EPI_BIAS_F32, logits)
         saved = dict(x=x, u1=u1, h1=h1, u2=u2, h2=h2, zn=zn, inv=inv) if save else None
         return logits, saved
 
@@ -157,7 +164,7 @@ class DINOHead(nn.Module):
         f.attach_grads()
         dev, R = dlogits.device, dlogits.shape[0]
         e = lambda *s: torch.empty(*s, dtype=F32, device=dev)
-        w, wt, winv = self._what
+        w, wt, winv, _ = self._what
         dzn = e(R, self.bottleneck_dim)
         ops.gemm_nt_f32(dlogits, wt, L.EPI_BIAS_F32, dzn)
         dw = torch.zeros(self.out_dim, self.bottleneck_dim, dtype=F32, device=dev)
@@ -485,8 +492,10 @@ def train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_sch
         if i == 0:
             g["weight_decay"] = float(wd_schedule[it])
     with torch.no_grad():
-        teacher_output = teacher.forward_kernels(images[:2], save=False)[0]          # :535
-        student_output, saved = student.forward_kernels(images, save=True)           # :536
+        groups = student._groups(images)         # one concatenation per resolution, shared by both networks
+        two_global = groups[0] if groups[0].shape[0] == 2 * images[0].shape[0] else images[:2]
+        teacher_output = teacher.forward_kernels(two_global, save=False)[0]          # :535  teacher(images[:2])
+        student_output, saved = student.forward_kernels(groups, save=True)           # :536  student(images)
         loss = dino_loss(student_output, teacher_output, epoch)                      # :537
         optimizer.zero_grad()                                                        # :544
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

@@ -445,6 +445,12 @@ def dino_center_ema(center, colsum, momentum, inv_count):
     L.call("sais_dino_center_ema", _p(center), _p(colsum), center.numel(), float(momentum), float(inv_count), _stream())
 
 
+def split_bf16x3(src, dst, b_side):
+    """dst bf16 [rows, 3 K] = [hi | hi | lo] (A side) or [hi | lo | hi] (B side) of src f32 [rows, K]."""
+    _chk(src, F32, "src"); _chk(dst, BF16, "dst")
+    L.call("sais_split_bf16x3", _p(src), src.stride(0), src.shape[0], src.shape[1], _p(dst), 1 if b_side else 0, _stream())
+
+
 def gelu_fwd_f32(u, h):
     _chk(u, F32, "u"); _chk(h, F32, "h")
     L.call("sais_gelu_fwd_f32", _p(u), _p(h), u.numel(), _stream())

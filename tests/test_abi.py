@@ -52,4 +52,5 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_adamw_ema_step(None, None) == -1 and lib.sais_adamw_ema_step(ctypes.byref(_lib.SaisAdamW()), None) == -1
     assert lib.sais_grad_norms(None, None, 0, None, 0, 1.0, None, None, None) == -1
     assert lib.sais_weight_norm_fwd(None, None, 1, 256, None, None, None) == -1
+    assert lib.sais_split_bf16x3(None, 256, 1, 256, None, 0, None) == -1
     assert lib.sais_pos_interp_fwd(None, 36, 196, None, 384, None, None) == -1

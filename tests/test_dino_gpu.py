@@ -144,6 +144,28 @@ def test_gelu_l2norm_weightnorm_vs_torch(ops):
     assert rel(dv - 1.0, vd.grad) < 1e-5 and rel(dg - 1.0, gd.grad) < 1e-5
 
 
+def test_bf16x3_concat_gemm_is_fp32_grade(ops):
+    """The logits GEMM: [hi | hi | lo] . [hi | lo | hi]^T on the bf16 kernel (K' = 3 K) against fp64; the plain bf16
+    product of the same operands is ~2^-9 off, this one ~2^-17."""
+    from sais_amd import _lib as L
+    x = torch.nn.functional.normalize(rnd(40, 256, seed=16), dim=-1)
+    w = torch.nn.functional.normalize(rnd(1024, 256, seed=17), dim=-1)
+    x3 = torch.empty(40, 768, dtype=torch.bfloat16, device=DEV)
+    w3 = torch.empty(1024, 768, dtype=torch.bfloat16, device=DEV)
+    ops.split_bf16x3(x, x3, False)
+    ops.split_bf16x3(w, w3, True)
+    assert torch.equal(x3[:, :256], x.to(torch.bfloat16)) and torch.equal(x3[:, 256:512], x3[:, :256])
+    assert torch.equal(w3[:, 512:], w.to(torch.bfloat16))
+    assert torch.equal(w3[:, 256:512], (w - w.to(torch.bfloat16).float()).to(torch.bfloat16))
+    out = torch.empty(40, 1024, device=DEV)
+    ops.gemm_nt(x3, w3, L.EPI_BIAS_F32, out)
+    ref = x.double() @ w.double().t()
+    err = (out.double() - ref).abs().max().item()
+    plain = (x.to(torch.bfloat16).double() @ w.to(torch.bfloat16).double().t() - ref).abs().max().item()
+    parity_log("dino_bf16x3_concat_abs", err, 2e-5)
+    assert err < 2e-5 and plain > 20 * err                            # cosines in [-1, 1]
+
+
 def test_pos_interp_kernels(ops):
     from sais_amd import vit
     Wm = torch.from_numpy(vit.pos_interp_matrix(14, 96, 96).astype(np.float32)).to(DEV)
