@@ -41,7 +41,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def rel(a, b):
-    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
