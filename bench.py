@@ -461,7 +461,11 @@ def main():
         restore()
         graph_check = dict(loss_graph_replay=lg, loss_eager=le, abs_diff=abs(lg - le))
         if not abs(lg - le) <= 1e-6 * max(1.0, abs(le)):
-            raise SystemExit(f"bench.py: hipGraph replay loss {lg!r} != eager loss {le!r} from the same weights")
+            if world == 1:
+                raise SystemExit(f"bench.py: hipGraph replay loss {lg!r} != eager loss {le!r} from the same weights")
+            # N > 1: one rank leaving would strand the others in their next collective; the line carries the mismatch
+            graph_check["mismatch"] = True
+            sys.stderr.write(f"bench.py[rank {rank}]: hipGraph replay loss {lg!r} != eager loss {le!r}\n")
 
     # instrumented pass (outside the timed region): HIP events around every MFMA kernel launch
     # With N > 1 a step contains collectives (gradient all-reduces from the backward hooks), so EVERY rank runs these
