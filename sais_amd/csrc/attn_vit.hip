@@ -36,14 +36,25 @@ struct Geo {
 };
 
 // stage rows [0,197) x 64 bf16 of a [M, ld] matrix (column offset applied by caller) into LDS, zero-fill pad rows
+// Both global loads of every row segment are issued before the first LDS write, with clamped (not branched-on) row
+// addresses: a workgroup then has its whole K / V fill in flight at once instead of one dependent round trip per
+// conditional load (the compiler serialised the `r < NTOK ? load : 0` form into ~10 of them).
 template <class G>
-DEVINL void stage_matrix(char* lds, const bf16* src, long ld, int tid) {
+DEVINL void stage_two(char* lds0, const bf16* src0, char* lds1, const bf16* src1, long ld, int tid) {
     const int c = tid & 7, r0 = tid >> 3;
+    u32x4 v0[G::NKS], v1[G::NKS];
 #pragma unroll
     for (int i = 0; i < G::NKS; ++i) {
-        int r = r0 + 32 * i;
-        u32x4 v = r < G::NTOK ? *(const u32x4*)(src + (size_t)r * ld + c * 8) : u32x4{0, 0, 0, 0};
-        *(u32x4*)(lds + r * ROWB + c * 16) = v;
+        const int r = r0 + 32 * i, rc = r < G::NTOK ? r : G::NTOK - 1;
+        v0[i] = *(const u32x4*)(src0 + (size_t)rc * ld + c * 8);
+        v1[i] = *(const u32x4*)(src1 + (size_t)rc * ld + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < G::NKS; ++i) {
+        const int r = r0 + 32 * i;
+        const u32x4 z = {0, 0, 0, 0};
+        *(u32x4*)(lds0 + r * ROWB + c * 16) = r < G::NTOK ? v0[i] : z;
+        *(u32x4*)(lds1 + r * ROWB + c * 16) = r < G::NTOK ? v1[i] : z;
     }
 }
 DEVINL bf16x8 row_frag(const char* lds, int row, int chunk) { return *(const bf16x8*)(lds + row * ROWB + chunk * 16); }
@@ -110,8 +121,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
     const int h = blockIdx.x, f = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, li = lane & 15;
     const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
-    stage_matrix<G>(sK, base + DM, ldq, tid);
-    stage_matrix<G>(sV, base + 2 * DM, ldq, tid);
+    stage_two<G>(sK, base + DM, sV, base + 2 * DM, ldq, tid);
     __syncthreads();
     const float c = scale * LOG2E;
     const int extra = (f * NH + h) & 3;
@@ -191,6 +201,11 @@ template <class G> constexpr int bwd_lds() {               // 197 tokens: 152320
     return 3 * G::MAT_BYTES + 2 * G::TILE_ROWS * 4 + 2 * G::TILE_ROWS * SROW;
 }
 
+// SAIS_ATTN_ABL (timing ablations, results are WRONG when set; tools/gpu_attn_abl.sh): 1 no exponential, 2 no dQ phase,
+// 4 no dV / dK products, 8 no S / dP products, 16 no query loop at all (staging + final stores), 32 no dS store
+#ifndef SAIS_ATTN_ABL
+#define SAIS_ATTN_ABL 0
+#endif
 template <class G>
 __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
                                                         const bf16* out, long ldout, const float* lse, int nprob,
@@ -215,48 +230,59 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
         const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
         const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
         const bf16* ob = out + (size_t)f * NTOK * ldout + h * HD;
-        // ---- stage Q, dO, K (rows >= 197 zero) and delta = rowsum(dO * O); 8 threads per row, 128 rows per pass
+        // ---- stage Q, dO, K (rows >= NTOK zero) and delta = rowsum(dO * O); 8 threads per row, RPP rows per pass.
+        // EVERY global load of the problem — the passes' four row segments each, the log-sum-exp values and this wave's K / V
+        // fragments — is issued before the first use: addresses are clamped instead of branched on, so the compiler keeps
+        // ~14 loads in flight per lane instead of five dependent round trips (loads, wait, lse, wait, second pass, ...),
+        // which were most of the 49 us this phase takes on its own (tools/gpu_attn_abl.sh, ablation 16).
+        const int kt = wid;                                // waves >= NKT own no key tile
+        const int key = kt * 16 + li;
+        bf16x8 fk[2], fv[2];
         {
+            constexpr int NPASS = (TILE_ROWS + RPP - 1) / RPP;
             const int cch = tid & 7, r0 = tid >> 3;
+            u32x4 vq[NPASS], vk[NPASS], vd[NPASS], vo[NPASS];
+            float lv[NPASS];
 #pragma unroll
-            for (int i = 0; i < (TILE_ROWS + RPP - 1) / RPP; ++i) {
+            for (int i = 0; i < NPASS; ++i) {
+                const int r = r0 + RPP * i, rc = r < NTOK ? r : NTOK - 1;
+                vq[i] = *(const u32x4*)(base + (size_t)rc * ldq + cch * 8);
+                vk[i] = *(const u32x4*)(base + DM + (size_t)rc * ldq + cch * 8);
+                vd[i] = *(const u32x4*)(dob + (size_t)rc * ldo + cch * 8);
+                vo[i] = *(const u32x4*)(ob + (size_t)rc * ldout + cch * 8);
+                lv[i] = lse[((size_t)f * NH + h) * NTOK + rc];
+            }
+            if (kt < NKT) {
+                load_q_frags<G>(base + DM, ldq, key, g, fk);
+                load_q_frags<G>(base + 2 * DM, ldq, key, g, fv);
+            }
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
                 const int r = r0 + RPP * i;
                 if (r < TILE_ROWS) {
                     const bool ok = r < NTOK;
                     const u32x4 z = {0, 0, 0, 0};
-                    const u32x4 vq = ok ? *(const u32x4*)(base + (size_t)r * ldq + cch * 8) : z;
-                    const u32x4 vk = ok ? *(const u32x4*)(base + DM + (size_t)r * ldq + cch * 8) : z;
-                    const u32x4 vd = ok ? *(const u32x4*)(dob + (size_t)r * ldo + cch * 8) : z;
-                    const u32x4 vo = ok ? *(const u32x4*)(ob + (size_t)r * ldout + cch * 8) : z;
-                    *(u32x4*)(sQ + r * ROWB + cch * 16) = vq;
-                    *(u32x4*)(sK + r * ROWB + cch * 16) = vk;
-                    *(u32x4*)(sO + r * ROWB + cch * 16) = vd;
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, vd), b = __builtin_bit_cast(bf16x8, vo);
+                    *(u32x4*)(sQ + r * ROWB + cch * 16) = ok ? vq[i] : z;
+                    *(u32x4*)(sK + r * ROWB + cch * 16) = ok ? vk[i] : z;
+                    *(u32x4*)(sO + r * ROWB + cch * 16) = ok ? vd[i] : z;
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, vd[i]), b = __builtin_bit_cast(bf16x8, vo[i]);
                     float dl = 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)a[e], (float)b[e], dl);
                     dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4);
                     if (cch == 0) {
-                        sD[r] = dl;
-                        sL[r] = ok ? lse[((size_t)f * NH + h) * NTOK + r] * LOG2E : INFINITY;    // exp2(-inf) = 0: pad queries
+                        sD[r] = ok ? dl : 0.f;
+                        sL[r] = ok ? lv[i] * LOG2E : INFINITY;               // exp2(-inf) = 0: pad queries
                     }
                 }
             }
-        }
-        // this wave's key tile: K and V fragments in registers (key on the lane)
-        const int kt = wid;                                // waves >= NKT own no key tile
-        const int key = kt * 16 + li;
-        bf16x8 fk[2], fv[2];
-        if (kt < NKT) {
-            load_q_frags<G>(base + DM, ldq, key, g, fk);
-            load_q_frags<G>(base + 2 * DM, ldq, key, g, fv);
         }
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
         __syncthreads();
 #pragma unroll 1
-        for (int qs = 0; qs < NKS; ++qs) {
+        for (int qs = 0; qs < ((SAIS_ATTN_ABL & 16) ? 0 : NKS); ++qs) {
             char* const sb = sS + (qs & 1) * S_BYTES;
             if (kt < NKT) {
                 f32x4 p[2], ds[2];
@@ -265,7 +291,7 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
                     const int qrow = 32 * qs + 16 * u;      // lane holds q = qrow + 4 g + r, key = 16 kt + li
                     f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
+                    for (int ks = 0; ks < ((SAIS_ATTN_ABL & 8) ? 0 : 2); ++ks) {
                         a = mfma16(row_frag(sQ, qrow + li, 4 * ks + g), fk[ks], a);     // S[q][key]
                         b = mfma16(row_frag(sO, qrow + li, 4 * ks + g), fv[ks], b);     // dP[q][key]
                     }
@@ -274,20 +300,21 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
                     bf16x4 dsb;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = fast_exp2(__builtin_fmaf(a[r], c, -l4[r]));
+                        const float pv = (SAIS_ATTN_ABL & 1) ? __builtin_fmaf(a[r], c, -l4[r]) : fast_exp2(__builtin_fmaf(a[r], c, -l4[r]));
                         p[u][r] = pv;
                         const float t = pv * (b[r] - d4[r]);             // x scale at the dK / dQ stores
                         ds[u][r] = t;
                         dsb[r] = (bf16)(key < NTOK ? t : 0.f);           // pad keys must not reach dQ
                     }
-                    *(bf16x4*)(sb + key * SROW + (16 * u + 4 * g) * 2) = dsb;
+                    if (!(SAIS_ATTN_ABL & 32)) *(bf16x4*)(sb + key * SROW + (16 * u + 4 * g) * 2) = dsb;
                 }
                 const bf16x8 pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < ((SAIS_ATTN_ABL & 4) ? 0 : 4); ++dt) {
                     dv[dt] = mfma16(tr_frag(sO, qs, dt, g, li), pf, dv[dt]);            // dV^T[d][key]
                     dk[dt] = mfma16(tr_frag(sQ, qs, dt, g, li), dsf, dk[dt]);           // dK^T[d][key]
                 }
+                if (SAIS_ATTN_ABL & 4) { dv[0] += p[0] + p[1]; dk[0] += ds[0] + ds[1]; }   // keep the producers alive
             } else if constexpr (NKT & 1) {                 // the last 16 rows of the dS image belong to no key tile
                 if (qs < 2) {
                     for (int i = lane + 64 * (wid - NKT); i < 16 * SROW / 8; i += 64 * (NWAVES - NKT))
@@ -295,7 +322,7 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
                 }
             }
             __syncthreads();                                // dS of this query step is complete
-            if (wid >= DQ_FIRST)                            // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  (uniform branch)
+            if (wid >= DQ_FIRST && !(SAIS_ATTN_ABL & 2))    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  (uniform branch)
             for (int w = wid - DQ_FIRST; w < 8; w += DQ_WAVES) {
                 const int qt = w >> 2, dt = w & 3;
                 f32x4 o = {0, 0, 0, 0};

@@ -7,7 +7,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/tools/bin/$name
 mkdir -p $out
-for f in gemm gemm_row norm attn_vit misc temporal tgemm tattn preprocess; do
+for f in gemm gemm_row norm attn_vit misc temporal tgemm tattn preprocess dino; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-result \
       -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c $root/sais_amd/csrc/$f.hip -o $out/$f.o &
 done
