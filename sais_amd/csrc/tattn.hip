@@ -55,14 +55,39 @@ DEVINL void dot_tile2(const float (&x0)[24], const float (&y0)[24], const float 
 DEVINL float max4g(float v) { v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
 DEVINL float sum4g(float v) { v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
 
-// head slice `which` (0 q, 1 k, 2 v) of qkv [B*S, 1152] -> dst[S_pad][TLD], rows >= S zero
-DEVINL void stage_head(const float* qkv, int b, int h, int S, int Spad, int which, float* dst, int tid, int nt) {
-    for (int i = tid; i < Spad * (THD / 4); i += nt) {
-        const int s = i / (THD / 4), c4 = i % (THD / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (s < S) v = *(const f32x4*)(qkv + ((size_t)b * S + s) * (3 * D) + which * D + h * THD + 4 * c4);
-        *(f32x4*)(dst + s * TLD + 4 * c4) = v;
+// head slices q, k, v of qkv [B*S, 1152] -> sQ / sK / sV [S_pad][TLD], rows >= S zero.  Addresses are clamped instead of
+// branched on and a lane issues the loads of SU consecutive passes (3 SU float4) before the first LDS write: the
+// `if (s < S) load` loop this replaces compiled to one dependent round trip per pass and matrix (~15 per launch for S = 33,
+// each ~0.5 us of a 16-us kernel).
+constexpr int SU = 3;
+DEVINL void stage_qkv(const float* qkv, int b, int h, int S, int Spad, float* sQ, float* sK, float* sV, int tid) {
+    const int total = Spad * (THD / 4);
+    for (int i0 = tid; i0 < total; i0 += 256 * SU) {
+        f32x4 v[SU][3];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = min(i0 + 256 * u, total - 1), s = i / (THD / 4), c4 = i % (THD / 4);
+            const float* src = qkv + ((size_t)b * S + min(s, S - 1)) * (3 * D) + h * THD + 4 * c4;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) v[u][w] = *(const f32x4*)(src + w * D);
+        }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < total) {
+                const int s = i / (THD / 4), c4 = i % (THD / 4);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *(f32x4*)(sQ + s * TLD + 4 * c4) = s < S ? v[u][0] : z;
+                *(f32x4*)(sK + s * TLD + 4 * c4) = s < S ? v[u][1] : z;
+                *(f32x4*)(sV + s * TLD + 4 * c4) = s < S ? v[u][2] : z;
+            }
+        }
     }
+}
+// key flags of sequence b into LDS: 1 = masked (key_padding_mask) or past the sequence; read back per (key tile, lane)
+// without the serialised global byte loads the `key >= S || pad[key]` form compiled to
+DEVINL void stage_pad(const unsigned char* pad, int S, int Spad, unsigned char* sP, int tid) {
+    if (tid < Spad) sP[tid] = tid >= S ? (unsigned char)1 : pad[tid];
 }
 
 constexpr int MAXT = 6;                                  // 16-token tiles: S <= 96
@@ -77,13 +102,12 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const float* qkv, const 
     float* sQ = (float*)smem;
     float* sK = sQ + Spad * TLD;
     float* sV = sK + Spad * TLD;
+    unsigned char* sP = (unsigned char*)(sV + Spad * TLD);
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    stage_head(qkv, b, h, S, Spad, 0, sQ, tid, 256);
-    stage_head(qkv, b, h, S, Spad, 1, sK, tid, 256);
-    stage_head(qkv, b, h, S, Spad, 2, sV, tid, 256);
+    stage_pad(key_pad + (size_t)b * S, S, Spad, sP, tid);
+    stage_qkv(qkv, b, h, S, Spad, sQ, sK, sV, tid);
     __syncthreads();
-    const unsigned char* pad = key_pad + (size_t)b * S;
     const bool dropping = p_drop > 0.f;
     const unsigned thr = drop_threshold(p_drop);
     const float inv_keep = dropping ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -111,8 +135,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(const float* qkv, const 
             if (kt >= nt) break;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = 16 * kt + 4 * g + r;
-                if (key >= S || pad[key < S ? key : 0]) p[kt][r] = -INFINITY;
+                if (sP[16 * kt + 4 * g + r]) p[kt][r] = -INFINITY;
                 m = fmaxf(m, p[kt][r]);
             }
         }
@@ -174,24 +197,38 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
     float* sM = sG + Spad * TLD;                          // per query: row max, 1 / row sum, rowsum(P dP)
     float* sI = sM + Spad;
     float* sDot = sI + Spad;
+    unsigned char* sP = (unsigned char*)(sDot + Spad);
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
     const float scale = 0.10206207261596577f;
-    stage_head(qkv, b, h, S, Spad, 0, sQ, tid, 256);
-    stage_head(qkv, b, h, S, Spad, 1, sK, tid, 256);
-    stage_head(qkv, b, h, S, Spad, 2, sV, tid, 256);
-    for (int i = tid; i < Spad * (THD / 4); i += 256) {
-        const int s = i / (THD / 4), c4 = i % (THD / 4);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (s < S) {
-            const float* src = dctx + ((size_t)b * S + s) * D + h * THD + 4 * c4;
-            v = *(const f32x4*)src;
-            for (int z = 1; z < nslab; ++z) v += *(const f32x4*)(src + (size_t)z * slab_stride);
+    stage_pad(key_pad + (size_t)b * S, S, Spad, sP, tid);
+    {   // dctx = sum of the out_proj dX slabs: the loads of SU passes x one slab in flight together
+        const int total = Spad * (THD / 4);
+        for (int i0 = tid; i0 < total; i0 += 256 * SU) {
+            f32x4 v[SU];
+            const float* src[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = min(i0 + 256 * u, total - 1), sr = i / (THD / 4), c4 = i % (THD / 4);
+                src[u] = dctx + ((size_t)b * S + min(sr, S - 1)) * D + h * THD + 4 * c4;
+                v[u] = *(const f32x4*)src[u];
+            }
+            for (int z = 1; z < nslab; ++z) {
+#pragma unroll
+                for (int u = 0; u < SU; ++u) v[u] += *(const f32x4*)(src[u] + (size_t)z * slab_stride);
+            }
+#pragma unroll
+            for (int u = 0; u < SU; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < total) {
+                    const int sr = i / (THD / 4), c4 = i % (THD / 4);
+                    *(f32x4*)(sG + sr * TLD + 4 * c4) = sr < S ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
         }
-        *(f32x4*)(sG + s * TLD + 4 * c4) = v;
     }
+    stage_qkv(qkv, b, h, S, Spad, sQ, sK, sV, tid);
     __syncthreads();
-    const unsigned char* pad = key_pad + (size_t)b * S;
     const bool dropping = p_drop > 0.f;
     const unsigned thr = drop_threshold(p_drop);
     const float inv_keep = dropping ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -218,7 +255,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * kt + 4 * g + r;
-                if (key >= S || pad[key < S ? key : 0]) p[kt][r] = -INFINITY;
+                if (sP[key]) p[kt][r] = -INFINITY;
                 m = fmaxf(m, p[kt][r]);
             }
         }
@@ -278,7 +315,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(const float* qkv, const 
     // ---- phase 2: a wave owns 16 keys (on the lane), all queries: P' and dS with the key on the lane -> dV, dK
     for (int kt = wid; kt < nt; kt += 4) {
         const int key = 16 * kt + li;
-        const bool key_ok = key < S && !pad[key < S ? key : 0];
+        const bool key_ok = !sP[key];
         float kf[24], vf[24];
         load24(sK + key * TLD, g, kf);
         load24(sV + key * TLD, g, vf);
@@ -347,7 +384,7 @@ extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key
     if (!qkv || !key_pad || !ctx || B <= 0 || S <= 0 || S > SAIS_TEMPORAL_MAX_S_FWD) return SAIS_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !rng_state)) return SAIS_ERR_ARG;
     const int Spad = (S + 15) / 16 * 16;
-    const int lds = 3 * Spad * TLD * 4;
+    const int lds = 3 * Spad * TLD * 4 + Spad;
     if (set_lds(tattn_fwd_kernel, lds)) return SAIS_ERR_LAUNCH;
     hipStream_t s = (hipStream_t)stream;
     if (attn_avg && hipMemsetAsync(attn_avg, 0, (size_t)B * S * S * 4, s) != hipSuccess) return SAIS_ERR_LAUNCH;
@@ -364,7 +401,7 @@ extern "C" int sais_temporal_attn_bwd(const float* qkv, const unsigned char* key
         return SAIS_ERR_ARG;
     if (p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !rng_state)) return SAIS_ERR_ARG;
     const int Spad = (S + 15) / 16 * 16;
-    const int lds = (4 * Spad * TLD + 3 * Spad) * 4;
+    const int lds = (4 * Spad * TLD + 3 * Spad) * 4 + Spad;
     if (set_lds(tattn_bwd_kernel, lds)) return SAIS_ERR_LAUNCH;
     hipLaunchKernelGGL(tattn_bwd_kernel, dim3(TH, B), dim3(256), lds, (hipStream_t)stream, qkv, key_pad, S, dctx, nslab,
                        slab_stride, dqkv, p_drop, rng_state, site);
