@@ -383,8 +383,8 @@ int launch_fwd(const void* qkv, long ldqkv, int frames, void* out, long ldo, flo
 template <class G>
 int launch_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout, const float* lse,
                int frames, void* dqkv, long lddqkv, void* stream) {
-    if (set_lds<G>(attn_bwd_kernel<G>, bwd_lds<G>())) return SAIS_ERR_LAUNCH;
     const int nprob = frames * NH;
+    if (set_lds<G>(attn_bwd_kernel<G>, bwd_lds<G>())) return SAIS_ERR_LAUNCH;
     // short sequences leave most of the LDS free: several workgroups per CU
     int per_cu = 160 * 1024 / bwd_lds<G>();                       // resident workgroups per CU (LDS-limited)
     per_cu = G::BWD_THREADS == 1024 ? 1 : (per_cu > 4 ? 4 : per_cu);
