@@ -201,6 +201,14 @@ template <class G> constexpr int bwd_lds() {               // 197 tokens: 152320
     return 3 * G::MAT_BYTES + 2 * G::TILE_ROWS * 4 + 2 * G::TILE_ROWS * SROW;
 }
 
+// SAIS_ATTN_STAMP (debug builds only, tools/gpu_attn_stamp.sh): lane 0 of every wave of workgroup 0 records the shader clock
+// at the phase boundaries of its SECOND problem; sais_debug_attn_stamps() copies the table out.
+#ifdef SAIS_ATTN_STAMP
+__device__ unsigned long long g_attn_stamps[16][40];
+#define STAMP(i) do { if (blockIdx.x == 0 && prob == (int)gridDim.x && lane == 0) g_attn_stamps[wid][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 // SAIS_ATTN_ABL (timing ablations, results are WRONG when set; tools/gpu_attn_abl.sh): 1 no exponential, 2 no dQ phase,
 // 4 no dV / dK products, 8 no S / dP products, 16 no query loop at all (staging + final stores), 32 no dS store
 #ifndef SAIS_ATTN_ABL
@@ -230,6 +238,7 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
         const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
         const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
         const bf16* ob = out + (size_t)f * NTOK * ldout + h * HD;
+        STAMP(0);
         // ---- stage Q, dO, K (rows >= NTOK zero) and delta = rowsum(dO * O); 8 threads per row, RPP rows per pass.
         // EVERY global load of the problem — the passes' four row segments each, the log-sum-exp values and this wave's K / V
         // fragments — is issued before the first use: addresses are clamped instead of branched on, so the compiler keeps
@@ -280,7 +289,9 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+        STAMP(1);
         __syncthreads();
+        STAMP(2);
 #pragma unroll 1
         for (int qs = 0; qs < ((SAIS_ATTN_ABL & 16) ? 0 : NKS); ++qs) {
             char* const sb = sS + (qs & 1) * S_BYTES;
@@ -308,6 +319,7 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
                     }
                     if (!(SAIS_ATTN_ABL & 32)) *(bf16x4*)(sb + key * SROW + (16 * u + 4 * g) * 2) = dsb;
                 }
+                STAMP(3 + 5 * qs);                          // S / dP, exponentials, dS written
                 const bf16x8 pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);
 #pragma unroll
                 for (int dt = 0; dt < ((SAIS_ATTN_ABL & 4) ? 0 : 4); ++dt) {
@@ -321,7 +333,9 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
                         *(u32x2*)(sS + qs * S_BYTES + NKT * 16 * SROW + i * 8) = u32x2{0, 0};
                 }
             }
+            STAMP(4 + 5 * qs);                              // dV / dK products issued
             __syncthreads();                                // dS of this query step is complete
+            STAMP(5 + 5 * qs);
             if (wid >= DQ_FIRST && !(SAIS_ATTN_ABL & 2))    // dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]  (uniform branch)
             for (int w = wid - DQ_FIRST; w < 8; w += DQ_WAVES) {
                 const int qt = w >> 2, dt = w & 3;
@@ -340,7 +354,9 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
                     *(bf16x4*)(dqkv + ((size_t)f * NTOK + q) * lddq + h * HD + 16 * dt + 4 * g) = v;
                 }
             }
+            STAMP(6 + 5 * qs);                              // dQ product stored (dQ waves)
         }
+        STAMP(38);
         if (kt < NKT && key < NTOK) {
             bf16* krow = dqkv + ((size_t)f * NTOK + key) * lddq + DM + h * HD + 4 * g;
 #pragma unroll
@@ -353,6 +369,7 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
             }
         }
         __syncthreads();                                    // every read of this problem's images is done
+        STAMP(39);
     }
 }
 
@@ -395,6 +412,12 @@ int launch_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const v
     return sais_check_launch();
 }
 }  // namespace
+
+#ifdef SAIS_ATTN_STAMP
+extern "C" int sais_debug_attn_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_stamps), sizeof(unsigned long long) * 16 * 40) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, int ntok, void* out, long ldo, float* lse,
                                  float* probs, void* stream) {
