@@ -222,6 +222,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 // K-tile's round trip, ~19 % of a K = 384 tile) runs under the epilogue's arithmetic and stores.  vmcnt is in-order
 // and counts stores: the wait that follows the epilogue allows exactly the stores it issued (+ the two A'(1) pieces)
 // to stay outstanding, which is only known for full tiles, so a ragged tile waits for everything.
+// SAIS_NT_STAMP (debug builds only, tools/nt_stamp.py): lane 0 of every wave of workgroup 0 records the shader clock at the
+// phase boundaries of its THIRD tile; sais_debug_nt_stamps() copies the table out.
+#ifdef SAIS_NT_STAMP
+__device__ unsigned long long g_nt_stamps[8][16];
+#define NTSTAMP(i) do { if (blockIdx.x == 0 && titer == 2 && lane == 0) g_nt_stamps[wid][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NTSTAMP(i) do { } while (0)
+#endif
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
@@ -290,7 +298,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
     if (nk > 1) issue_a(1);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    [[maybe_unused]] int titer = -1;
     for (;;) {
+        ++titer;
+        NTSTAMP(0);
         f32x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -324,7 +335,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
             if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
             else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: only the epilogue's loads are out
+            NTSTAMP(1 + 2 * kt);                                         // MFMAs issued, operands of the next step awaited
             __builtin_amdgcn_s_barrier();
+            NTSTAMP(2 + 2 * kt);
         }
         __builtin_amdgcn_s_setprio(0);
         // the next tile's first loads go out before this tile's epilogue
@@ -350,6 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
                 for (int r = 0; r < 4; ++r) vv[4 * nt + r] = acc[mt][nt][r];
             epilogue8<EPI>(p, m, cn0 + wc * 32 + 8 * g, vv, bias, aux, mt);
         }
+        NTSTAMP(13);                                                     // epilogue arithmetic done, stores issued
         if (!more) break;
         v = nv;
         // A'(0) and W'(0) must have landed; the two A'(1) pieces and this epilogue's stores may stay in flight
@@ -361,9 +375,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
         else if (allow == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         else if (allow == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        NTSTAMP(14);                                                     // the next tile's first operands have landed
         __builtin_amdgcn_s_barrier();
+        NTSTAMP(15);
     }
 }
+
+#ifdef SAIS_NT_STAMP
+extern "C" int sais_debug_nt_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // NT with fp32 operands at ~fp32 accuracy on the bf16 matrix cores ("bf16x3"): every operand is split
