@@ -129,12 +129,14 @@ def train_dino(args):
     for epoch in range(start_epoch, args.epochs):
         sampler.set_epoch(epoch)
         total, count, t0 = torch.zeros((), device=dev), 0, time.time()
+        finite = torch.ones((), device=dev)                          # device-side AND of isfinite(loss), every iteration
         for i, (images, _, _) in enumerate(loader):
             it = niter * epoch + i
             images = [im.to(dev, non_blocking=True) for im in images]
             loss, _ = dino.train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_schedule, wd_schedule,
                                       momentum_schedule, clip_grad=args.clip_grad, freeze_last_layer=args.freeze_last_layer)
             total += loss
+            finite *= torch.isfinite(loss).to(finite.dtype)
             count += 1
             if i % 10 == 0:                                          # the reference logs every 10 iterations
                 lv = loss.item()
@@ -145,6 +147,10 @@ def train_dino(args):
                     print(f"Epoch: [{epoch}/{args.epochs}]  [{i}/{niter}]  loss: {lv:.6f}  lr: {lr_schedule[it]:.6f}  "
                           f"wd: {wd_schedule[it]:.6f}  {(time.time() - t0) / (i + 1):.4f} s / it")
         dist.all_reduce(total)
+        dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+        if finite.item() == 0:                                       # the reference checks every iteration (main_dino.py:540-542);
+            print("Loss went non-finite in epoch {}, stopping training".format(epoch))   # here: before checkpoint.pth is
+            sys.exit(1)                                              # overwritten with poisoned weights
         stats = {"loss": (total / max(count * args.world_size, 1)).item(), "lr": float(lr_schedule[min(it, len(lr_schedule) - 1)]),
                  "wd": float(wd_schedule[min(it, len(wd_schedule) - 1)])} if count else {}
         if main:

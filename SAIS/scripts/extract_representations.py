@@ -108,8 +108,10 @@ def main():
             try:
                 parts = [fx(b).cpu() for b in frame_batches(os.path.join(args.data_path, sub, v), dev, rank=rank, world=world)]
                 mine = torch.cat(parts) if parts else torch.empty(0, 384)
-            except FrameError as e:          # a rank-local failure: the other ranks are about to enter the gather below
-                err, mine = str(e), torch.empty(0, 384)
+            except Exception as e:           # ANY rank-local failure (bad frame mode, PIL decode error, OSError, a geometry
+                # error inside fx): the other ranks are about to enter the gather below, so it is reported there
+                err = str(e) if isinstance(e, FrameError) else f'rank {rank}: {type(e).__name__}: {e}'
+                mine = torch.empty(0, 384)
         # the error flag travels WITH the payload, so that one rank's bad frame ends the job on every rank at once instead of
         # leaving the others in all_gather_object until the process-group timeout
         gathered = gather_in_rank_order((err, mine), world)

@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--dino-batch", type=int, default=64, help="--workload dino: images per GPU (batch_size_per_gpu)")
     ap.add_argument("--dino-local-crops", type=int, default=8)
     ap.add_argument("--dino-out-dim", type=int, default=65536)
+    ap.add_argument("--parity-clips", type=int, default=1,
+                    help="clips of the timed batch that also go through the CPU oracle (with the draws the GPU forward "
+                         "used) for the in-line parity gate; 0 = skip")
     ap.add_argument("--sustain-seconds", type=float, default=20.0,
                     help="after the timed region, keep replaying the step for this long and report the settled rate "
                          "(clock under sustained MFMA load); 0 = skip")
@@ -122,6 +125,7 @@ def make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, d
         loss.backward()
         if dist_on:
             sync.reduce_params(protos.values())
+            sync.flush()                                  # the last open bucket + the packed small slices go out now
             if comm_events is not None and comm_events.enabled:   # compute-stream stall for the collectives = exposed comm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -327,6 +331,66 @@ def dino_main(args):
         dist.destroy_process_group()
 
 
+def parity_gate(vit, model, protos, frames, pad, labels, B, T, C, two, nclips):
+    """BASELINE.md §3 / perform_training.py:119-127: the TIMED model on the TIMED inputs against the CPU oracle, in the same
+    run.  One train-mode forward of the whole batch on the GPU (temporal dropout and ViT DropPath on, as timed); the draws
+    it used are exported (per-sample DropPath factors, dropout keep masks regenerated from the forward's RNG state) and
+    the first `nclips` clips go through the oracle with the same weights and the same draws.  Returns max-abs deviations
+    of the cosine class logits, the returned attention map, the embeddings, and of the per-clip NCE loss."""
+    import torch
+    from oracle import sais_oracle as O
+    from sais_amd.loss import calcNCELoss, cosine_logits_and_probs
+    n, S = min(nclips, B), T + 1
+    lens = [T] * B
+    with torch.no_grad():
+        reps = vit(frames)
+        if two:
+            r = reps.view(2, B, 1, T, 384)
+            emb, attn = model(r[0], r[1], lens, lens, 'Prototypes', pad, pad, None)
+        else:
+            emb, attn = model(reps.view(B, 1, T, 384), None, lens, None, 'Prototypes', pad, None, None)
+        sim, _ = cosine_logits_and_probs(emb, protos)
+        loss_gpu = float(calcNCELoss(0, emb[:n].contiguous(), labels[:n], [f"v_{i}" for i in range(n)], protos, None))
+    fac = None
+    if vit.training and vit.drop_path_rate > 0:
+        sc = vit.last_droppath_scales.view(2 * vit.depth, -1, 197)[:, :, 0].cpu()          # [24, frames] per-sample factors
+        fac = sc
+    drop = None
+    if model.training and model.dropout_p > 0:
+        st = model.last_dropout_state
+        drop = {"rgb": [{k: v[:n].cpu() for k, v in lm.items()} for lm in model.dropout_masks(st, B, S, stream=0)]}
+        if two:
+            drop["flow"] = [{k: v[:n].cpu() for k, v in lm.items()} for lm in model.dropout_masks(st, B, S, stream=1)]
+    vsd = {k: v.detach().float().cpu() for k, v in vit.state_dict().items()}
+    tsd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    pr = {k: v.detach().float().cpu() for k, v in protos.items()}
+    fr = frames.cpu()
+    t0 = time.time()
+    with torch.no_grad():
+        def feats(lo):                                        # oracle ViT on frames [lo, lo + n T) with their DropPath factors
+            return O.vit_forward(vsd, fr[lo:lo + n * T], droppath=None if fac is None else fac[:, lo:lo + n * T])
+        x = feats(0).view(n, 1, T, 384)
+        f = feats(B * T).view(n, 1, T, 384) if two else None
+        pc = pad[:n].cpu()
+        e_ref, a_ref = O.temporal_forward(tsd, x, f, pc, pc if two else None, "RGB-Flow" if two else "RGB", drop=drop,
+                                          p=float(model.dropout_p))
+        sim_ref = O.cosine_logits(e_ref, pr)
+        loss_ref = float(O.nce_loss(e_ref, labels[:n], pr))
+    dl = float((sim[:n].cpu() - sim_ref).abs().max())
+    out = dict(max_abs_logit=dl, max_abs_attn=float((attn[:n].cpu() - a_ref).abs().max()),
+               max_abs_emb=float((emb[:n].cpu() - e_ref).abs().max()), loss_abs=abs(loss_gpu - loss_ref),
+               max_abs_feature_rel=float((reps[:n * T].cpu() - x.view(n * T, 384)).abs().max() / x.abs().max()),
+               tolerance_logit=1e-3, clips_checked=n, frames_checked=n * T * (2 if two else 1),
+               oracle_seconds=round(time.time() - t0, 1),
+               what="timed model (same weights) on the timed inputs, train mode, temporal dropout "
+                    f"{float(model.dropout_p) if model.training else 0.0} + ViT DropPath "
+                    f"{vit.drop_path_rate if vit.training else 0.0} with the draws of the GPU forward fed to the fp32 CPU "
+                    "oracle (oracle/sais_oracle.py, pinned to the reference's golden vectors)")
+    out = {k: (round(v, 7) if isinstance(v, float) else v) for k, v in out.items()}
+    out["pass"] = bool(dl <= 1e-3)
+    return out
+
+
 def load_pmc(name):
     path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
@@ -467,6 +531,15 @@ def main():
             graph_check["mismatch"] = True
             sys.stderr.write(f"bench.py[rank {rank}]: hipGraph replay loss {lg!r} != eager loss {le!r}\n")
 
+    # in-run parity gate (rank 0): the timed model on the timed inputs vs the CPU oracle, same draws
+    parity = None
+    if rank == 0 and args.parity_clips > 0:
+        restore()
+        parity = parity_gate(vit, model, protos, frames, pad, labels, B, T, C, two, args.parity_clips)
+        restore()
+        if not parity["pass"]:
+            sys.stderr.write(f"bench.py: PARITY GATE FAILED: max-abs logit deviation {parity['max_abs_logit']} > 1e-3\n")
+
     # instrumented pass (outside the timed region): HIP events around every MFMA kernel launch
     # With N > 1 a step contains collectives (gradient all-reduces from the backward hooks), so EVERY rank runs these
     # passes; only rank 0 brackets its kernels with events.
@@ -488,8 +561,12 @@ def main():
                     exposed_comm_measured_in="eager instrumented passes after the timed region (HIP events around the "
                                              "join; events cannot be timed inside a captured graph)",
                     payload_dtype="fp32",
-                    payload="flat gradient slices, one all-reduce per ViT block issued from the backward hooks, "
-                            "captured into the step's hipGraph" + ("" if use_graph else " (eager launch path)"))
+                    buckets=[dict(kind=k, mbytes=round(b / 2 ** 20, 2), slices=n) for k, b, n in sync.last_buckets],
+                    bucket_rule=f">= {sync.bucket_bytes >> 20} MiB of adjacent flat-gradient slices per all-reduce, in "
+                                f"backward (reverse-layer) order; slices < {sync.small_bytes >> 20} MiB packed into one",
+                    payload="flat gradient slices handed over by the backward hooks (temporal encoder, then ViT blocks "
+                            "last..first) and coalesced into buckets, captured into the step's hipGraph"
+                            + ("" if use_graph else " (eager launch path)"))
     if rank == 0:
         summ = ops.TIMER.summary()
         ops.TIMER = None
@@ -584,6 +661,7 @@ def main():
             "loss": round(timed_loss, 6),
             "sustained": None if sustained is None else dict(sustained, ratio_to_value=round(sustained["frames_per_s"] / fps, 4)),
             "graph_vs_eager": graph_check,
+            "parity": parity,
             "comm": comm,
             "roofline": roof,
         }

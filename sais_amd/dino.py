@@ -377,6 +377,7 @@ class DINOOptimizer:
                                    ("last_layer.weight_g", "last_layer.weight_v")), False)]
 
     def zero_grad(self, set_to_none=False):
+        self._norms_fresh = False                        # new gradients: the norms of the last step no longer describe them
         for m in (self.student.backbone, self.student.head):
             if m.flat is not None:
                 m.flat.grad.zero_()
@@ -391,13 +392,19 @@ class DINOOptimizer:
             norms = part.grad_norms(self.grad_scale)
             keep = [i for i, fl in enumerate(part.flags) if not fl & L.OPT_NO_GRAD]
             out.append(norms[keep])
+        self._norms_fresh = True
         return torch.cat(out)
 
     def step(self, clip_grad=0.0, frozen_last_layer=False, ema_momentum=None):
-        """One optimizer.step() + cancel_gradients_last_layer + teacher EMA.  clip_grad > 0 needs clip_gradients() to
-        have been called on these gradients (train_one_epoch's order)."""
+        """One optimizer.step() + cancel_gradients_last_layer + teacher EMA.  clip_grad > 0 clips against the per-tensor
+        norms of THESE gradients: clip_gradients() computes them (train_one_epoch's order); if it was not called since the
+        last zero_grad() / step() they are computed here, so a stand-alone step() never clips against stale or zero norms."""
         if self._parts is None:
             self._build()
+        if clip_grad and clip_grad > 0 and not getattr(self, "_norms_fresh", False):
+            for part, _ in self._parts:
+                part.grad_norms(self.grad_scale)
+        self._norms_fresh = False
         lr, wd = self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"]
         self.steps[0] += 1
         if not frozen_last_layer:

@@ -79,7 +79,25 @@ class DataAugmentationDINO:
     def __init__(self, global_crops_scale, local_crops_scale, local_crops_number, seed=None, global_size=224, local_size=96):
         self.gscale, self.lscale, self.local_crops_number = tuple(global_crops_scale), tuple(local_crops_scale), local_crops_number
         self.gsize, self.lsize = global_size, local_size
-        self.rng = random.Random(seed)
+        self.seed = seed
+        self._rng, self._rng_key = None, None
+
+    @property
+    def rng(self):
+        """One random.Random per (process, DataLoader worker, epoch).  DataLoader workers are forked with a COPY of this
+        object, re-forked every epoch from the parent's never-advancing state: a single generator made every worker draw
+        the same crop / flip / jitter sequence and replay it every epoch.  torch gives each worker a seed
+        `base_seed + worker_id` with a fresh base_seed per epoch (what torchvision's transforms draw from in the
+        reference); the generator here is re-created from (seed, that worker seed) whenever it changes."""
+        info = torch.utils.data.get_worker_info()
+        key = (os.getpid(), None if info is None else (info.id, info.seed))
+        if self._rng is None or key != self._rng_key:
+            if info is None:
+                self._rng = random.Random(self.seed)
+            else:
+                self._rng = random.Random(hash((self.seed, info.id, info.seed)) & 0xFFFFFFFFFFFF)
+            self._rng_key = key
+        return self._rng
 
     def _flip_and_color_jitter(self, img):
         r = self.rng

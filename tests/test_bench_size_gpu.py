@@ -220,6 +220,129 @@ def test_two_stream_train_step_stagewise_vs_oracle_at_config4_size(gpu):
     assert worst <= VIT_GRAD_REL, worst
 
 
+def test_benchmarked_configuration_with_dropout_and_droppath_vs_oracle(gpu):
+    """the configuration bench.py TIMES — B = 8, T = 32 (M = 50 432), train() with temporal dropout 0.1
+    AND ViT DropPath 0.1 — against the oracle fed the SAME draws: the per-sample DropPath factors the forward used
+    (`last_droppath_scales`) and the dropout masks regenerated from the forward's RNG state (`dropout_masks`).  Forward:
+    features, cosine logits, attention map, loss.  Backward, stage-wise as above: temporal gradients at the GPU's own
+    features (same masks), ViT parameter gradients driven by the GPU's own d loss / d features (same DropPath factors)."""
+    from oracle import sais_oracle as O
+    from parity import parity_log
+    from sais_amd.loss import calcNCELoss, cosine_logits_and_probs
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    B, T, C = 8, 32, 2
+    F, S = B * T, T + 1
+    vit = vit_small(patch_size=16, drop_path_rate=0.1)
+    vit.load_state_dict(synth.vit_state_dict(seed=0), strict=True)
+    vit = vit.to(DEV).train()
+    vit.drop_path_seed = 7919
+    m = fullModel('reps', C, 'in_vs_out', 384, 'ViT', modalities='RGB')
+    m.load_state_dict(synth.temporal_state_dict(seed=1), strict=True)
+    m = m.to(DEV).train()
+    assert m.dropout_p == 0.1                                # the reference's nn.TransformerEncoderLayer default
+    m.dropout_seed = 5
+    protos = torch.nn.ParameterDict({k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in synth.prototypes(2, C).items()})
+    frames = synth.clips(seed=3000, B=B, T=T).view(F, 3, 224, 224)
+    lens = [T] * B                                            # the benchmark's clips are full length
+    pad = synth.padding_mask(lens)
+    lab = synth.labels(seed=3001, B=B, nclasses=C)
+    reps = vit(frames.to(DEV))
+    reps.retain_grad()
+    emb, attn = m(reps.view(B, 1, T, 384), None, lens, None, 'Prototypes', pad.to(DEV), None, None)
+    loss = calcNCELoss(0, emb, lab, [f"v{b}" for b in range(B)], protos, None)
+    loss.backward()
+    sim, _ = cosine_logits_and_probs(emb, protos)
+    torch.cuda.synchronize()
+    # the draws this step used
+    sc = vit.last_droppath_scales.view(24, F, 197)
+    assert bool((sc == sc[:, :, :1]).all())
+    fac = sc[:, :, 0].cpu()                                   # [24, F] per-sample branch factors
+    assert float((fac == 0).sum()) >= 1                       # something was dropped
+    st = m.last_dropout_state
+    drop = {"rgb": [{k: v.cpu() for k, v in lm.items()} for lm in m.dropout_masks(st, B, S, stream=0)]}
+
+    vsd = {k: v.clone().requires_grad_(True) for k, v in synth.vit_state_dict(seed=0).items()}
+    tsd = {k: v.clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+    pr = {k: v.clone().requires_grad_(True) for k, v in synth.prototypes(2, C).items()}
+    dreps_gpu = reps.grad.detach().cpu()
+    parts = []
+    for i in range(0, F, 32):
+        r = O.vit_forward(vsd, frames[i:i + 32], droppath=fac[:, i:i + 32])
+        parts.append(r.detach())
+        (r * dreps_gpu[i:i + 32]).sum().backward()
+    reps_ref = torch.cat(parts)
+    with torch.no_grad():
+        e_ref, a_ref = O.temporal_forward(tsd, reps_ref.view(B, 1, T, 384), None, pad, None, "RGB", drop=drop, p=m.dropout_p)
+        sim_ref, loss_ref = O.cosine_logits(e_ref, pr), O.nce_loss(e_ref, lab, pr)
+    tag = "benchmarked step[B8,T32,dropout 0.1,DropPath 0.1]/"
+    dfeat = (reps.detach().cpu() - reps_ref).abs().max().item() / reps_ref.abs().max().item()
+    dlogit = (sim.cpu() - sim_ref).abs().max().item()
+    dattn = (attn.cpu() - a_ref).abs().max().item()
+    dloss = abs(loss.item() - loss_ref.item())
+    parity_log(tag + "features max-abs / max|ref|", dfeat, FEAT_REL)
+    parity_log(tag + "cosine logits max-abs", dlogit, LOGIT_TOL)
+    parity_log(tag + "attention map max-abs (the dropped map)", dattn, 2e-3)
+    parity_log(tag + "loss abs", dloss, LOGIT_TOL)
+    assert dfeat <= FEAT_REL and dlogit <= LOGIT_TOL and dattn <= 2e-3 and dloss <= LOGIT_TOL, (dfeat, dlogit, dattn, dloss)
+    # stage 1: temporal backward at the GPU's own features, same masks
+    rx = reps.detach().cpu().view(B, 1, T, 384).clone().requires_grad_(True)
+    e1, _ = O.temporal_forward(tsd, rx, None, pad, None, "RGB", drop=drop, p=m.dropout_p)
+    O.nce_loss(e1, lab, pr).backward()
+    r = rel_l2(reps.grad, rx.grad.reshape(F, 384))
+    parity_log(tag + "d loss / d features rel-L2", r, 4e-2)
+    assert r <= 4e-2, r                                       # a flipped ReLU gate moves one clip's gradient (DESIGN §2)
+    P = dict(m.named_parameters())
+    grads = {n: rel_l2(P[n].grad, tsd[n].grad) for n in (
+        "linear.weight", "frame_cls", "frame_pos_embeddings.0", f"frame_pos_embeddings.{T - 1}",
+        "transEncoderFrame.layers.0.self_attn.in_proj_weight", "transEncoderFrame.layers.3.norm2.bias",
+        "transEncoderFrame.layers.1.linear1.weight", "transEncoderFrame.layers.2.linear2.bias")}
+    parity_log(tag + "temporal parameter gradients, worst tensor rel-L2", max(grads.values()), 4e-2)
+    assert max(grads.values()) <= 4e-2, grads
+    # stage 2: ViT backward with the same DropPath factors
+    worst = {n: rel_l2(q.grad, vsd[n].grad) for n, q in vit.named_parameters()}
+    parity_log(tag + "ViT parameter gradients, worst tensor rel-L2 (150 tensors)", max(worst.values()), VIT_GRAD_REL)
+    assert max(worst.values()) <= VIT_GRAD_REL, {k: v for k, v in worst.items() if v > VIT_GRAD_REL}
+
+
+def test_outlier_weights_at_the_eight_wave_dispatch(gpu):
+    """The DINO-like outlier weights (synth.vit_state_dict_outlier: residual |x| ~ 37, LayerNorm outputs ~ 150, attention
+    logits up to +-30) at M = 146 x 197 = 28 762 rows — the eight-wave row tile and the persistent 128 x 128 kernels the
+    benchmark dispatches — against the oracle on the same frames; the deviation is logged."""
+    from oracle import sais_oracle as O
+    from parity import parity_log
+    from sais_amd.loss import cosine_logits_and_probs
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    F, B, T = 146, 4, 32                                      # 146 frames through the ViT, the first 128 form 4 clips
+    vit = vit_small(patch_size=16, drop_path_rate=0.0)
+    sdo = synth.vit_state_dict_outlier(seed=3)
+    vit.load_state_dict(sdo, strict=True)
+    vit = vit.to(DEV).eval()
+    m = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB')
+    m.load_state_dict(synth.temporal_state_dict(seed=1), strict=True)
+    m = m.to(DEV).eval()
+    protos = {k: v.to(DEV) for k, v in synth.prototypes(2, 2).items()}
+    frames = synth.clips(seed=3100, B=1, T=F)[0]
+    lens = [T, T - 5, T, T - 11]
+    pad = synth.padding_mask(lens)
+    with torch.no_grad():
+        reps = vit(frames.to(DEV))
+        emb, attn = m(reps[:B * T].view(B, 1, T, 384), None, lens, None, 'Prototypes', pad.to(DEV), None, None)
+        sim, _ = cosine_logits_and_probs(emb, protos)
+        ref = torch.cat([O.vit_forward(sdo, frames[i:i + 32]) for i in range(0, B * T, 32)])
+        e_ref, a_ref = O.temporal_forward(synth.temporal_state_dict(seed=1), ref.view(B, 1, T, 384), None, pad, None, "RGB")
+        sim_ref = O.cosine_logits(e_ref, synth.prototypes(2, 2))
+    tag = "outlier weights[M 28762]/"
+    dfeat = (reps[:B * T].cpu() - ref).abs().max().item() / ref.abs().max().item()
+    dlogit = (sim.cpu() - sim_ref).abs().max().item()
+    dattn = (attn.cpu() - a_ref).abs().max().item()
+    parity_log(tag + "features max-abs / max|ref|", dfeat, 3e-2)
+    parity_log(tag + "cosine logits max-abs", dlogit, LOGIT_TOL)
+    parity_log(tag + "attention map max-abs", dattn, 2e-3)
+    assert dfeat <= 3e-2 and dlogit <= LOGIT_TOL and dattn <= 2e-3, (dfeat, dlogit, dattn)
+
+
 def test_config2_graph_replay_equals_eager_step(gpu):
     """The code path bench.py times: one config-2 step (8 clips x 32 frames, M = 50 432) replayed from a hipGraph vs
     issued eagerly, both from the same weights."""

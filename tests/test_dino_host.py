@@ -160,3 +160,40 @@ def test_augmentation_and_dataset(tmp_path):
     mod = _load_cli()
     crops_b, labels, names = mod.collate([ds[0], ds[1]])
     assert [tuple(c.shape) for c in crops_b] == [(2, 3, 224, 224)] * 2 + [(2, 3, 96, 96)] * 3 and len(labels) == 2
+
+
+class _ConstImages(torch.utils.data.Dataset):
+    """Every item is the SAME image: whatever differs between the returned crops comes from the augmentation draws."""
+
+    def __init__(self, transform, n=8):
+        from PIL import Image
+        rng = np.random.default_rng(7)
+        self.img = Image.fromarray(rng.integers(0, 256, (120, 160, 3), dtype=np.uint8))
+        self.transform, self.n = transform, n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return self.transform(self.img)[0]                     # the first global crop
+
+
+def test_augmentation_draws_differ_between_workers_and_between_epochs():
+    """with one random.Random copied into every forked DataLoader worker, all workers drew the same
+    crop sequence and every epoch replayed the first.  The generator is now keyed by (seed, worker id, torch's per-epoch
+    worker seed)."""
+    from sais_amd.dino_data import DataAugmentationDINO
+    aug = DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), 0, seed=3, global_size=32)
+    loader = torch.utils.data.DataLoader(_ConstImages(aug), batch_size=2, num_workers=2, shuffle=False)
+    torch.manual_seed(0)
+    epoch0 = [b.clone() for b in loader]                       # batches 0, 2 come from worker 0; 1, 3 from worker 1
+    epoch1 = [b.clone() for b in loader]
+    assert len(epoch0) == 4
+    assert not torch.equal(epoch0[0], epoch0[1])               # two workers, same items' image: different draws
+    assert not torch.equal(epoch0[0][0], epoch0[0][1])         # consecutive draws of one worker differ
+    assert all(not torch.equal(a, b) for a, b in zip(epoch0, epoch1))   # a new epoch does not replay the old one
+    # the single-process path (num_workers = 0) is still reproducible from the seed
+    a = DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), 0, seed=3, global_size=32)
+    b = DataAugmentationDINO((0.4, 1.0), (0.05, 0.4), 0, seed=3, global_size=32)
+    ds = _ConstImages(None)
+    assert torch.equal(a(ds.img)[0], b(ds.img)[0])

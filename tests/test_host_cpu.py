@@ -166,6 +166,80 @@ def test_data_parallel_gradient_exchange_gloo_world2(tmp_path):
     assert int(nbytes) > 4 * 3_000_000
 
 
+def _bucket_worker(rank, world, port, out):
+    import json
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sais_amd.flat import FlatParams
+    from sais_amd.parallel import GradSync
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    torch.manual_seed(0)
+    vit, m = vit_small(depth=12), fullModel('reps', 2, 'd', 384, 'ViT', modalities='RGB')
+    vit.flat, m.flat = FlatParams(vit, 'cpu'), FlatParams(m, 'cpu')
+    T = 32
+    protos = [torch.nn.Parameter(torch.zeros(1, 256)) for _ in range(2)]
+    g = torch.Generator().manual_seed(200 + rank)
+    vit.flat.grad.copy_(torch.randn(vit.flat.numel, generator=g))
+    m.flat.grad.copy_(torch.randn(m.flat.numel, generator=g))
+    for q in protos:
+        q.grad = torch.randn(1, 256, generator=g)
+    local = [vit.flat.grad.clone(), m.flat.grad.clone()] + [q.grad.clone() for q in protos]
+    sync = GradSync(world)
+    logs = []
+    for step in range(2):                              # two steps: the bucket plan is the same every step
+        if step:
+            vit.flat.grad.copy_(local[0]); m.flat.grad.copy_(local[1])
+            for q, l in zip(protos, local[2:]):
+                q.grad.copy_(l)
+        m._touched_T = T
+        sync.temporal_hook(m, T)(0, m.flat.numel)
+        hook = sync.vit_hook(vit)                       # the order of VisionTransformer._backward_kernels
+        hook(vit.flat.offsets["norm.weight"], vit.flat.numel)
+        for i in reversed(range(12)):
+            hook(*vit.block_grad_range(i))
+        hook(0, vit.flat.offsets["blocks.0.norm1.weight"])
+        sync.reduce_params(protos)
+        nbytes = sync.wait()
+        logs.append([list(b) for b in sync.last_buckets])
+    gathered = []
+    for l in local:
+        parts = [torch.zeros_like(l) for _ in range(world)]
+        dist.all_gather(parts, l)
+        gathered.append(sum(parts))
+    touched = torch.zeros(m.flat.numel, dtype=torch.bool)
+    for a, b in GradSync.temporal_ranges(m, T):
+        touched[a:b] = True
+    ok = torch.allclose(vit.flat.grad, gathered[0], atol=1e-6) \
+        and torch.allclose(m.flat.grad[touched], gathered[1][touched], atol=1e-6) \
+        and torch.equal(m.flat.grad[~touched], local[1][~touched]) \
+        and all(torch.allclose(q.grad, s, atol=1e-6) for q, s in zip(protos, gathered[2:]))
+    json.dump(dict(ok=bool(ok), logs=logs, nbytes=nbytes), open(out + f".{rank}", "w"))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_are_identical_on_both_ranks_and_at_least_16_mib_gloo_world2(tmp_path):
+    """the ~20 per-slice all-reduces of a config-2 step are coalesced into <= 8 collectives (>= 16 MiB of
+    adjacent slices each, small slices packed into one), the same boundaries in the same order on every rank and every
+    step, and the exchanged gradients equal the sum over the ranks."""
+    import json
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "buckets")
+    mp.spawn(_bucket_worker, args=(2, 30500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    r0, r1 = (json.load(open(out + f".{r}")) for r in range(2))
+    assert r0["ok"] and r1["ok"]
+    assert r0["logs"] == r1["logs"] and r0["logs"][0] == r0["logs"][1]
+    plan = r0["logs"][0]
+    assert len(plan) <= 8, plan
+    buckets = [b for b in plan if b[0] == "bucket"]
+    assert all(b[1] >= 16 << 20 for b in buckets), plan                    # every bucket reached the threshold
+    assert [b[0] for b in plan].count("packed") == 1 and plan[-1][0] == "packed"
+    # reverse-layer order: the temporal encoder's slice first, then 4 x 3 ViT blocks
+    assert [b[2] for b in buckets] == [1, 3, 3, 3, 3], plan
+    assert r0["nbytes"] == sum(b[1] for b in plan) and r0["nbytes"] > 4 * 30_000_000
+
+
 def _sync_state_worker(rank, world, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
