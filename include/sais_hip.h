@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 7
+#define SAIS_ABI_VERSION 8
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -170,9 +170,43 @@ typedef struct SaisGemmLn {
     const float* rowscale;         /* fwd, optional (DropPath): x_out = resid + rowscale[m] * (A.W^T + bias)            */
     const float* rowscale16;       /* bwd, optional (DropPath): out16 = bf16(rowscale16[m] * dx): the gradient that enters
                                       the NEXT branch's backward GEMMs; out32 (the residual-stream gradient) is not scaled */
+    int dres_period;               /* bwd (ABI 8): 0 = dres is [M,384].  > 0: dres is COMPACT [ceil(M / period), 384]: row m of the
+                                      residual-stream gradient is dres[m / period] when m % period == 0 and ZERO otherwise — the
+                                      gradient entering the last ViT block exists on the CLS rows only (period = tokens per frame;
+                                      VisionTransformer.forward returns x[:, 0], vision_transformer.py:212-214)            */
 } SaisGemmLn;
 int sais_gemm_ln_fwd(const SaisGemmLn* g, void* stream);
 int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream);
+
+/* ---------------------------------------------------------------- the MLP branch of a ViT block as ONE launch (ABI 8)
+ * Block-level entry points (ln_fc1_gelu + fc2_residual of Block.forward in one call).
+ *   sais_mlp_fwd:  Mlp.forward (dino-main/vision_transformer.py:49-65: fc1 -> nn.GELU() exact erf -> fc2, dropout p = 0)
+ *       + the residual add of Block.forward (:111-112: x = x + drop_path(mlp(norm2(x)))) + the NEXT LayerNorm of the
+ *       residual stream (the next block's norm1, :107-108; eps 1e-6 via vit_small :243-247):
+ *         u = X . W1^T + bias1;  h = GELU(u);  g = GELU'(u);
+ *         out32 = resid + rowscale[m] * (h . W2^T + tail.bias);  out16 = LayerNorm(out32);  mean / rstd saved.
+ *       X = LayerNorm2(x_mid) bf16 [M,384]; W1 = fc1.weight bf16 [H,384]; W2 = fc2.weight bf16 [384,H]; H % 128 == 0.
+ *       h / g: bf16 [M,H] outputs the backward pass needs (dW2 = d^T h, du = (d W2) g).  g == NULL (inference): GELU'
+ *       is not evaluated, and with h == NULL too the hidden activation is never written to HBM at all.
+ *       tail.gamma == NULL: no following LayerNorm (the last block): only out32 is written.
+ *   sais_mlp_bwd:  autograd of the same branch up to the block's norm2 (backward of :59-65 and of nn.LayerNorm):
+ *         du = (X . W1^T) * g  (X = bf16 gradient entering the branch [M,384], W1 = fc2.weight^T bf16 [H,384], g = GELU'(u)
+ *         saved by the forward) -> written to h (dW1 = du^T xn2 needs it);  dxn = du . W2^T (W2 = fc1.weight^T bf16 [384,H]);
+ *         then exactly sais_gemm_ln_bwd's epilogue on dxn with tail.{resid = x_mid, mean, rstd, gamma, dres, dgamma, dbeta,
+ *         out32, out16, rowscale16}.
+ * `tail` is read like the argument of sais_gemm_ln_fwd / _bwd; its A / lda / W / ldw / M / K fields are ignored.        */
+typedef struct SaisMlp {
+    const void* X; int ldx;
+    const void* W1; int ldw1;
+    const float* bias1;            /* fwd: f32 [H] or NULL; bwd: unused */
+    const void* W2; int ldw2;
+    int M, H;
+    void* h; int ldh;
+    void* g; int ldg;
+    SaisGemmLn tail;
+} SaisMlp;
+int sais_mlp_fwd(const SaisMlp* a, void* stream);
+int sais_mlp_bwd(const SaisMlp* a, void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm over dim = 384
  * nn.LayerNorm in Block / final norm (vision_transformer.py:99,103,107-113,212; eps 1e-6 from
@@ -206,6 +240,14 @@ int sais_vit_attn_fwd(const void* qkv, long ldqkv, int frames, int ntok, void* o
  * kernel: P is rebuilt once per (query, key) from lse.  delta_ws is unused since ABI 2 (may be NULL).              */
 int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout,
                       const float* lse, float* delta_ws, int frames, int ntok, void* dqkv, long lddqkv, void* stream);
+/* The LAST block's attention (ABI 8).  VisionTransformer.forward returns norm(x)[:, 0] (vision_transformer.py:209-214): of the
+ * last block only the CLS row of every frame is read, so of its Attention.forward (:80-92) only the CLS QUERY is needed (keys
+ * and values of all tokens still are).  out bf16 [frames, 384] (compact: one row per frame).  The backward takes the compact
+ * dout bf16 [frames, 384], recomputes P and writes the WHOLE dqkv bf16 [frames*ntok, 1152]: dk, dv for every token, dq on the
+ * CLS rows and zeros on the others.  Results equal sais_vit_attn_fwd / _bwd restricted to those rows (fp32 softmax here). */
+int sais_vit_attn_cls_fwd(const void* qkv, long ldqkv, int frames, int ntok, void* out, long ldo, void* stream);
+int sais_vit_attn_cls_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, int frames, int ntok, void* dqkv,
+                          long lddqkv, void* stream);
 
 /* ---------------------------------------------------------------- ViT embedding glue
  * PatchEmbed + prepare_tokens, vision_transformer.py:116-131,196-207.                            */

@@ -41,7 +41,14 @@ class SaisGemmLn(ctypes.Structure):
                 ("bias", c_void_p), ("resid", c_void_p), ("ldr", c_int), ("out32", c_void_p), ("ldo32", c_int),
                 ("out16", c_void_p), ("ldo16", c_int), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
                 ("mean", c_void_p), ("rstd", c_void_p), ("dres", c_void_p), ("lddres", c_int),
-                ("dgamma", c_void_p), ("dbeta", c_void_p), ("rowscale", c_void_p), ("rowscale16", c_void_p)]
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("rowscale", c_void_p), ("rowscale16", c_void_p),
+                ("dres_period", c_int)]
+
+
+class SaisMlp(ctypes.Structure):
+    _fields_ = [("X", c_void_p), ("ldx", c_int), ("W1", c_void_p), ("ldw1", c_int), ("bias1", c_void_p),
+                ("W2", c_void_p), ("ldw2", c_int), ("M", c_int), ("H", c_int), ("h", c_void_p), ("ldh", c_int),
+                ("g", c_void_p), ("ldg", c_int), ("tail", SaisGemmLn)]
 
 
 class SaisOptChunk(ctypes.Structure):
@@ -71,6 +78,8 @@ SIGNATURES = {
     "sais_gemm_nt_f32": [ctypes.POINTER(SaisGemm), c_void_p],
     "sais_gemm_ln_fwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
     "sais_gemm_ln_bwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
+    "sais_mlp_fwd": [ctypes.POINTER(SaisMlp), c_void_p],
+    "sais_mlp_bwd": [ctypes.POINTER(SaisMlp), c_void_p],
     "sais_gemm_tn_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_transpose_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_gemm_tn_grouped": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p],
@@ -84,6 +93,8 @@ SIGNATURES = {
     "sais_vit_attn_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p, c_void_p, c_void_p],
     "sais_vit_attn_bwd": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p,
                           c_long, c_void_p],
+    "sais_vit_attn_cls_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p],
+    "sais_vit_attn_cls_bwd": [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p],
     "sais_patchify": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_vit_cls_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "sais_vit_embed_bwd": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -300,33 +300,52 @@ __global__ __launch_bounds__(256) void importance_loss_kernel(const float* logit
 }
 
 // ---------------------------------------------------------------- SupCon / prototype loss; one workgroup
-__global__ __launch_bounds__(256) void nce_kernel(const float* emb, const float* protos, const int* label_col, int B,
-                                                  int C, float* sim, float* probs, float* loss, float* demb,
-                                                  float* dprotos, float loss_scale) {
+// Latency is the whole cost of this kernel (B x C = 8 x 2 outputs): round 3's 4-wave form walked the B + C rows and the
+// B C pairs in rounds of four with a dependent global load in each (17.9 us inside the step).  Now 16 waves, and the
+// (B + C) x 256 operands are staged ONCE into LDS by all threads (one round trip); every later phase is one round out of
+// LDS for B + C <= 16.  The arithmetic (summation order of every dot product, the loss sum) is unchanged.
+constexpr int NCE_THREADS = 1024;
+__global__ __launch_bounds__(NCE_THREADS) void nce_kernel(const float* emb, const float* protos, const int* label_col, int B,
+                                                         int C, float* sim, float* probs, float* loss, float* demb,
+                                                         float* dprotos, float loss_scale, int staged) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* en = (float*)smem;                 // [B] |emb|
     float* pn = en + B;                       // [C] |p|
     float* ss = pn + C;                       // [B*C] sim
     float* dsim = ss + B * C;                 // [B*C]
     float* lrow = dsim + B * C;               // [B]
+    float* stage = lrow + B + ((4 - ((2 * B + C + 2 * B * C) & 3)) & 3);        // 16-B aligned: [B + C][EMB] when staged
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int r = w; r < B + C; r += 4) {
-        const float* v = r < B ? emb + (size_t)r * EMB : protos + (size_t)(r - B) * EMB;
+    constexpr int NWV = NCE_THREADS / 64;
+    const float* E = emb;
+    const float* P = protos;
+    if (staged) {
+        for (int i = tid; i < (B + C) * (EMB / 4); i += NCE_THREADS) {
+            const int r = i / (EMB / 4), c4 = i - r * (EMB / 4);
+            const float* v = r < B ? emb + (size_t)r * EMB : protos + (size_t)(r - B) * EMB;
+            *(f32x4*)(stage + (size_t)r * EMB + 4 * c4) = *(const f32x4*)(v + 4 * c4);
+        }
+        E = stage;
+        P = stage + (size_t)B * EMB;
+        __syncthreads();
+    }
+    for (int r = w; r < B + C; r += NWV) {
+        const float* v = r < B ? E + (size_t)r * EMB : P + (size_t)(r - B) * EMB;
         float a = 0.f;
         for (int c = lane; c < EMB; c += 64) a += v[c] * v[c];
         a = sqrtf(wave_sum(a));
         if (lane == 0) (r < B ? en[r] : pn[r - B]) = a;
     }
     __syncthreads();
-    for (int idx = w; idx < B * C; idx += 4) {
+    for (int idx = w; idx < B * C; idx += NWV) {
         int i = idx / C, j = idx % C;
         float a = 0.f;
-        for (int c = lane; c < EMB; c += 64) a += emb[(size_t)i * EMB + c] * protos[(size_t)j * EMB + c];
+        for (int c = lane; c < EMB; c += 64) a += E[(size_t)i * EMB + c] * P[(size_t)j * EMB + c];
         a = wave_sum(a) / (en[i] * pn[j]);
         if (lane == 0) { ss[idx] = a; if (sim) sim[idx] = a; }
     }
     __syncthreads();
-    for (int i = tid; i < B; i += 256) {
+    for (int i = tid; i < B; i += NCE_THREADS) {
         float den = 0.f;
         for (int j = 0; j < C; ++j) den += __expf(ss[i * C + j]);
         int y = label_col ? label_col[i] : 0;
@@ -345,10 +364,10 @@ __global__ __launch_bounds__(256) void nce_kernel(const float* emb, const float*
     }
     if (!demb) return;
     // d s_hat_i = sum_j dsim[i][j] p_hat_j ;  d emb_i = (d s_hat_i - s_hat_i (s_hat_i . d s_hat_i)) / |emb_i|
-    for (int r = w; r < B + C; r += 4) {
+    for (int r = w; r < B + C; r += NWV) {
         const bool is_e = r < B;
         const int i = is_e ? r : r - B;
-        const float* self = is_e ? emb + (size_t)i * EMB : protos + (size_t)i * EMB;
+        const float* self = is_e ? E + (size_t)i * EMB : P + (size_t)i * EMB;
         const float nself = is_e ? en[i] : pn[i];
         float g[EMB / 64], sh[EMB / 64];
         float dot = 0.f;
@@ -356,8 +375,8 @@ __global__ __launch_bounds__(256) void nce_kernel(const float* emb, const float*
         for (int u = 0; u < EMB / 64; ++u) {
             int c = lane + 64 * u;
             float a = 0.f;
-            if (is_e) for (int j = 0; j < C; ++j) a += dsim[i * C + j] * protos[(size_t)j * EMB + c] / pn[j];
-            else      for (int k = 0; k < B; ++k) a += dsim[k * C + i] * emb[(size_t)k * EMB + c] / en[k];
+            if (is_e) for (int j = 0; j < C; ++j) a += dsim[i * C + j] * P[(size_t)j * EMB + c] / pn[j];
+            else      for (int k = 0; k < B; ++k) a += dsim[k * C + i] * E[(size_t)k * EMB + c] / en[k];
             g[u] = a;
             sh[u] = self[c] / nself;
             dot += a * sh[u];
@@ -488,9 +507,12 @@ extern "C" int sais_nce(const float* emb, const float* protos, const int* label_
                         float* probs, float* loss, float* demb, float* dprotos, float loss_scale, void* stream) {
     SAIS_ENTER();
     if (!emb || !protos || B <= 0 || C <= 0 || (demb && (!dprotos || !label_col))) return SAIS_ERR_ARG;
-    int lds = (B + C + 2 * B * C + B) * 4;
+    int lds = (B + C + 2 * B * C + B + 3) * 4;
     if (lds > 64 * 1024) return SAIS_ERR_ARG;
-    hipLaunchKernelGGL(nce_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, emb, protos, label_col, B, C, sim, probs,
-                       loss, demb, dprotos, loss_scale);
+    const long stage = (long)(B + C) * EMB * 4;
+    const int staged = lds + stage <= 60 * 1024 ? 1 : 0;              // within the default dynamic-LDS limit: no attribute call
+    if (staged) lds += (int)stage;
+    hipLaunchKernelGGL(nce_kernel, dim3(1), dim3(NCE_THREADS), lds, (hipStream_t)stream, emb, protos, label_col, B, C, sim,
+                       probs, loss, demb, dprotos, loss_scale, staged);
     return sais_check_launch();
 }

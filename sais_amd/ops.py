@@ -110,9 +110,11 @@ def gemm_ln_fwd(a, w, bias, resid, x_out, xn_out, gamma, beta, eps, mean=None, r
            lambda: L.call("sais_gemm_ln_fwd", ctypes.byref(g), _stream()))
 
 
-def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dgamma=None, dbeta=None, rowscale16=None):
+def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dgamma=None, dbeta=None, rowscale16=None,
+                dres_period=0):
     """dy = a[M,K] . w[384,K]^T, then LayerNorm backward at the saved input x / mean / rstd:
-    dx = dres + dLN(dy) -> dx32 (f32) and/or dx16 (bf16); dgamma / dbeta accumulated.  dres may alias dx32."""
+    dx = dres + dLN(dy) -> dx32 (f32) and/or dx16 (bf16); dgamma / dbeta accumulated.  dres may alias dx32.
+    dres_period > 0: dres is compact [M / period, 384] — row m gets dres[m / period] when m % period == 0, else nothing."""
     _chk(a, BF16, "A"); _chk(w, BF16, "W"); _chk(x, F32, "x"); _chk(dres, F32, "dres"); _chk(dx32, F32, "dx32")
     _chk(dx16, BF16, "dx16"); _chk(gamma, F32, "gamma")
     M, K = a.shape
@@ -120,10 +122,57 @@ def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dga
         raise L.SaisHipError(f"gemm_ln_bwd: W must be [384,{K}], got {tuple(w.shape)}")
     g = L.SaisGemmLn(_p(a), a.stride(0), _p(w), w.stride(0), M, K, None, _p(x), _ld(x), _p(dx32), _ld(dx32),
                      _p(dx16), _ld(dx16), _p(gamma), None, 0.0, _p(mean), _p(rstd), _p(dres), _ld(dres),
-                     _p(dgamma), _p(dbeta), None, _p(rowscale16))
+                     _p(dgamma), _p(dbeta), None, _p(rowscale16), int(dres_period))
     nbytes = 2 * (M * K + 384 * K) + M * 384 * (4 + 4 + 4 + 2)
     _timed(f"gemm_ln_bwd[N384,K{K}]", 2.0 * M * 384 * K, nbytes,
            lambda: L.call("sais_gemm_ln_bwd", ctypes.byref(g), _stream()))
+
+
+MLP_FUSED_MIN_M = 8192       # from this M on, the MLP branch of a ViT block is ONE launch per direction (mlp_fused.hip)
+
+
+def mlp_fused_enabled(M):
+    """SAIS_MLP_FUSED=1 runs the MLP branch of every ViT block as ONE launch per direction (sais_mlp_fwd / _bwd).  It is
+    correct (same h / g' bits, same x_out up to fp32 summation order: tests/test_kernels_gpu.py) but MEASURED SLOWER than the
+    launch pairs it replaces at the benchmark's size, so the default is the two-launch form."""
+    import os
+    return os.environ.get("SAIS_MLP_FUSED", "0") == "1" and M >= MLP_FUSED_MIN_M
+
+
+def mlp_fwd(xn2, w1, b1, w2, b2, resid, x_out, h=None, g=None, xn_out=None, gamma=None, beta=None, eps=1e-6, mean=None,
+            rstd=None, rowscale=None):
+    """Mlp.forward + residual add + the next LayerNorm in ONE launch (include/sais_hip.h, sais_mlp_fwd):
+    u = xn2 . w1^T + b1; h = GELU(u); g = GELU'(u); x_out = resid + rowscale (h . w2^T + b2); xn_out = LN(x_out).
+    h / g None: not materialised (inference).  gamma None: no following LayerNorm (the last block)."""
+    _chk(xn2, BF16, "xn2"); _chk(w1, BF16, "w1"); _chk(w2, BF16, "w2"); _chk(b1, F32, "b1"); _chk(b2, F32, "b2")
+    _chk(resid, F32, "resid"); _chk(x_out, F32, "x_out"); _chk(h, BF16, "h"); _chk(g, BF16, "g"); _chk(xn_out, BF16, "xn_out")
+    M, H = xn2.shape[0], w1.shape[0]
+    if tuple(w1.shape) != (H, 384) or tuple(w2.shape) != (384, H) or xn2.shape[1] != 384:
+        raise L.SaisHipError(f"mlp_fwd: shapes {tuple(xn2.shape)} {tuple(w1.shape)} {tuple(w2.shape)}")
+    tail = L.SaisGemmLn(None, 0, None, 0, M, H, _p(b2), _p(resid), _ld(resid), _p(x_out), _ld(x_out), _p(xn_out),
+                        _ld(xn_out), _p(gamma), _p(beta), eps, _p(mean), _p(rstd), None, 0, None, None, _p(rowscale), None)
+    a = L.SaisMlp(_p(xn2), xn2.stride(0), _p(w1), w1.stride(0), _p(b1), _p(w2), w2.stride(0), M, H, _p(h), _ld(h),
+                  _p(g), _ld(g), tail)
+    nbytes = 2 * M * 384 + 4 * 384 * H + 2 * M * H * ((h is not None) + (g is not None)) + M * 384 * (4 + 4 + (2 if gamma is not None else 0))
+    _timed(f"mlp_fwd[H{H}]", 4.0 * M * 384 * H, nbytes, lambda: L.call("sais_mlp_fwd", ctypes.byref(a), _stream()))
+
+
+def mlp_bwd(d16, w2t, g, w1t, du, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dgamma=None, dbeta=None,
+            rowscale16=None):
+    """dX of the MLP branch + LayerNorm backward in ONE launch (sais_mlp_bwd): du = (d16 . w2t^T) * g -> du (bf16, kept for
+    dW1); dxn = du . w1t^T; dx = dres + dLN(dxn) at the saved x / mean / rstd.  w2t = fc2.weight^T [H,384],
+    w1t = fc1.weight^T [384,H]."""
+    _chk(d16, BF16, "d16"); _chk(w2t, BF16, "w2t"); _chk(w1t, BF16, "w1t"); _chk(g, BF16, "g"); _chk(du, BF16, "du")
+    _chk(x, F32, "x"); _chk(dres, F32, "dres"); _chk(dx32, F32, "dx32"); _chk(dx16, BF16, "dx16"); _chk(gamma, F32, "gamma")
+    M, H = d16.shape[0], w2t.shape[0]
+    if tuple(w2t.shape) != (H, 384) or tuple(w1t.shape) != (384, H) or d16.shape[1] != 384:
+        raise L.SaisHipError(f"mlp_bwd: shapes {tuple(d16.shape)} {tuple(w2t.shape)} {tuple(w1t.shape)}")
+    tail = L.SaisGemmLn(None, 0, None, 0, M, H, None, _p(x), _ld(x), _p(dx32), _ld(dx32), _p(dx16), _ld(dx16), _p(gamma),
+                        None, 0.0, _p(mean), _p(rstd), _p(dres), _ld(dres), _p(dgamma), _p(dbeta), None, _p(rowscale16))
+    a = L.SaisMlp(_p(d16), d16.stride(0), _p(w2t), w2t.stride(0), None, _p(w1t), w1t.stride(0), M, H, _p(du), _ld(du),
+                  _p(g), _ld(g), tail)
+    nbytes = 2 * M * 384 + 4 * 384 * H + 4 * M * H + M * 384 * (4 + 4 + 4 + 2)
+    _timed(f"mlp_bwd[H{H}]", 4.0 * M * 384 * H, nbytes, lambda: L.call("sais_mlp_bwd", ctypes.byref(a), _stream()))
 
 
 def gemm_nt_f32(a, w, epilogue, out, bias=None, aux=None, M=None, drop=None):
@@ -250,6 +299,21 @@ def vit_attn_bwd(qkv, dout, out, lse, delta_ws, frames, dqkv, ntok=197):
     _timed("vit_attn_bwd", 10.0 * frames * 6 * ntok * ntok * 64, 2 * frames * ntok * 384 * 9,
            lambda: L.call("sais_vit_attn_bwd", _p(qkv), qkv.stride(0), _p(dout), dout.stride(0), _p(out), out.stride(0),
                           _p(lse), _p(delta_ws), frames, ntok, _p(dqkv), dqkv.stride(0), _stream()))
+
+
+def vit_attn_cls_fwd(qkv, frames, out_c, ntok=197):
+    """The last block's attention for the CLS query only: out_c bf16 [frames, 384] (include/sais_hip.h)."""
+    _chk(qkv, BF16, "qkv"); _chk(out_c, BF16, "out")
+    _timed("vit_attn_cls_fwd", 4.0 * frames * 6 * ntok * 64, 2 * frames * ntok * 768,
+           lambda: L.call("sais_vit_attn_cls_fwd", _p(qkv), qkv.stride(0), frames, ntok, _p(out_c), out_c.stride(0), _stream()))
+
+
+def vit_attn_cls_bwd(qkv, dout_c, frames, dqkv, ntok=197):
+    """dqkv bf16 [frames*ntok, 1152] (written entirely) from the compact dout_c bf16 [frames, 384]."""
+    _chk(qkv, BF16, "qkv"); _chk(dout_c, BF16, "dout"); _chk(dqkv, BF16, "dqkv")
+    _timed("vit_attn_cls_bwd", 10.0 * frames * 6 * ntok * 64, 2 * frames * ntok * (768 + 1152),
+           lambda: L.call("sais_vit_attn_cls_bwd", _p(qkv), qkv.stride(0), _p(dout_c), dout_c.stride(0), frames, ntok,
+                          _p(dqkv), dqkv.stride(0), _stream()))
 
 
 def patchify(frames_f32, patches):

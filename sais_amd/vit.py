@@ -128,6 +128,11 @@ class VisionTransformer(nn.Module):
         self.depth = depth
         self.drop_path_rate = drop_path_rate        # identity in eval(); per-sample stochastic depth in train()
         self.drop_path_seed = 0
+        # forward() returns norm(x)[:, 0] (:212-214): of the LAST block only the CLS rows are ever read, so its row-local half
+        # (proj, norm2, MLP, residual adds) runs on the CLS rows and its attention for the CLS query only; outputs and all
+        # parameter gradients are unchanged.  SAIS_VIT_PRUNE_LAST=0 / prune_last_block = False computes every row.
+        import os as _os
+        self.prune_last_block = _os.environ.get("SAIS_VIT_PRUNE_LAST", "1") != "0"
         self._rng = None
         self.last_droppath_scales = None
         self.patch_embed = _PatchEmbed()
@@ -278,17 +283,27 @@ class VisionTransformer(nn.Module):
         xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
         xn2 = e16(M, D)
         mean1 = rstd1 = None
+        prune = self.prune_last_block and len(groups) == 1 and not want_last_attn
         for i in range(self.depth):
             p = f"blocks.{i}."
             last_attn = want_last_attn and i == self.depth - 1
             if save:
-                qkv, ao, h = e16(M, 3 * D), e16(M, D), e16(M, HID)
+                if prune and i == self.depth - 1:
+                    qkv = e16(M, 3 * D)                  # the pruned last block keeps its compact tensors itself
+                else:
+                    qkv, ao, h = e16(M, 3 * D), e16(M, D), e16(M, HID)
             if i == 0 or not fused:                      # otherwise xn / mean1 / rstd1 came out of the previous fc2
                 if save:
                     xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
                 ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
                                   rstd=rstd1)
             ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
+            if prune and i == self.depth - 1:
+                reps, tail = self._cls_tail_fwd(f, i, x, xn, mean1, rstd1, qkv, groups[0], dp, save, e16, e32)
+                if save:
+                    saved["blocks"].append(tail)
+                    saved.update(x_final=tail["x_out"], meanN=tail["meanN"], rstdN=tail["rstdN"], pruned=True)
+                return reps, saved
             lse, probs = [], None
             for g in groups:
                 Fr, ntok, lo = g["Fr"], g["ntok"], g["off"]
@@ -314,20 +329,30 @@ class VisionTransformer(nn.Module):
                 ops.layernorm_fwd(x_mid, M, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2,
                                   mean=mean2, rstd=rstd2)
             u = e16(M, HID) if save else None
-            ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
-                        bias=f.w32(p + "mlp.fc1.bias"), out2=u)
             x_out = e32(M, D) if save else x
             blk = dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, mean2=mean2,
                        rstd2=rstd2, xn2=xn2, dgelu=u, h=h) if save else None
-            if fused and i + 1 < self.depth:
-                q = f"blocks.{i + 1}."
-                if save:
-                    xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
-                ops.gemm_ln_fwd(h, f.w(p + "mlp.fc2.weight"), f.w32(p + "mlp.fc2.bias"), x_mid, x_out, xn,
-                                f.w32(q + "norm1.weight"), f.w32(q + "norm1.bias"), 1e-6, mean1, rstd1, rowscale=rs_mlp)
+            nxt = fused and i + 1 < self.depth
+            if nxt and save:
+                xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
+            q = f"blocks.{i + 1}." if nxt else None
+            if ops.mlp_fused_enabled(M):
+                # the whole MLP branch in ONE launch: fc1 + GELU (+ GELU') -> fc2 + residual (+ the next block's norm1); h is
+                # written for the backward pass but never read back, and in inference it is not materialised at all
+                ops.mlp_fwd(xn2, f.w(p + "mlp.fc1.weight"), f.w32(p + "mlp.fc1.bias"), f.w(p + "mlp.fc2.weight"),
+                            f.w32(p + "mlp.fc2.bias"), x_mid, x_out, h=h if save else None, g=u,
+                            xn_out=xn if nxt else None, gamma=f.w32(q + "norm1.weight") if nxt else None,
+                            beta=f.w32(q + "norm1.bias") if nxt else None, eps=1e-6, mean=mean1 if nxt else None,
+                            rstd=rstd1 if nxt else None, rowscale=rs_mlp)
             else:
-                ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"),
-                            aux=x_mid, rowscale=rs_mlp)
+                ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
+                            bias=f.w32(p + "mlp.fc1.bias"), out2=u)
+                if nxt:
+                    ops.gemm_ln_fwd(h, f.w(p + "mlp.fc2.weight"), f.w32(p + "mlp.fc2.bias"), x_mid, x_out, xn,
+                                    f.w32(q + "norm1.weight"), f.w32(q + "norm1.bias"), 1e-6, mean1, rstd1, rowscale=rs_mlp)
+                else:
+                    ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"),
+                                aux=x_mid, rowscale=rs_mlp)
             if save:
                 saved["blocks"].append(blk)
             x = x_out
@@ -343,6 +368,86 @@ class VisionTransformer(nn.Module):
             saved.update(x_final=x, meanN=meanN, rstdN=rstdN)
         return reps, saved
 
+    def _cls_tail_fwd(self, f, i, x, xn1, mean1, rstd1, qkv, grp, dp, save, e16, e32):
+        """The last block from its qkv on, restricted to what forward() returns (the CLS rows): attention for the CLS query
+        (sais_vit_attn_cls_fwd), then proj + residual, norm2, fc1 + GELU, fc2 + residual and the final norm on [frames, 384]
+        tensors.  The residual input is the strided view x[::ntok]."""
+        Fr, ntok = grp["Fr"], grp["ntok"]
+        p = f"blocks.{i}."
+        ao = e16(Fr, D)
+        ops.vit_attn_cls_fwd(qkv, Fr, ao, ntok)
+        x_cls = x.view(Fr, ntok, D)[:, 0]
+        rs_attn = None if dp is None else dp[2 * i].view(Fr, ntok)[:, 0].contiguous()
+        rs_mlp = None if dp is None else dp[2 * i + 1].view(Fr, ntok)[:, 0].contiguous()
+        x_mid, xn2, x_out = e32(Fr, D), e16(Fr, D), e32(Fr, D)
+        mean2, rstd2 = (e32(Fr), e32(Fr)) if save else (None, None)
+        ops.gemm_nt(ao, f.w(p + "attn.proj.weight"), L.EPI_BIAS_RESID_F32, x_mid, bias=f.w32(p + "attn.proj.bias"), aux=x_cls,
+                    rowscale=rs_attn)
+        ops.layernorm_fwd(x_mid, Fr, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2, mean=mean2,
+                          rstd=rstd2)
+        h, u = e16(Fr, HID), (e16(Fr, HID) if save else None)
+        ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
+                    bias=f.w32(p + "mlp.fc1.bias"), out2=u)
+        ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"), aux=x_mid,
+                    rowscale=rs_mlp)
+        reps = e32(Fr, D)
+        meanN, rstdN = (e32(Fr), e32(Fr)) if save else (None, None)
+        ops.layernorm_fwd(x_out, Fr, D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN, rstd=rstdN)
+        tail = dict(cls=True, x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn1, qkv=qkv, ao=ao, x_mid=x_mid, mean2=mean2, rstd2=rstd2,
+                    xn2=xn2, dgelu=u, h=h, rs_attn=rs_attn, rs_mlp=rs_mlp, x_out=x_out, meanN=meanN, rstdN=rstdN) if save else None
+        return reps, tail
+
+    def _cls_tail_bwd(self, f, saved, dreps, dx, dxa, dqkv, fused):
+        """Backward of _cls_tail_fwd: the gradient enters on the CLS rows only.  Everything row-local stays on [frames, 384]
+        tensors; the attention backward (sais_vit_attn_cls_bwd) writes the whole dqkv (dk, dv of every token, dq of the CLS
+        rows, zeros elsewhere); the dX of qkv + norm1's backward then writes EVERY row of dx / dxa, taking the residual-stream
+        gradient from the compact CLS tensor (dres_period) — no zero-filled [M, 384] buffer, no full-size cast."""
+        i = self.depth - 1
+        p = f"blocks.{i}."
+        s = saved["blocks"][i]
+        grp = saved["groups"][0]
+        Fr, ntok, M = grp["Fr"], grp["ntok"], saved["M"]
+        dev = dreps.device
+        e16 = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=dev)
+        dx_c = torch.empty(Fr, D, dtype=torch.float32, device=dev)
+        ops.layernorm_bwd(s["x_out"], D, s["meanN"], s["rstdN"], f.w32("norm.weight"), Fr, dy32=dreps, dx32=dx_c,
+                          dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
+        if self.grad_ready_hook:
+            self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
+        dxa_c, du, dxn, dxb_c, dao = e16(Fr, D), e16(Fr, HID), e16(Fr, D), e16(Fr, D), e16(Fr, D)
+        if s["rs_mlp"] is None:
+            ops.cast_bf16(dx_c, dxa_c)
+        else:
+            ops.cast_bf16_rows(dx_c, s["rs_mlp"], dxa_c)
+        ops.gemm_nt(dxa_c, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
+        ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
+        ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), Fr, dy16=dxn, dres=dx_c, dx32=dx_c,
+                          dx16=dxb_c, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"), rowscale16=s["rs_attn"])
+        ops.gemm_nt(dxb_c, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
+        ops.vit_attn_cls_bwd(s["qkv"], dao, Fr, dqkv, ntok)
+        ops.gemm_tn_grouped([
+            (dxa_c, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
+            (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
+            (dxb_c, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias"))], Fr)
+        ops.gemm_tn_grouped([(dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
+        dp = saved.get("dp")
+        rs_prev = None if dp is None or i == 0 else dp[2 * (i - 1) + 1]
+        if fused:
+            ops.gemm_ln_bwd(dqkv, f.wt16[p + "attn.qkv.weight"], s["x_in"], s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"),
+                            dres=dx_c, dres_period=ntok, dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"),
+                            dbeta=f.g(p + "norm1.bias"), rowscale16=rs_prev)
+        else:                                         # small M: scatter the CLS gradient into a zeroed residual-stream gradient
+            dx.zero_()
+            dx.view(Fr, ntok, D)[:, 0].copy_(dx_c)
+            dxn_full = e16(M, D)
+            ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn_full)
+            ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn_full, dres=dx,
+                              dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"),
+                              rowscale16=rs_prev)
+        saved["blocks"][i] = None
+        if self.grad_ready_hook:
+            self.grad_ready_hook(*self.block_grad_range(i))
+
     # ------------------------------------------------------------------ backward kernels
     def _backward_kernels(self, saved, dreps):
         f = self.flat
@@ -350,9 +455,16 @@ class VisionTransformer(nn.Module):
         dev = dreps.device
         groups, M = saved["groups"], saved["M"]
         e16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
-        dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
+        pruned = bool(saved.get("pruned"))
+        fused = M >= ops.ROW_GEMM_MIN_M
         dxa, dxb = e16(M, D), e16(M, D)            # bf16 copies of the residual-stream gradient (block input / mid)
-        for g in groups:
+        if pruned:                                  # every row of dx is WRITTEN by the last block's dX qkv + norm1' kernel
+            dx = torch.empty(M, D, dtype=torch.float32, device=dev)
+            dqkv0 = e16(M, 3 * D)
+            self._cls_tail_bwd(f, saved, dreps, dx, dxa, dqkv0, fused)
+        else:
+            dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
+        for g in ([] if pruned else groups):
             Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
             ops.layernorm_bwd(saved["x_final"][lo:lo + Fr * ntok], ntok * D, saved["meanN"][fo:fo + Fr],
                               saved["rstdN"][fo:fo + Fr], f.w32("norm.weight"), Fr, dy32=dreps[fo:fo + Fr],
@@ -361,26 +473,33 @@ class VisionTransformer(nn.Module):
         dp = saved.get("dp")
         # with DropPath the gradient that enters a branch is s dx (the residual stream keeps dx): the bf16 copies carry the
         # NEXT branch's scale — dxa feeds an MLP branch (2i + 1), dxb an attention branch (2i)
-        if dp is None:
+        if pruned:
+            pass
+        elif dp is None:
             ops.cast_bf16(dx, dxa)
         else:
             ops.cast_bf16_rows(dx, dp[2 * (self.depth - 1) + 1], dxa)
-        fused = M >= ops.ROW_GEMM_MIN_M
-        dxn, dao, du, dqkv = (None if fused else e16(M, D)), e16(M, D), e16(M, HID), e16(M, 3 * D)
-        if self.grad_ready_hook:
+        dxn, dao, du = (None if fused else e16(M, D)), e16(M, D), e16(M, HID)
+        dqkv = dqkv0 if pruned else e16(M, 3 * D)
+        if self.grad_ready_hook and not pruned:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
-        for i in reversed(range(self.depth)):
+        for i in reversed(range(self.depth - 1 if pruned else self.depth)):
             p = f"blocks.{i}."
             s = saved["blocks"][i]
             rs_attn = None if dp is None else dp[2 * i]                        # this block's attention branch
             rs_prev = None if dp is None or i == 0 else dp[2 * (i - 1) + 1]     # the MLP branch of block i - 1
             # MLP branch
-            ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
-            if fused:         # dX of fc1 with norm2's backward (+ residual gradient) in its epilogue
+            if fused and ops.mlp_fused_enabled(M):    # dX of fc2 x GELU' -> dX of fc1 -> norm2's backward: ONE launch
+                ops.mlp_bwd(dxa, f.wt16[p + "mlp.fc2.weight"], s["dgelu"], f.wt16[p + "mlp.fc1.weight"], du, s["x_mid"],
+                            s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), dres=dx, dx32=dx, dx16=dxb,
+                            dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"), rowscale16=rs_attn)
+            elif fused:       # dX of fc1 with norm2's backward (+ residual gradient) in its epilogue
+                ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
                 ops.gemm_ln_bwd(du, f.wt16[p + "mlp.fc1.weight"], s["x_mid"], s["mean2"], s["rstd2"],
                                 f.w32(p + "norm2.weight"), dres=dx, dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"),
                                 dbeta=f.g(p + "norm2.bias"), rowscale16=rs_attn)
             else:
+                ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
                 ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
                 ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
                                   dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"),

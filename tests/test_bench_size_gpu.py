@@ -212,8 +212,26 @@ def test_two_stream_train_step_stagewise_vs_oracle_at_config4_size(gpu):
     worst = max(rel_l2(P[n].grad, tsd[n].grad) for n in (
         "linear.weight", "frame_cls", "frame_pos_embeddings.0", "transEncoderFrame.layers.0.self_attn.in_proj_weight",
         "transEncoderFrame.layers.3.norm2.bias", "transEncoderFrame.layers.1.linear1.weight"))
-    parity_log(tag + "temporal parameter gradients, worst tensor rel-L2", worst, GRAD_REL)
-    assert worst <= GRAD_REL, worst
+    # vs the fp32 oracle a ReLU gate within rounding of zero may be open in one evaluation and closed in the other, which moves
+    # that clip's gradient by per cents: loose bar here, tight bar against the fp64 oracle at the HIP forward's
+    # own gates below
+    parity_log(tag + "temporal parameter gradients, worst tensor rel-L2", worst, 4e-2)
+    assert worst <= 4e-2, worst
+    from parity import hip_temporal_gates
+    gd = reps.detach().view(2, B, 1, T, 384)
+    gates = hip_temporal_gates(m, gd[0], gd[1], pad.to(DEV), pad.to(DEV))
+    tsd64 = {k: v.double().clone().requires_grad_(True) for k, v in synth.temporal_state_dict(seed=1).items()}
+    pr64 = {k: v.double().clone() for k, v in synth.prototypes(2, 2).items()}
+    rx64, rf64 = gx[0].double().clone().requires_grad_(True), gx[1].double().clone().requires_grad_(True)
+    with O.imposed_gates(gates) as ig:
+        e64, _ = O.temporal_forward(tsd64, rx64, rf64, pad, pad, "RGB-Flow")
+        O.nce_loss(e64, lab, pr64).backward()
+    tight = max(rel_l2(P[n].grad, tsd64[n].grad) for n in (
+        "linear.weight", "frame_cls", "frame_pos_embeddings.0", "transEncoderFrame.layers.0.self_attn.in_proj_weight",
+        "transEncoderFrame.layers.3.norm2.bias", "transEncoderFrame.layers.1.linear1.weight"))
+    parity_log(tag + "temporal parameter gradients vs fp64 oracle at the same ReLU gates, worst tensor", tight, 5e-3)
+    parity_log(tag + "ReLU gates that differ from the fp64 oracle", sum(ig.mismatches), 400)
+    assert tight <= 5e-3 and sum(ig.mismatches) <= 400, (tight, ig.mismatches)
     # stage 2: ViT backward over all 512 frames
     worst = max(rel_l2(q.grad, vsd[n].grad) for n, q in vit.named_parameters())
     parity_log(tag + "ViT parameter gradients, worst tensor rel-L2 (150 tensors)", worst, VIT_GRAD_REL)

@@ -215,6 +215,35 @@ def test_vit_attention_fwd_bwd(ops, frames):
     assert torch.equal(again, dqkv)
 
 
+@pytest.mark.parametrize("frames,ntok", [(5, 197), (70, 197), (9, 37)])
+def test_vit_attention_cls_query_only(ops, frames, ntok):
+    """The last block's attention restricted to the CLS query (sais_vit_attn_cls_fwd / _bwd) vs fp32 torch autograd of the
+    full attention with the output gradient zero outside the CLS rows: out on [frames, 384]; dqkv complete (dk, dv of every
+    token, dq on the CLS rows, exact zeros elsewhere)."""
+    qkv = rnd(frames * ntok, 1152, seed=33, scale=1.5, dtype=torch.bfloat16)
+    out_c = torch.full((frames, 384), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.vit_attn_cls_fwd(qkv, frames, out_c, ntok)
+    qr = qkv.float().requires_grad_(True)
+    t = qr.view(frames, ntok, 3, 6, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax((t[0] @ t[1].transpose(-2, -1)) * 0.125, -1) @ t[2]).transpose(1, 2).reshape(frames, ntok, 384)
+    assert_close(out_c, ref[:, 0], atol=2e-2, rtol=2e-2, name="out (CLS rows)")
+    dout_c = rnd(frames, 384, seed=34, dtype=torch.bfloat16)
+    ref[:, 0].backward(dout_c.float())
+    dqkv = torch.full((frames * ntok, 1152), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.vit_attn_cls_bwd(qkv, dout_c, frames, dqkv, ntok)
+    g = qr.grad
+    assert torch.isfinite(dqkv.float()).all()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a, b = dqkv[:, 384 * i:384 * (i + 1)].float(), g[:, 384 * i:384 * (i + 1)]
+        assert ((a - b).norm() / b.norm()).item() <= 6e-3, name              # bf16 rounding of the outputs only
+    dq = dqkv[:, :384].float().view(frames, ntok, 384)
+    assert float(dq[:, 1:].abs().max()) == 0.0 and float(dq[:, 0].abs().max()) > 0
+    if ntok == 197:                                       # and against the full kernels on the same data
+        out = torch.empty(frames * 197, 384, dtype=torch.bfloat16, device=DEV)
+        ops.vit_attn_fwd(qkv, frames, out)
+        assert_close(out_c, out.view(frames, 197, 384)[:, 0], atol=2e-2, rtol=2e-2, name="vs the full forward")
+
+
 def test_vit_attention_forced_peaky_rows(ops):
     """A spiked key per query forces near-one-hot softmax rows (exercises the max subtraction)."""
     frames = 1
@@ -564,6 +593,117 @@ def test_gemm_ln_bwd(ops, M, K):
     dx_only = torch.empty(M, 384, device=DEV)
     ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dx32=dx_only)
     assert_close(dx_only, xr.grad, atol=2e-4 * scale, rtol=1e-4, name="dx (no dres)")
+
+
+def _gelu_parts(u):
+    cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
+    return u * cdf, cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+
+
+@pytest.mark.parametrize("M,ln,dp", [(8192 + 57, True, False), (197 * 64, True, True), (197 * 146 + 5, False, True),
+                                     (197 * 256, True, False)])
+def test_mlp_fused_fwd(ops, M, ln, dp):
+    """sais_mlp_fwd (fc1 + GELU / GELU' -> fc2 + residual -> LayerNorm in ONE launch) vs (a) fp32 torch on the same bf16
+    operands and (b) the two-launch form it replaces (gemm_nt<GELU_GRAD> + gemm_ln_fwd / gemm_nt<RESID>), ragged last tile,
+    DropPath row scales, with and without the following LayerNorm, training (h, g written) and inference (nothing
+    materialised) forms."""
+    from sais_amd import _lib as L
+    H = 1536
+    xn2 = rnd(M, 384, seed=300, dtype=torch.bfloat16)
+    w1 = rnd(H, 384, seed=301, scale=0.06, dtype=torch.bfloat16)
+    w2 = rnd(384, H, seed=302, scale=0.04, dtype=torch.bfloat16)
+    b1, b2 = rnd(H, seed=303, scale=0.3), rnd(384, seed=304, scale=0.1)
+    resid = rnd(M, 384, seed=305, scale=2.0)
+    resid[:, 7] += 30.0
+    gamma, beta = 1 + 0.1 * rnd(384, seed=306), 0.05 * rnd(384, seed=307)
+    rs = None
+    if dp:
+        rs = (torch.rand(M, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) > 0.2).float() / 0.8
+    x_out = torch.empty(M, 384, device=DEV)
+    xn = torch.empty(M, 384, dtype=torch.bfloat16, device=DEV) if ln else None
+    mean, rstd = (torch.empty(M, device=DEV), torch.empty(M, device=DEV)) if ln else (None, None)
+    h = torch.full((M, H), 7.0, dtype=torch.bfloat16, device=DEV)
+    g = torch.full((M, H), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.mlp_fwd(xn2, w1, b1, w2, b2, resid, x_out, h=h, g=g, xn_out=xn, gamma=gamma if ln else None,
+                beta=beta if ln else None, eps=1e-6, mean=mean, rstd=rstd, rowscale=rs)
+    # (a) fp32 reference; the second GEMM sees the bf16-rounded h, as in the kernel
+    u = xn2.float() @ w1.float().t() + b1
+    h_ref, g_ref = _gelu_parts(u)
+    assert_close(h, h_ref, atol=2e-2, rtol=1e-2, name="h")
+    assert_close(g, g_ref, atol=2e-2, rtol=1e-2, name="g")
+    y = h.float() @ w2.float().t() + b2
+    ref_x = resid + (y * rs[:, None] if dp else y)
+    assert_close(x_out, ref_x, atol=3e-3, rtol=1e-5, name="x_out")
+    if ln:
+        assert_close(mean, ref_x.mean(1), atol=1e-4, name="mean")
+        assert_close(rstd, 1.0 / torch.sqrt(ref_x.var(1, unbiased=False) + 1e-6), atol=0, rtol=1e-4, name="rstd")
+        assert_close(xn, _ln_ref(x_out, gamma, beta, 1e-6), atol=2e-2, rtol=1e-2, name="xn")
+    # (b) the two-launch form: same bf16 h / g (same arithmetic, element for element), same x_out up to fp32 summation order
+    h2, g2 = torch.empty_like(h), torch.empty_like(g)
+    ops.gemm_nt(xn2, w1, L.EPI_BIAS_GELU_GRAD_BF16, h2, bias=b1, out2=g2)
+    assert torch.equal(h2, h) and torch.equal(g2, g)
+    x2 = torch.empty_like(x_out)
+    if ln:
+        xn_2 = torch.empty_like(xn)
+        ops.gemm_ln_fwd(h2, w2, b2, resid, x2, xn_2, gamma, beta, 1e-6, rowscale=rs)
+    else:
+        ops.gemm_nt(h2, w2, L.EPI_BIAS_RESID_F32, x2, bias=b2, aux=resid, rowscale=rs)
+    assert_close(x_out, x2, atol=1e-5, rtol=1e-6, name="x_out vs two launches")
+    # inference form: nothing materialised, in place on the residual stream
+    r2 = resid.clone()
+    ops.mlp_fwd(xn2, w1, b1, w2, b2, r2, r2, xn_out=xn, gamma=gamma if ln else None, beta=beta if ln else None,
+                eps=1e-6, rowscale=rs)
+    assert_close(r2, x_out, atol=1e-5, rtol=1e-6, name="in place, h not materialised")
+
+
+@pytest.mark.parametrize("M,dp", [(8192 + 57, False), (197 * 146 + 5, True), (197 * 256, False)])
+def test_mlp_fused_bwd(ops, M, dp):
+    """sais_mlp_bwd (dX fc2 x GELU' -> dX fc1 -> LayerNorm backward in ONE launch) vs the two launches it replaces
+    (gemm_nt<MUL> + gemm_ln_bwd) and vs fp32 torch."""
+    from sais_amd import _lib as L
+    H = 1536
+    d16 = rnd(M, 384, seed=320, scale=0.5, dtype=torch.bfloat16)
+    w2t = rnd(H, 384, seed=321, scale=0.05, dtype=torch.bfloat16)          # fc2.weight^T
+    w1t = rnd(384, H, seed=322, scale=0.05, dtype=torch.bfloat16)          # fc1.weight^T
+    g = (0.5 + 0.6 * rnd(M, H, seed=323)).to(torch.bfloat16)
+    x = rnd(M, 384, seed=324, scale=1.5)
+    x[:, 11] -= 20.0
+    gamma = 1 + 0.1 * rnd(384, seed=325)
+    dres = rnd(M, 384, seed=326)
+    mean = x.mean(1)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+    rs = None
+    if dp:
+        rs = (torch.rand(M, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6)) > 0.2).float() / 0.8
+    dgamma, dbeta = torch.zeros(384, device=DEV), torch.zeros(384, device=DEV)
+    dx32 = dres.clone()
+    dx16 = torch.empty(M, 384, dtype=torch.bfloat16, device=DEV)
+    du = torch.full((M, H), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.mlp_bwd(d16, w2t, g, w1t, du, x, mean, rstd, gamma, dres=dx32, dx32=dx32, dx16=dx16, dgamma=dgamma, dbeta=dbeta,
+                rowscale16=rs)
+    # the two-launch form
+    du2 = torch.empty_like(du)
+    ops.gemm_nt(d16, w2t, L.EPI_MUL_BF16, du2, aux=g)
+    assert torch.equal(du2, du)
+    dg2, db2 = torch.zeros(384, device=DEV), torch.zeros(384, device=DEV)
+    dx32_2, dx16_2 = dres.clone(), torch.empty_like(dx16)
+    ops.gemm_ln_bwd(du2, w1t, x, mean, rstd, gamma, dres=dx32_2, dx32=dx32_2, dx16=dx16_2, dgamma=dg2, dbeta=db2, rowscale16=rs)
+    scale = float((du.float() @ w1t.float().t()).abs().max())
+    assert_close(dx32, dx32_2, atol=1e-5 * scale, rtol=1e-5, name="dx32 vs two launches")
+    assert_close(dgamma, dg2, atol=2e-5 * scale * math.sqrt(M), rtol=1e-4, name="dgamma vs two launches")
+    assert_close(dbeta, db2, atol=2e-5 * scale * math.sqrt(M), rtol=1e-4, name="dbeta vs two launches")
+    # fp32 torch
+    dy = du.float() @ w1t.float().t()
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = torch.zeros(384, device=DEV, requires_grad=True)
+    F.layer_norm(xr, (384,), gr, br, 1e-6).backward(dy)
+    assert_close(du, (d16.float() @ w2t.float().t()) * g.float(), atol=2e-2, rtol=1e-2, name="du")
+    assert_close(dx32, xr.grad + dres, atol=2e-4 * scale, rtol=1e-4, name="dx32")
+    want16 = (xr.grad + dres) * (rs[:, None] if dp else 1.0)
+    assert_close(dx16, want16, atol=2e-2, rtol=1e-2, name="dx16")
+    assert_close(dgamma, gr.grad, atol=2e-4 * scale * math.sqrt(M), rtol=1e-4, name="dgamma")
+    assert_close(dbeta, br.grad, atol=2e-4 * scale * math.sqrt(M), rtol=1e-4, name="dbeta")
 
 
 def test_integration_md_ctypes_stub_runs_as_written(ops):

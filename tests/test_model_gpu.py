@@ -391,6 +391,36 @@ def test_sgd_step_matches_oracle_update(gpu):
     assert loss1.item() < loss.item()
 
 
+@pytest.mark.parametrize("frames,rate", [(6, 0.0), (48, 0.2)])
+def test_pruned_last_block_equals_full_compute(gpu, frames, rate):
+    """forward() returns norm(x)[:, 0]: the last block runs on the CLS rows / the CLS query only (sais_amd.vit,
+    prune_last_block).  Features and EVERY parameter gradient must equal the run that computes all rows (both dispatch
+    regimes: stand-alone kernels at 6 frames, row-owning / fused kernels at 48; with DropPath draws shared)."""
+    from sais_amd.vit import vit_small
+
+    def run(prune):
+        v = vit_small(patch_size=16, drop_path_rate=rate, depth=3)
+        v.load_state_dict(synth.vit_state_dict(seed=0, depth=3), strict=True)
+        v = v.to(DEV).train()
+        v.prune_last_block = prune
+        v.drop_path_seed = 3
+        x = synth.clips(seed=941, B=1, T=frames)[0].to(DEV)
+        w = synth.reps(seed=942, B=1, T=frames)[0, 0].to(DEV)
+        feat = v(x)
+        (feat * w).sum().backward()
+        with torch.no_grad():
+            ev = v.eval()(x)
+        return feat.detach(), {n: q.grad.detach().clone() for n, q in v.named_parameters()}, ev
+
+    f1, g1, e1 = run(True)
+    f0, g0, e0 = run(False)
+    scale = float(f0.abs().max())
+    assert float((f1 - f0).abs().max()) <= 5e-3 * scale and float((e1 - e0).abs().max()) <= 5e-3 * scale
+    worst = {n: float((g1[n] - g0[n]).norm() / g0[n].norm().clamp_min(1e-12)) for n in g0}
+    bad = {n: r for n, r in worst.items() if r > 1e-2}
+    assert not bad, bad
+
+
 def test_outlier_weights_logits_within_the_bar(gpu, golden):
     """Weights with the dynamic range of a TRAINED DINO checkpoint (synth.vit_state_dict_outlier: massive-activation
     residual channels up to |x| ~ 70, LayerNorm gains x20-x50, sharper attention) instead of an initialiser's: the
