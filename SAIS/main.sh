@@ -1,7 +1,8 @@
 #!/bin/bash
 # Same surface as the reference's SAIS/main.sh (:1-30): run from the repo root  ->  bash ./SAIS/main.sh -f <videoname>
-# Stages that are out of this build's scope are skipped with a note (ffmpeg frame dump, RAFT optical flow:
-# SURVEY.md §2); the two stages on the hot path run on the MI355X kernels.
+# The ffmpeg frame dump (video_to_frames.sh) is out of this build's scope: frames are read from
+# ./SAIS/images/<video>/.  Every other stage runs: the flow maps (RAFT, parity unpinned: sais_amd/raft.py), the two feature
+# extractions and the inference on the MI355X kernels.
 while getopts f:s: flag
 do
     case "${flag}" in
@@ -12,11 +13,12 @@ done
 SYN=""
 if [ -n "$synthetic" ]; then SYN="--synthetic_frames $synthetic"; fi
 
-# (video_to_frames.sh / --optical_flow: not part of this build — frames are read straight from
-#  ./SAIS/images/<video>/ and ./SAIS/flows/<video>/ if they exist)
 
 # generate paths to frames and flows and save as csv files
 python ./SAIS/scripts/generate_paths.py -f $videoname -p ./SAIS/ $SYN || exit 1
+
+# generate flow maps (skipped for a video whose ./SAIS/flows/<video>/ already exists, as in the reference)
+python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 2 --data_path ./SAIS/ --data_list Custom --save_type h5 --optical_flow --video $videoname $SYN || exit 1
 
 # extract representations of rgb images
 python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 1024 --data_path ./SAIS/ --data_list Custom --save_type h5 --video $videoname $SYN || exit 1

@@ -55,6 +55,70 @@ def frame_batches(folder, dev, chunk=256, rank=0, world=1):
         yield flush()
 
 
+def extract_flows(args, t0):
+    """--optical_flow (reference :30-143,221-288 and the __main__ branch :472-497): for every row of
+    paths/<dataset>_FlowPaths.csv (frames 15 apart, written by generate_paths.py) estimate the flow with RAFT, colour-code it
+    (flow_to_rgb) and save flows/<label>/flows_<nflow:08d>.jpg with nflow = frame number // jump_size.  RAFT runs on the GPU
+    (sais_amd.raft: correlation volume on the HIP kernels); PARITY UNPINNED — ptlflow 0.2.5 / the 'things' checkpoint are
+    absent, so without --raft_checkpoint the weights are seeded random.  Videos whose flows folder exists are skipped, as in
+    the reference (:487)."""
+    import csv
+    from PIL import Image
+    from sais_amd.raft import RAFT, flow_image_uint8, flow_to_rgb
+    dev = torch.device('cuda', args.local_rank)
+    torch.manual_seed(0)
+    model = RAFT(iters=args.raft_iters)
+    if args.raft_checkpoint:
+        sd = torch.load(args.raft_checkpoint, map_location='cpu')
+        model.load_state_dict({k.replace('module.', '', 1): v for k, v in sd.items()}, strict=True)
+    else:
+        print('[flow] no --raft_checkpoint: seeded random RAFT weights (parity unpinned; see sais_amd/raft.py)')
+    model = model.to(dev).eval()
+    for dataset in args.data_list:
+        jump = 30 if dataset in ('VUA_Lab', 'DVC_UCL') else 15                       # :488-493
+        with open(os.path.join(args.data_path, 'paths', '%s_FlowPaths.csv' % dataset)) as fh:
+            rows = list(csv.DictReader(fh))
+        if args.video:
+            rows = [r for r in rows if r['label'] == args.video]
+        done = {lab for lab in {r['label'] for r in rows} if os.path.exists(os.path.join(args.data_path, 'flows', lab))}
+        rows = [r for r in rows if r['label'] not in done]
+        bs = max(1, args.batch_size_per_gpu)
+        nsaved = 0
+        for i in range(0, len(rows), bs):
+            chunk = rows[i:i + bs]
+            pairs, nflows = [], []
+            for r in chunk:
+                p1, p2 = (r[k].replace('\\', '/') for k in ('path1', 'path2'))
+                name = 'frames_' if 'frames' in p1 else 'frame_'
+                nflows.append(int(p1.split(name)[-1].strip('.jpg')) // jump)          # :104
+                if args.synthetic_frames:
+                    g = torch.Generator().manual_seed(nflows[-1])
+                    base = torch.rand(3, 232, 232, generator=g)
+                    pairs.append((base[:, :224, :224], base[:, 4:228, 2:226]))
+                else:
+                    fr = []
+                    for p in (p1, p2):
+                        with Image.open(os.path.join(args.data_path, p)) as im:
+                            a = torch.from_numpy(np.asarray(im.convert('RGB'))).permute(2, 0, 1).float() / 255.0
+                        fr.append(a.flip(0))                                          # cv.imread order (BGR), as the reference feeds it
+                    pairs.append(tuple(fr))
+            shapes = {tuple(a.shape) for a, _ in pairs}
+            groups = [[k for k, (a, _) in enumerate(pairs) if tuple(a.shape) == sh] for sh in shapes]
+            for idx in groups:                                                         # frames of one size per batch
+                i1 = torch.stack([pairs[k][0] for k in idx]).to(dev)
+                i2 = torch.stack([pairs[k][1] for k in idx]).to(dev)
+                flows = model(i1, i2)
+                for k, fl in zip(idx, flows):
+                    img = Image.fromarray(flow_image_uint8(flow_to_rgb(fl)))          # :245-249
+                    out = os.path.join(args.data_path, 'flows', chunk[k]['label'])
+                    os.makedirs(out, exist_ok=True)
+                    img.save(os.path.join(out, 'flows_%08d.jpg' % nflows[k]))         # :254-262
+                    nsaved += 1
+        print(f'[flow] {dataset}: {nsaved} flow maps saved' + (f' ({len(done)} videos already had flows)' if done else ''))
+    print('All Flows Saved!')
+    print('Time taken (s): %.3f' % (time.time() - t0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--arch', default='vit_small', type=str, choices=['vit_tiny', 'vit_small', 'vit_base'])
@@ -73,12 +137,18 @@ def main():
     ap.add_argument('--video', default=None, type=str, help='video label (folder under images/ or flows/)')
     ap.add_argument('--synthetic_frames', default=0, type=int, help='use N seeded synthetic frames instead of JPEGs')
     ap.add_argument('--checkpoint', default=None, type=str, help='dino_deitsmall16_pretrain.pth (default: dino-main/outputs/)')
+    ap.add_argument('--raft_checkpoint', default=None, type=str,
+                    help='--optical_flow: a RAFT state dict with the published key names (e.g. raft-things.pth); default: '
+                         'seeded random weights (ptlflow and its checkpoint are unreachable offline: parity unpinned)')
+    ap.add_argument('--raft_iters', default=12, type=int)
     args = ap.parse_args()
     if args.arch != 'vit_small' or args.patch_size != 16:
         raise SystemExit('the MI355X kernels implement vit_small / patch 16 only')
-    if args.optical_flow or args.segmentation or args.segmentation_to_reps:
-        raise SystemExit('RAFT optical flow / segmentation are out of scope of this build (SURVEY.md §2)')
+    if args.segmentation or args.segmentation_to_reps:
+        raise SystemExit('segmentation is out of scope of this build (SURVEY.md §2)')
     t0 = time.time()
+    if args.optical_flow:
+        return extract_flows(args, t0)
     from sais_amd.inference import FeatureExtractor
     from sais_amd.model_io import load_vit
     from sais_amd.parallel import gather_in_rank_order, init_from_env, shard_range

@@ -34,6 +34,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 MFMA_PEAK_TFLOPS = 2500.0        # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md (2:1-sparse figure NOT used)
 HBM_PEAK_GBPS = 8000.0           # HBM3E spec (same guide; ~6.3 TB/s achievable)
 FLOP_PER_FRAME_FWD_BWD = 27.475e9   # 3 x 9.197 GF - 0.1156 GF (no dX for pixels)
+# The last ViT block runs on the CLS rows / the CLS query only (sais_amd.vit, prune_last_block: forward() returns x[:, 0], so
+# the other rows of that block feed nothing): its proj, MLP and query-side attention products are not executed.  Per frame:
+# 3 x (proj .058098 + fc1 .232391 + fc2 .232391) + attention (fwd .059610, bwd 2.5 x) = 1.777 GF.  The roofline fractions
+# below are computed from the EXECUTED flops, so the pruning does not inflate them.
+FLOP_PRUNED_PER_FRAME = 3 * (0.058098e9 + 2 * 0.232391e9) + 3.5 * 0.059610e9
 FLOP_TEMPORAL_PER_CLIP = 3 * 0.57764e9
 HBM_BYTES_PER_FRAME = 133e6      # SURVEY §8d / BASELINE.md §4: fused bf16 plan, fwd+bwd
 
@@ -632,7 +637,9 @@ def main():
     if rank == 0:
         fps = world * B * T * args.steps / dt
         nstream = 2 if two else 1
-        step_flops = nstream * (B * T * FLOP_PER_FRAME_FWD_BWD + B * FLOP_TEMPORAL_PER_CLIP)
+        pruned = bool(getattr(vit, "prune_last_block", False))
+        per_frame = FLOP_PER_FRAME_FWD_BWD - (FLOP_PRUNED_PER_FRAME if pruned else 0.0)
+        step_flops = nstream * (B * T * per_frame + B * FLOP_TEMPORAL_PER_CLIP)
         if roof is not None:
             roof["hbm_frac"] = round(nstream * B * T * HBM_BYTES_PER_FRAME * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)
             roof["hbm_frac_note"] = "MODEL-based: 133 MB/frame fused-plan algorithmic bytes / step time / 8 TB/s"
@@ -655,7 +662,14 @@ def main():
                                     f"random-init weights, RGB stream"), "clips_per_gpu": B, "frames_per_clip": T,
                        "streams": nstream, "vit_frames_per_step_per_gpu": nstream * B * T,
                        "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else (graph_note or "eager"),
-                       "temporal_dropout": model.dropout_p, "vit_drop_path": vit.drop_path_rate},
+                       "temporal_dropout": model.dropout_p, "vit_drop_path": vit.drop_path_rate,
+                       "last_block_cls_only": pruned,
+                       "flops_per_frame": {"reference_dense": FLOP_PER_FRAME_FWD_BWD, "executed": per_frame,
+                                           "note": "forward() returns the CLS row: the last block's row-local half and the "
+                                                   "non-CLS queries of its attention feed nothing and are not computed; "
+                                                   "outputs and all parameter gradients are unchanged (tests vs the oracle). "
+                                                   "SAIS_VIT_PRUNE_LAST=0 computes every row; step_tflops and "
+                                                   "frac_of_mfma_roofline use the executed count"}},
             "step_tflops": round(step_flops * world * args.steps / dt / 1e12, 1),
             "frac_of_mfma_roofline": round(step_flops * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
             "loss": round(timed_loss, 6),

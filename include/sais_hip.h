@@ -249,6 +249,19 @@ int sais_vit_attn_cls_fwd(const void* qkv, long ldqkv, int frames, int ntok, voi
 int sais_vit_attn_cls_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, int frames, int ntok, void* dqkv,
                           long lddqkv, void* stream);
 
+/* ---------------------------------------------------------------- optical-flow stage: RAFT correlation volume (ABI 8)
+ * The reference renders its flow maps with ptlflow's `raft` ('things' checkpoint): SAIS/scripts/extract_representations.py
+ * :33,62-67,221-252,267 and main.sh:18.  ptlflow 0.2.5 is a third-party dependency that is ABSENT from the reference tree
+ * and this image: PARITY UNPINNED — these entries follow the published model (Teed & Deng, ECCV 2020) and are tested against
+ * oracle/raft_oracle.py.  The all-pairs correlation itself is sais_gemm_nt_f32 on the [H W, 256] feature matrices.
+ *   sais_raft_corr_pool: levels 1-3 of the correlation pyramid (2 x 2 average pooling over the last two dims of
+ *       [rows, 1, H, W]; corr0 row r starts at corr0 + r * ld0) in one pass.  l1 / l2 / l3: f32 [rows, (H>>l) * (W>>l)].
+ *   sais_raft_lookup: out f32 [B, 4 (2r+1)^2, H, W]; channel l (2r+1)^2 + a (2r+1) + b = level l sampled (bilinear, zeros
+ *       outside, pixel coordinates) at (x / 2^l + a - r, y / 2^l + b - r) for (x, y) = coords[b', :, y', x'].          */
+int sais_raft_corr_pool(const float* corr0, long ld0, int rows, int H, int W, float* l1, float* l2, float* l3, void* stream);
+int sais_raft_lookup(const float* l0, long ld0, const float* l1, const float* l2, const float* l3, const float* coords,
+                     int B, int H, int W, int radius, float* out, void* stream);
+
 /* ---------------------------------------------------------------- ViT embedding glue
  * PatchEmbed + prepare_tokens, vision_transformer.py:116-131,196-207.                            */
 int sais_patchify(const float* frames_f32 /*[F,3,side,side]*/, int frames, int side /* % 16 == 0 */,

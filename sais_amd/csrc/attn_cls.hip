@@ -11,159 +11,140 @@
 //              recomputed, nothing is saved); the q part of dqkv is ZERO for the other rows and is written as such
 //              (the buffer is reused between blocks).
 //
-// These are 2 x ntok x 64 MACs per problem: latency- and store-bound (the backward writes the whole [M, 1152] bf16 gradient,
-// 116 MB at config 2), against 131 us for the full single-pass backward it replaces in this block.
+// These are 2 x ntok x 64 MACs per problem: read- / store-bound (the forward reads K and V once, 77 MB at config 2; the
+// backward also writes the whole [M, 1152] bf16 gradient, 116 MB), against 48 / 131 us for the full kernels they replace in
+// this block.  Everything moves in whole 128-B rows, 8 rows per wave instruction; reductions are lane shuffles.
 #include "common.hpp"
 #include "../../include/sais_hip.h"
 
 namespace {
 constexpr int HD = 64, NH = 6, DM = 384;
-constexpr int MAXTOK = 256;
+constexpr int MAXTOK = 200;                      // 25 row groups of 8
+constexpr int NI = MAXTOK / 8;
 constexpr float SCALE = 0.125f;                  // 64^-0.5
 
-// scores of the CLS query against keys lane, lane + 64, ...: lane-per-key, each lane reads whole 128-B K rows
-DEVINL void cls_scores(const bf16* qkv, long ld, int row0, int ntok, int h, int lane, float (&s)[MAXTOK / 64], float& mx) {
-    const bf16* qp = qkv + (size_t)row0 * ld + h * HD;
-    float q[HD];
+// Lane (r = lane >> 3, c = lane & 7) owns the 16-B piece c (features 8 c .. 8 c + 7) of the rows 8 i + r: one wave
+// instruction moves 8 whole 128-B rows of K or V, every dot product over the 64 features is a reduction over the 8 lanes of
+// a row group (xor 1, 2, 4), every sum over the keys a reduction over the row groups (xor 8, 16, 32).  No LDS.
+DEVINL float red_c(float v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); return v + __shfl_xor(v, 4); }
+DEVINL float red_r(float v) { v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); return v + __shfl_xor(v, 32); }
+DEVINL float max_r(float v) { v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 16)); return fmaxf(v, __shfl_xor(v, 32)); }
+DEVINL float dot8(const bf16x8& a, const float (&b)[8]) {
+    float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-        const bf16x8 v = *(const bf16x8*)(qp + 8 * c);              // same address in every lane: a broadcast load
+    for (int e = 0; e < 8; ++e) s += (float)a[e] * b[e];
+    return s;
+}
+DEVINL void unpack8(const bf16x8& a, float (&b)[8]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) q[8 * c + e] = (float)v[e];
+    for (int e = 0; e < 8; ++e) b[e] = (float)a[e];
+}
+
+// P of the CLS query (unnormalised exp, 25 keys per lane: key 8 i + r) and 1 / sum; optionally keeps the K pieces
+template <bool KEEPK>
+DEVINL void cls_softmax(const bf16* qkv, long ld, int row0, int ntok, int h, int r, int c, const float (&q)[8],
+                        bf16x8 (&kf)[NI], float (&p)[NI], float& inv) {
+    const bf16* kp = qkv + (size_t)row0 * ld + DM + h * HD + 8 * c;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int k = 8 * i + r;
+        const bf16x8 v = *(const bf16x8*)(kp + (size_t)(k < ntok ? k : ntok - 1) * ld);
+        if (KEEPK) kf[i] = v;
+        const float sc = red_c(dot8(v, q)) * SCALE;
+        p[i] = k < ntok ? sc : -INFINITY;
+        mx = fmaxf(mx, p[i]);
     }
-    mx = -INFINITY;
+    mx = max_r(mx);
+    float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXTOK / 64; ++i) {
-        const int k = lane + 64 * i;
-        float a = -INFINITY;
-        if (k < ntok) {
-            const bf16* kp = qkv + (size_t)(row0 + k) * ld + DM + h * HD;
-            a = 0.f;
-#pragma unroll
-            for (int c = 0; c < HD / 8; ++c) {
-                const bf16x8 v = *(const bf16x8*)(kp + 8 * c);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a += q[8 * c + e] * (float)v[e];
-            }
-            a *= SCALE;
-        }
-        s[i] = a;
-        mx = fmaxf(mx, a);
-    }
-    mx = wave_max(mx);
+    for (int i = 0; i < NI; ++i) { p[i] = __expf(p[i] - mx); sum += p[i]; }      // exp(-inf) = 0 past the last token
+    inv = 1.0f / red_r(sum);
 }
 
 __global__ __launch_bounds__(256) void attn_cls_fwd_kernel(const bf16* qkv, long ld, int frames, int ntok, bf16* out, long ldo) {
-    __shared__ float sp[4][MAXTOK];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int prob = blockIdx.x * 4 + w;
     if (prob >= frames * NH) return;
-    const int f = prob / NH, h = prob - f * NH, row0 = f * ntok;
-    float s[MAXTOK / 64], mx;
-    cls_scores(qkv, ld, row0, ntok, h, lane, s, mx);
-    float sum = 0.f;
+    const int f = prob / NH, h = prob - f * NH, row0 = f * ntok, r = lane >> 3, c = lane & 7;
+    float q[8];
+    unpack8(*(const bf16x8*)(qkv + (size_t)row0 * ld + h * HD + 8 * c), q);
+    bf16x8 kf[NI];
+    float p[NI], inv;
+    cls_softmax<false>(qkv, ld, row0, ntok, h, r, c, q, kf, p, inv);
+    const bf16* vp = qkv + (size_t)row0 * ld + 2 * DM + h * HD + 8 * c;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < MAXTOK / 64; ++i) {
-        const float p = lane + 64 * i < ntok ? __expf(s[i] - mx) : 0.f;
-        sp[w][lane + 64 * i] = p;
-        sum += p;
-    }
-    sum = wave_sum(sum);
-    const float inv = 1.0f / sum;
-    // out[d = lane] = sum_k p_k v[k][d]: one coalesced 128-B row of V per key, four independent partial sums
-    const bf16* vp = qkv + (size_t)row0 * ld + 2 * DM + h * HD + lane;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 4 <= ntok; k += 4) {
+    for (int i = 0; i < NI; ++i) {
+        const int k = 8 * i + r;
+        const bf16x8 v = *(const bf16x8*)(vp + (size_t)(k < ntok ? k : ntok - 1) * ld);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += sp[w][k + j] * (float)vp[(size_t)(k + j) * ld];
+        for (int e = 0; e < 8; ++e) acc[e] += p[i] * (float)v[e];                // p = 0 past the last token
     }
-    for (; k < ntok; ++k) acc[0] += sp[w][k] * (float)vp[(size_t)k * ld];
-    out[(size_t)f * ldo + h * HD + lane] = (bf16)(((acc[0] + acc[1]) + (acc[2] + acc[3])) * inv);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)(red_r(acc[e]) * inv);
+    if (r == 0) *(bf16x8*)(out + (size_t)f * ldo + h * HD + 8 * c) = o;
 }
 
-__global__ __launch_bounds__(256) void attn_cls_bwd_kernel(const bf16* qkv, long ld, const bf16* dout, long lddo, int frames,
+__global__ __launch_bounds__(256, 2) void attn_cls_bwd_kernel(const bf16* qkv, long ld, const bf16* dout, long lddo, int frames,
                                                            int ntok, bf16* dqkv, long lddq) {
-    __shared__ float sp[4][MAXTOK], sds[4][MAXTOK];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int prob = blockIdx.x * 4 + w;
     if (prob >= frames * NH) return;
-    const int f = prob / NH, h = prob - f * NH, row0 = f * ntok;
-    float s[MAXTOK / 64], mx;
-    cls_scores(qkv, ld, row0, ntok, h, lane, s, mx);
-    float p[MAXTOK / 64], sum = 0.f;
+    const int f = prob / NH, h = prob - f * NH, row0 = f * ntok, r = lane >> 3, c = lane & 7;
+    float q[8], dO[8];
+    unpack8(*(const bf16x8*)(qkv + (size_t)row0 * ld + h * HD + 8 * c), q);
+    unpack8(*(const bf16x8*)(dout + (size_t)f * lddo + h * HD + 8 * c), dO);
+    bf16x8 kf[NI];
+    float p[NI], inv;
+    cls_softmax<true>(qkv, ld, row0, ntok, h, r, c, q, kf, p, inv);
+    // dP_k = dO . v_k, delta = sum_k P_k dP_k, dS_k = P_k (dP_k - delta) / 8
+    const bf16* vp = qkv + (size_t)row0 * ld + 2 * DM + h * HD + 8 * c;
+    float dP[NI], delta = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXTOK / 64; ++i) {
-        p[i] = lane + 64 * i < ntok ? __expf(s[i] - mx) : 0.f;
-        sum += p[i];
-    }
-    const float inv = 1.0f / wave_sum(sum);
-    // dP_k = dO . v_k (lane per key), delta = sum_k P_k dP_k, dS_k = P_k (dP_k - delta)
-    const bf16* dop = dout + (size_t)f * lddo + h * HD;
-    float dO[HD];
-#pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-        const bf16x8 v = *(const bf16x8*)(dop + 8 * c);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dO[8 * c + e] = (float)v[e];
-    }
-    float dP[MAXTOK / 64], delta = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXTOK / 64; ++i) {
-        const int k = lane + 64 * i;
-        float a = 0.f;
+    for (int i = 0; i < NI; ++i) {
+        const int k = 8 * i + r;
+        const bf16x8 v = *(const bf16x8*)(vp + (size_t)(k < ntok ? k : ntok - 1) * ld);
         p[i] *= inv;
+        dP[i] = red_c(dot8(v, dO));
+        delta += p[i] * dP[i];
+    }
+    delta = red_r(delta);
+    // row k of dqkv: dq (zero unless k = 0: written as zeros, the buffer is reused between blocks), dk = dS_k q, dv = P_k dO
+    bf16* op = dqkv + (size_t)row0 * lddq + h * HD + 8 * c;
+    float dq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    bf16x8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (bf16)0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int k = 8 * i + r;
+        const float ds = p[i] * (dP[i] - delta) * SCALE;
+        bf16x8 dk, dv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dq[e] += ds * (float)kf[i][e];                                       // ds = 0 past the last token (p = 0)
+            dk[e] = (bf16)(ds * q[e]);
+            dv[e] = (bf16)(p[i] * dO[e]);
+        }
         if (k < ntok) {
-            const bf16* vp = qkv + (size_t)(row0 + k) * ld + 2 * DM + h * HD;
-#pragma unroll
-            for (int c = 0; c < HD / 8; ++c) {
-                const bf16x8 v = *(const bf16x8*)(vp + 8 * c);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a += dO[8 * c + e] * (float)v[e];
-            }
-        }
-        dP[i] = a;
-        delta += p[i] * a;
-    }
-    delta = wave_sum(delta);
-#pragma unroll
-    for (int i = 0; i < MAXTOK / 64; ++i) {
-        sp[w][lane + 64 * i] = p[i];
-        sds[w][lane + 64 * i] = p[i] * (dP[i] - delta) * SCALE;       // d(q . k) = dS / 8
-    }
-    // lane = feature d from here on: dk[k][d] = dS_k q[d], dv[k][d] = P_k dO[d], dq[d] = sum_k dS_k k[k][d]
-    const float qd = (float)qkv[(size_t)row0 * ld + h * HD + lane];
-    const float dod = (float)dop[lane];
-    const bf16* kp = qkv + (size_t)row0 * ld + DM + h * HD + lane;
-    bf16* o = dqkv + (size_t)row0 * lddq + h * HD + lane;
-    float dq[4] = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 4 <= ntok; k += 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float ds = sds[w][k + j];
-            dq[j] += ds * (float)kp[(size_t)(k + j) * ld];
-            bf16* r = o + (size_t)(k + j) * lddq;
-            if (k + j) r[0] = (bf16)0.f;                               // q rows other than CLS receive no gradient
-            r[DM] = (bf16)(ds * qd);
-            r[2 * DM] = (bf16)(sp[w][k + j] * dod);
+            bf16* o = op + (size_t)k * lddq;
+            if (k) *(bf16x8*)o = zero;
+            *(bf16x8*)(o + DM) = dk;
+            *(bf16x8*)(o + 2 * DM) = dv;
         }
     }
-    for (; k < ntok; ++k) {
-        const float ds = sds[w][k];
-        dq[0] += ds * (float)kp[(size_t)k * ld];
-        bf16* r = o + (size_t)k * lddq;
-        if (k) r[0] = (bf16)0.f;
-        r[DM] = (bf16)(ds * qd);
-        r[2 * DM] = (bf16)(sp[w][k] * dod);
-    }
-    o[0] = (bf16)((dq[0] + dq[1]) + (dq[2] + dq[3]));
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)red_r(dq[e]);
+    if (r == 0) *(bf16x8*)op = o;
 }
 }  // namespace
 
 extern "C" int sais_vit_attn_cls_fwd(const void* qkv, long ldqkv, int frames, int ntok, void* out, long ldo, void* stream) {
     SAIS_ENTER();
-    if (!qkv || !out || frames <= 0 || ntok <= 0 || ntok > MAXTOK || (ldqkv & 7)) return SAIS_ERR_ARG;
+    if (!qkv || !out || frames <= 0 || ntok <= 0 || ntok > MAXTOK || (ldqkv & 7) || (ldo & 7)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3((frames * NH + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv,
                        ldqkv, frames, ntok, (bf16*)out, ldo);
     return sais_check_launch();
@@ -172,7 +153,7 @@ extern "C" int sais_vit_attn_cls_fwd(const void* qkv, long ldqkv, int frames, in
 extern "C" int sais_vit_attn_cls_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, int frames, int ntok,
                                      void* dqkv, long lddqkv, void* stream) {
     SAIS_ENTER();
-    if (!qkv || !dout || !dqkv || frames <= 0 || ntok <= 0 || ntok > MAXTOK || (ldqkv & 7) || (lddo & 7)) return SAIS_ERR_ARG;
+    if (!qkv || !dout || !dqkv || frames <= 0 || ntok <= 0 || ntok > MAXTOK || (ldqkv & 7) || (lddo & 7) || (lddqkv & 7)) return SAIS_ERR_ARG;
     hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3((frames * NH + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)qkv,
                        ldqkv, (const bf16*)dout, lddo, frames, ntok, (bf16*)dqkv, lddqkv);
     return sais_check_launch();

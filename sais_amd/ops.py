@@ -316,6 +316,34 @@ def vit_attn_cls_bwd(qkv, dout_c, frames, dqkv, ntok=197):
                           _p(dqkv), dqkv.stride(0), _stream()))
 
 
+def raft_corr_pyramid(f1, f2):
+    """f1, f2: f32 [C = 256, H, W] feature maps of ONE frame pair -> (level 0 [H W, ld0] with row stride ld0 >= H W,
+    [level 1, 2, 3] as [H W, (H>>l) (W>>l)]).  Level 0 = <f1[:, i], f2[:, j]> / sqrt(C) on the fp32-grade matrix-core GEMM."""
+    C, H, W = f1.shape
+    HW = H * W
+    npad = (HW + 127) // 128 * 128
+    a = (f1.reshape(C, HW).t() * (1.0 / C ** 0.5)).contiguous()                  # [HW, C]; 1/16 is exact in fp32
+    b = torch.zeros(npad, C, dtype=F32, device=f1.device)
+    b[:HW] = f2.reshape(C, HW).t()
+    c0 = torch.empty(HW, npad, dtype=F32, device=f1.device)
+    gemm_nt_f32(a, b, L.EPI_BIAS_F32, c0)
+    lv = [torch.empty(HW, (H >> l) * (W >> l), dtype=F32, device=f1.device) for l in (1, 2, 3)]
+    L.call("sais_raft_corr_pool", _p(c0), npad, HW, H, W, _p(lv[0]), _p(lv[1]), _p(lv[2]), _stream())
+    return c0, lv
+
+
+def raft_lookup(pyr, coords, radius=4):
+    """pyr: list over the batch of raft_corr_pyramid results (same H, W); coords f32 [B, 2, H, W] -> f32 [B, 4 (2r+1)^2, H, W]."""
+    _chk(coords, F32, "coords")
+    B, _, H, W = coords.shape
+    n = (2 * radius + 1) ** 2
+    out = torch.empty(B, 4 * n, H, W, dtype=F32, device=coords.device)
+    for b, (c0, lv) in enumerate(pyr):                     # one frame pair per launch: every pair has its own volume
+        L.call("sais_raft_lookup", _p(c0), c0.stride(0), _p(lv[0]), _p(lv[1]), _p(lv[2]), _p(coords[b]), 1, H, W, radius,
+               _p(out[b]), _stream())
+    return out
+
+
 def patchify(frames_f32, patches):
     """frames f32 [F,3,side,side] -> bf16 [F*(side/16)^2, 768]."""
     _chk(frames_f32, F32, "frames")

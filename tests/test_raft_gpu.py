@@ -1,0 +1,110 @@
+"""Optical-flow stage on a real MI355X (PARITY UNPINNED — see oracle/raft_oracle.py): the HIP correlation
+volume (fp32-grade MFMA GEMM + one-pass pyramid pooling) and window lookup against the oracle, the product RAFT module end to
+end against the oracle with the same seeded weights, the colour coding, and the `--optical_flow` stage of the CLI."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import raft_synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return True
+
+
+@pytest.mark.parametrize("H,W", [(16, 21), (28, 41), (68, 120)])
+def test_correlation_pyramid_and_lookup_vs_oracle(gpu, H, W):
+    from oracle import raft_oracle as R
+    from sais_amd import ops
+    g = torch.Generator().manual_seed(H * 100 + W)
+    f1, f2 = torch.randn(1, 256, H, W, generator=g), torch.randn(1, 256, H, W, generator=g)
+    ref = R.corr_pyramid(f1, f2)
+    c0, lv = ops.raft_corr_pyramid(f1[0].to(DEV), f2[0].to(DEV))
+    HW = H * W
+    assert c0.shape[0] == HW and c0.stride(0) % 128 == 0
+    scale = float(ref[0].abs().max())
+    assert float((c0[:, :HW].cpu() - ref[0].view(HW, HW)).abs().max()) <= 2e-5 * scale       # bf16x3 split: fp32-grade
+    for l in range(3):
+        want = ref[l + 1].view(HW, -1)
+        assert tuple(lv[l].shape) == tuple(want.shape)
+        assert float((lv[l].cpu() - want).abs().max()) <= 2e-5 * scale
+    # lookup: fractional coordinates, some far outside the image (zero padding) and on its border
+    coords = torch.stack([torch.rand(H, W, generator=g) * (W + 12) - 6, torch.rand(H, W, generator=g) * (H + 12) - 6]).unsqueeze(0)
+    coords[0, :, 0, 0] = torch.tensor([0.0, 0.0])
+    coords[0, :, 1, 1] = torch.tensor([W - 1.0, H - 1.0])
+    coords[0, :, 2, 2] = torch.tensor([-40.0, 3.0])
+    got = ops.raft_lookup([(c0, lv)], coords.to(DEV).contiguous())
+    want = R.corr_lookup(ref, coords)
+    assert tuple(got.shape) == (1, 324, H, W)
+    assert float((got.cpu() - want).abs().max()) <= 1e-4 * scale
+
+
+def test_raft_forward_and_colour_coding_vs_oracle(gpu):
+    from oracle import raft_oracle as R
+    from sais_amd.raft import RAFT, flow_image_uint8, flow_to_rgb
+    sd = raft_synth.raft_state_dict(0)
+    pairs = [raft_synth.frame_pair(s, 125, 164, shift=sh) for s, sh in ((1, (3, -2)), (2, (-1, 4)))]
+    a, b = torch.cat([p[0] for p in pairs]), torch.cat([p[1] for p in pairs])
+    m = RAFT(iters=4)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    flow = m(a.to(DEV), b.to(DEV))
+    ref = R.raft_forward(sd, a, b, iters=4)
+    assert tuple(flow.shape) == (2, 2, 125, 164)
+    err = float((flow.cpu() - ref).abs().max())
+    assert err <= 2e-2 * max(1.0, float(ref.abs().max())), err      # fp32 convolutions on two devices + the recurrence
+    rgb = flow_to_rgb(flow[0])
+    want = R.flow_to_rgb(flow[0].cpu())
+    assert float((rgb.cpu() - want).abs().max()) <= 2e-3
+    img = flow_image_uint8(rgb)
+    assert img.shape == (125, 164, 3) and img.dtype == np.uint8
+    assert int(np.abs(img.astype(np.int32) - R.flow_image_uint8(want).astype(np.int32)).max()) <= 1
+
+
+def test_optical_flow_stage_writes_the_flow_images(gpu, tmp_path):
+    """`extract_representations.py --optical_flow` (main.sh:18): one flows_<n:08d>.jpg per row of Custom_FlowPaths.csv,
+    n = first frame // 15, the frame's own size, deterministic; a video whose flows folder exists is skipped."""
+    from PIL import Image
+    root = tmp_path / "SAIS"
+    (root / "images" / "vid_01").mkdir(parents=True)
+    g = np.random.default_rng(3)
+    h, w = 136, 200
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(46):
+        img = np.stack([127 + 100 * np.sin((xx + 0.4 * i) / (9.0 + c)) * np.cos((yy - 0.2 * i) / 13.0 - c) for c in range(3)], -1)
+        Image.fromarray(np.clip(img + g.normal(0, 3, img.shape), 0, 255).astype(np.uint8)).save(
+            root / "images" / "vid_01" / f"frames_{i:08d}.jpg", quality=92)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    data = str(root) + "/"
+    sc = lambda name: os.path.join(ROOT, "SAIS/scripts", name)
+    subprocess.run([sys.executable, sc("generate_paths.py"), "-f", "vid_01", "-p", data], check=True, env=env, cwd=ROOT)
+    cmd = [sys.executable, sc("extract_representations.py"), "--arch", "vit_small", "--patch_size", "16", "--model_type",
+           "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "2", "--data_path", data, "--data_list", "Custom",
+           "--save_type", "h5", "--optical_flow", "--raft_iters", "3"]
+    r = subprocess.run(cmd, check=True, env=env, cwd=ROOT, capture_output=True, text=True)
+    assert "All Flows Saved!" in r.stdout
+    files = sorted(os.listdir(root / "flows" / "vid_01"))
+    assert files == ["flows_00000000.jpg", "flows_00000001.jpg", "flows_00000002.jpg"]       # frames 0, 15, 30 (+15 each)
+    first = np.asarray(Image.open(root / "flows" / "vid_01" / files[0]))
+    assert first.shape == (h, w, 3) and first.std() > 1.0
+    r2 = subprocess.run(cmd, check=True, env=env, cwd=ROOT, capture_output=True, text=True)  # second run: nothing to do
+    assert "0 flow maps saved" in r2.stdout and "already had flows" in r2.stdout
+    # the flow images feed the next stage of main.sh
+    subprocess.run([sys.executable, sc("extract_representations.py"), "--arch", "vit_small", "--patch_size", "16", "--model_type",
+                    "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "256", "--data_path", data, "--data_list", "Custom",
+                    "--save_type", "h5", "--optical_flow_to_reps", "--video", "vid_01"], check=True, env=env, cwd=ROOT)
+    from SAIS.scripts._features_io import load_reps
+    assert load_reps(data, "ViT_SelfSupervised_ImageNet_FlowRepsAndLabels")["vid_01"].shape == (3, 384)
