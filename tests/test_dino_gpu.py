@@ -259,6 +259,8 @@ def test_multigroup_pass_equals_separate_passes():
     model = vit.vit_small(patch_size=16, depth=2)
     model.load_state_dict(synth.vit_state_dict(seed=27, depth=2))
     model = model.to(DEV).train()
+    model.prune_last_block = False          # single-resolution passes would otherwise take the CLS-only last block (its own
+    #                                         test: test_pruned_last_block_equals_full_compute); this one is about row stacking
     crops = synth.dino_crops(seed=340, B=5, n_local=2)
     a, b = torch.cat(crops[:2]).to(DEV), torch.cat(crops[2:]).to(DEV)            # 10 x 224^2, 10 x 96^2
     model._engine(a.device)
