@@ -44,8 +44,10 @@ enum {
     SAIS_EPI_BIAS_GELU_GRAD_BF16 = 10, /* out bf16 = gelu_erf(acc + bias) ; out2 bf16 = gelu'(acc + bias): the training
                                      forward stores the derivative instead of the pre-activation, so that ...     */
     SAIS_EPI_MUL_BF16 = 11,       /* ... the backward is out bf16 = acc * aux(bf16), with no erf/exp in its epilogue */
-    SAIS_EPI_PATCH_F32 = 7        /* patch-embed: row f*grp_in+q -> token row f*grp_out+q+grp_off,
+    SAIS_EPI_PATCH_F32 = 7,       /* patch-embed: row f*grp_in+q -> token row f*grp_out+q+grp_off,
                                      out f32 = acc + bias + aux(f32 pos)[q+grp_off]                  */
+    SAIS_EPI_RAW_SLABS_F32 = 12   /* (ABI 8, M < 8192 only) split-K: K is cut into grp_in slices, slice z writes its raw partial
+                                     sums to out f32 [grp_in][M][ldo]; sais_splitk_finish sums them in a fixed order      */
 };
 
 typedef struct SaisGemm {
@@ -68,6 +70,12 @@ typedef struct SaisGemm {
 } SaisGemm;
 
 int sais_gemm_nt(const SaisGemm* g, void* stream);
+/* Second half of a SAIS_EPI_RAW_SLABS_F32 product (the [frames, 384] GEMMs of the CLS-only last ViT block: a K = 1536 loop
+ * over 6 output tiles is 24 serial steps; cut 12 ways it is 72 workgroups of 2):
+ *   y = sum_z slabs[z][m][n] + bias[n];  y *= rowscale[m] (optional);  y += aux[m][n] (optional, f32);
+ *   out32 (optional) = y, out16 (optional) = bf16(y).  Deterministic (fixed summation order, no atomics).            */
+int sais_splitk_finish(const float* slabs, int nslabs, int M, int N, int lds, const float* bias, const float* rowscale,
+                       const float* aux, int ldaux, float* out32, int ldo32, void* out16, int ldo16, void* stream);
 
 /* Same contract with FP32 operands (A f32 [M,K], B f32 [N,K], out f32) at ~fp32 accuracy: each operand is
  * split hi/lo into two bf16 and three MFMA products are accumulated ("bf16x3").  Epilogues:

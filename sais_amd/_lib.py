@@ -68,7 +68,7 @@ OPT_DECAY, OPT_CLASS1, OPT_NO_GRAD = 1, 2, 4
 EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
 EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
-EPI_BIAS_GELU_GRAD_BF16, EPI_MUL_BF16 = 10, 11
+EPI_BIAS_GELU_GRAD_BF16, EPI_MUL_BF16, EPI_RAW_SLABS_F32 = 10, 11, 12
 TG_RAW, TG_BIAS, TG_BIAS_RELU, TG_DRELU = 0, 1, 2, 3
 
 # name -> argtypes; every symbol include/sais_hip.h declares (checked by tests/test_abi.py)
@@ -76,6 +76,8 @@ SIGNATURES = {
     "sais_abi_version": [],
     "sais_gemm_nt": [ctypes.POINTER(SaisGemm), c_void_p],
     "sais_gemm_nt_f32": [ctypes.POINTER(SaisGemm), c_void_p],
+    "sais_splitk_finish": [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                           c_int, c_void_p],
     "sais_gemm_ln_fwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
     "sais_gemm_ln_bwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
     "sais_mlp_fwd": [ctypes.POINTER(SaisMlp), c_void_p],

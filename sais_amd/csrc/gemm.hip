@@ -173,8 +173,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-    const int nk = p.K / BK;
-    issue(0, 0);
+    int nk = p.K / BK, kbase = 0;
+    if constexpr (EPI == SAIS_EPI_RAW_SLABS_F32) {                   // split-K: slice blockIdx.y of the K range
+        const int per = (nk + (int)gridDim.y - 1) / (int)gridDim.y;
+        kbase = blockIdx.y * per;
+        nk = min(per, nk - kbase);
+        if (nk <= 0) nk = 0;
+    }
+    if (nk > 0) issue(0, kbase * BK);
     __syncthreads();
     // the epilogue's own loads (bias, residual / pre-activation rows: first-touch HBM data) are issued before the MFMAs
     // of the LAST K-step, so their latency runs under that step instead of in front of the stores
@@ -182,10 +188,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
     EpiAux aux;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) issue(cur ^ 1, (kt + 1) * BK);
+        if (kt + 1 < nk) issue(cur ^ 1, (kbase + kt + 1) * BK);
         const char* sa = smem + cur * 2 * TILE_BYTES;
         const char* sb = sa + TILE_BYTES;
-        if (kt == nk - 1) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
+        if constexpr (EPI != SAIS_EPI_RAW_SLABS_F32)
+            if (kt == nk - 1) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fa[4], fb[4];
@@ -212,7 +219,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtParams p) {
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-        epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v, bias, aux, mt);
+        if constexpr (EPI == SAIS_EPI_RAW_SLABS_F32) {
+            float* o = (float*)p.out + ((size_t)blockIdx.y * p.M + m) * p.ldo + n0 + wc * 64 + 16 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(o + 4 * i) = f32x4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+        } else {
+            epilogue<EPI>(p, m, n0 + wc * 64 + 16 * g, v, bias, aux, mt);
+        }
+    }
+}
+
+// y = sum_z slabs[z] + bias; y *= rowscale[m]; y += aux; -> f32 and / or bf16 (fixed summation order: deterministic)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* ws, int ks, int M, int N, int lds, const float* bias,
+                                                            const float* rowscale, const float* aux, int ldaux, float* out32,
+                                                            int ldo32, bf16* out16, int ldo16) {
+    const int n4 = N >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)M * n4; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+        f32x4 y = *(const f32x4*)(ws + (size_t)m * lds + n);
+        for (int z = 1; z < ks; ++z) y += *(const f32x4*)(ws + ((size_t)z * M + m) * lds + n);
+        if (bias) y += *(const f32x4*)(bias + n);
+        if (rowscale) y *= rowscale[m];
+        if (aux) y += *(const f32x4*)(aux + (size_t)m * ldaux + n);
+        if (out32) *(f32x4*)(out32 + (size_t)m * ldo32 + n) = y;
+        if (out16) {
+            bf16x4 o;
+            o[0] = (bf16)y[0]; o[1] = (bf16)y[1]; o[2] = (bf16)y[2]; o[3] = (bf16)y[3];
+            *(bf16x4*)(out16 + (size_t)m * ldo16 + n) = o;
+        }
     }
 }
 
@@ -808,7 +842,7 @@ __global__ __launch_bounds__(256) void gemm_tn_grouped_f32_kernel(TnGroup gp) {
 
 // Wide variant of the grouped dW kernel: 128 (P columns) x 384 (Q columns) output tile per 512-thread workgroup
 // (8 waves as 2 x 4, 64 x 96 per wave), used when every item has N2 % 384 == 0 (all four dW of a ViT block do).
-// The 128x128 kernel above is paced by its global->LDS fill stream (ablation in DESIGN.md 4.1: 2.8 GB of fills per
+// The 128x128 kernel above is paced by its global->LDS fill stream (ablation in LABNOTES.md 4.1: 2.8 GB of fills per
 // launch, DMA-only 223 us vs 166 us of MFMA work); this tile needs a third fewer fill bytes per flop: 64 KiB per
 // 64-row step (P 16 KiB + three 128-column blocks of Q) for 2 x 128 x 384 x 64 flop.  Two 64-KiB stages = 128 KiB of
 // LDS, one workgroup per CU; 36 tiles x 7 M-splits = 252 workgroups fill the 256 CUs in one round.
@@ -837,7 +871,7 @@ struct TnWideGroup {
 // 4s-1 (B), and every R interval ends with lgkmcnt(0) BEFORE its barrier, so those reads have returned.
 // (212 -> 197 us per block inside the step.  Measured and dropped on this kernel: one bias MFMA per wave instead of four
 // on the wc = 0 waves, hand-counted vmcnt(12) instead of the compiler's vmcnt(7..4): no change either way — the kernel
-// is paced by the global fill stream)
+// is paced by the global fill stream, LABNOTES.md 4.2.)
 __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
     extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -998,8 +1032,13 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // Two kernels, chosen by M alone: the four-wave 128x128 kernel for small M (inference batches, tests, the
     // patch-embed epilogue) and the persistent eight-wave A-ring kernel for the ViT GEMMs of a training step
     // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
-    // four-wave A-ring) were measured slower inside the step and are gone from the library.
+    // four-wave A-ring) were measured slower inside the step and are gone from the library (LABNOTES.md 4.1).
     const bool big = g->M >= 8192;
+    if (g->epilogue == SAIS_EPI_RAW_SLABS_F32) {                // split-K over grp_in slices: small M only, raw fp32 slabs
+        if (big || g->grp_in < 1 || g->grp_in > g->K / BK || g->ldo % 4) return SAIS_ERR_ARG;
+        hipLaunchKernelGGL(gemm_nt_kernel<SAIS_EPI_RAW_SLABS_F32>, dim3(grid.x, g->grp_in), dim3(256), 0, (hipStream_t)stream, p);
+        return sais_check_launch();
+    }
     // the plain N = 384 GEMMs of a training step (dX of proj, the last block's fc2): balanced row tiles of gemm_row.hip
     if (big && g->N == 384 && (g->epilogue == SAIS_EPI_BIAS_BF16 || (g->epilogue == SAIS_EPI_BIAS_RESID_F32 && !g->out2)))
         return sais_gemm_nt_row_(g, stream);
@@ -1017,6 +1056,19 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
         LAUNCH_NT(SAIS_EPI_MUL_BF16)
         default: return SAIS_ERR_ARG;
     }
+    return sais_check_launch();
+}
+
+extern "C" int sais_splitk_finish(const float* slabs, int nslabs, int M, int N, int lds, const float* bias,
+                                  const float* rowscale, const float* aux, int ldaux, float* out32, int ldo32, void* out16,
+                                  int ldo16, void* stream) {
+    SAIS_ENTER();
+    if (!slabs || nslabs < 1 || M <= 0 || N <= 0 || N % 4 || lds % 4 || (!out32 && !out16)) return SAIS_ERR_ARG;
+    if ((aux && ldaux % 4) || (out32 && ldo32 % 4) || (out16 && ldo16 % 4)) return SAIS_ERR_ARG;
+    const long n = (long)M * (N / 4);
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, M, N, lds, bias,
+                       rowscale, aux, ldaux, out32, ldo32, (bf16*)out16, ldo16);
     return sais_check_launch();
 }
 

@@ -53,7 +53,7 @@ def _timed(tag, flops, nbytes, fn):
         TIMER.run(tag, flops, nbytes, fn)
 
 
-_NT_NAMES = {0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_bf16", 5: "dgelu_bf16", 6: "drelu_bf16",
+_NT_NAMES = {12: "raw_slabs_f32", 0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_bf16", 5: "dgelu_bf16", 6: "drelu_bf16",
              7: "patch_f32", 8: "relu_f32", 9: "drelu_f32", 10: "gelu_grad_bf16", 11: "mul_bf16"}
 
 
@@ -85,6 +85,21 @@ def gemm_nt(a, w, epilogue, out, bias=None, out2=None, aux=None, M=None, grp=(0,
     _timed(f"gemm_nt<{_NT_NAMES[epilogue]}>[N{N},K{K}]", 2.0 * M * N * K, nbytes,
            lambda: L.call("sais_gemm_nt", ctypes.byref(g), _stream()))
     return out
+
+
+def gemm_nt_splitk(a, w, ksplit, bias=None, rowscale=None, aux=None, out32=None, out16=None):
+    """out = aux + rowscale[m] * (a[M,K] . w[N,K]^T + bias) for SMALL M (the [frames, 384] GEMMs of the CLS-only last block):
+    K is cut into `ksplit` slices computed by separate workgroups into raw fp32 slabs, summed in a fixed order by
+    sais_splitk_finish (deterministic: no atomics).  out32 f32 and / or out16 bf16."""
+    _chk(a, BF16, "A"); _chk(w, BF16, "B"); _chk(bias, F32, "bias"); _chk(rowscale, F32, "rowscale"); _chk(aux, F32, "aux")
+    _chk(out32, F32, "out32"); _chk(out16, BF16, "out16")
+    M, K = a.shape
+    N = w.shape[0]
+    ksplit = max(1, min(int(ksplit), K // 64))
+    slabs = torch.empty(ksplit, M, N, dtype=F32, device=a.device)
+    gemm_nt(a, w, L.EPI_RAW_SLABS_F32, slabs, grp=(ksplit, 0, 0))
+    L.call("sais_splitk_finish", _p(slabs), ksplit, M, N, N, _p(bias), _p(rowscale), _p(aux), _ld(aux), _p(out32), _ld(out32),
+           _p(out16), _ld(out16), _stream())
 
 
 ROW_GEMM_MIN_M = 8192        # from this M on, the ViT GEMMs run on the 128 x 384 row-owning kernel (gemm_row.hip)

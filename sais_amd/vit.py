@@ -381,15 +381,16 @@ class VisionTransformer(nn.Module):
         rs_mlp = None if dp is None else dp[2 * i + 1].view(Fr, ntok)[:, 0].contiguous()
         x_mid, xn2, x_out = e32(Fr, D), e16(Fr, D), e32(Fr, D)
         mean2, rstd2 = (e32(Fr), e32(Fr)) if save else (None, None)
-        ops.gemm_nt(ao, f.w(p + "attn.proj.weight"), L.EPI_BIAS_RESID_F32, x_mid, bias=f.w32(p + "attn.proj.bias"), aux=x_cls,
-                    rowscale=rs_attn)
+        # [frames, 384] outputs: 6 tiles of 128 x 128 — the K loop is cut over workgroups (deterministic split-K)
+        ops.gemm_nt_splitk(ao, f.w(p + "attn.proj.weight"), 6, bias=f.w32(p + "attn.proj.bias"), rowscale=rs_attn, aux=x_cls,
+                           out32=x_mid)
         ops.layernorm_fwd(x_mid, Fr, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2, mean=mean2,
                           rstd=rstd2)
         h, u = e16(Fr, HID), (e16(Fr, HID) if save else None)
         ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
                     bias=f.w32(p + "mlp.fc1.bias"), out2=u)
-        ops.gemm_nt(h, f.w(p + "mlp.fc2.weight"), L.EPI_BIAS_RESID_F32, x_out, bias=f.w32(p + "mlp.fc2.bias"), aux=x_mid,
-                    rowscale=rs_mlp)
+        ops.gemm_nt_splitk(h, f.w(p + "mlp.fc2.weight"), 12, bias=f.w32(p + "mlp.fc2.bias"), rowscale=rs_mlp, aux=x_mid,
+                           out32=x_out)
         reps = e32(Fr, D)
         meanN, rstdN = (e32(Fr), e32(Fr)) if save else (None, None)
         ops.layernorm_fwd(x_out, Fr, D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN, rstd=rstdN)
@@ -420,10 +421,10 @@ class VisionTransformer(nn.Module):
         else:
             ops.cast_bf16_rows(dx_c, s["rs_mlp"], dxa_c)
         ops.gemm_nt(dxa_c, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
-        ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
+        ops.gemm_nt_splitk(du, f.wt16[p + "mlp.fc1.weight"], 12, out16=dxn)
         ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), Fr, dy16=dxn, dres=dx_c, dx32=dx_c,
                           dx16=dxb_c, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"), rowscale16=s["rs_attn"])
-        ops.gemm_nt(dxb_c, f.wt16[p + "attn.proj.weight"], L.EPI_BIAS_BF16, dao)
+        ops.gemm_nt_splitk(dxb_c, f.wt16[p + "attn.proj.weight"], 6, out16=dao)
         ops.vit_attn_cls_bwd(s["qkv"], dao, Fr, dqkv, ntok)
         ops.gemm_tn_grouped([
             (dxa_c, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),

@@ -706,6 +706,27 @@ def test_mlp_fused_bwd(ops, M, dp):
     assert_close(dbeta, br.grad, atol=2e-4 * scale * math.sqrt(M), rtol=1e-4, name="dbeta")
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(256, 384, 1536, 12), (200, 384, 384, 6), (37, 1536, 384, 4), (256, 384, 1536, 5)])
+def test_gemm_nt_splitk_small_m(ops, M, N, K, ks):
+    """Deterministic split-K for the [frames, 384] GEMMs of the CLS-only last block: raw slabs + sais_splitk_finish (bias,
+    row scale, fp32 residual, f32 and bf16 outputs) vs fp32 torch; ragged M, a split that does not divide K / 64."""
+    a = rnd(M, K, seed=70, dtype=torch.bfloat16)
+    w = rnd(N, K, seed=71, scale=0.05, dtype=torch.bfloat16)
+    bias, rs, aux = rnd(N, seed=72, scale=0.2), 0.5 + torch.rand(M, device=DEV), rnd(M, N, seed=73)
+    o32 = torch.full((M, N), float("nan"), device=DEV)
+    o16 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt_splitk(a, w, ks, bias=bias, rowscale=rs, aux=aux, out32=o32, out16=o16)
+    ref = aux + rs[:, None] * (a.float() @ w.float().t() + bias)
+    assert_close(o32, ref, atol=2e-3, rtol=1e-5, name="out32")
+    assert_close(o16, ref, atol=2e-2, rtol=1e-2, name="out16")
+    again = torch.empty_like(o32)
+    ops.gemm_nt_splitk(a, w, ks, bias=bias, rowscale=rs, aux=aux, out32=again)
+    assert torch.equal(again, o32)                               # fixed summation order
+    plain = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt_splitk(a, w, ks, out16=plain)
+    assert_close(plain, a.float() @ w.float().t(), atol=2e-2, rtol=1e-2, name="plain")
+
+
 def test_integration_md_ctypes_stub_runs_as_written(ops):
     """The ctypes binding shown in INTEGRATION.md (what a SAIS maintainer would paste) is executed verbatim: the struct
     layout in the document must match include/sais_hip.h, and the call must give fc1 + GELU."""

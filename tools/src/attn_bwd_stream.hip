@@ -3,7 +3,7 @@
 // inside the training step 13.75-13.81 vs 13.75 ms.  It passed every attention test.  What it shows: the up-front fill of
 // the staged-image kernel (49 us when timed alone, tools/gpu_attn_abl.sh) is NOT additive in the full kernel — taking 100
 // of its 150 KB off the critical path and under the query loop changes nothing; the per-step chain of dependent phases is
-// what paces the kernel.  To try it again: paste this block before `set_lds` in attn_vit.hip and launch it
+// what paces the kernel (LABNOTES.md 4.3).  To try it again: paste this block before `set_lds` in attn_vit.hip and launch it
 // with 1024 threads and bwd_stream_lds<Geo<197>>() bytes of dynamic LDS (same arguments as attn_bwd_kernel).
 // ------------------------------------------------------------------------------------------ backward, streamed queries
 // Same arithmetic and wave roles as attn_bwd_kernel, but Q, dO and O are never staged as whole images: the 32 query rows of

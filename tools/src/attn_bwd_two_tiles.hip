@@ -3,7 +3,7 @@
 // the same as the 16-wave attn_bwd_kernel of sais_amd/csrc/attn_vit.hip (131-132 us), both in the form below (all S / dP products
 // of a step first, then the exponentials, then dV / dK) and with the two 16-query halves processed one after the other; inside the
 // training step 13.73-13.76 vs 13.78 ms.  Halving the operand re-reads from LDS and doubling the independent work per wave at half
-// the waves per SIMD changes nothing: see the stamp timeline in DESIGN.md 4.3.  To try it again: paste this block before `set_lds`
+// the waves per SIMD changes nothing: see the stamp timeline in LABNOTES.md 4.3.  To try it again: paste this block before `set_lds`
 // in attn_vit.hip and launch it with 512 threads and bwd_lds<Geo<197>>() bytes of dynamic LDS (same arguments as attn_bwd_kernel).
 // ------------------------------------------------------------------------------------------ backward, two key tiles per wave
 // Same LDS images and arithmetic as attn_bwd_kernel with HALF the waves: 512 threads, waves 0-6 own key tiles 2w and 2w + 1
