@@ -280,6 +280,11 @@ int sais_vit_cls_rows(const float* cls, const float* pos0, float* tokens, long f
 int sais_vit_embed_bwd(const float* dtokens, int frames, int ntok, int dim, float* dcls, float* dpos,
                        void* dpatch_bf16, void* stream);
 
+/* Prefetch hint (ABI 8): reads [p, p + bytes) once with discarded loads so that the range is cache-resident (L2 /
+ * Infinity Cache) for the kernels that follow — the temporal encoder's ~70 small launches otherwise each pay a first-touch
+ * HBM round trip for weights the ViT's traffic evicted.  No effect on results.  p 16-B aligned.                       */
+int sais_touch(const void* p, long bytes, void* stream);
+
 /* ---------------------------------------------------------------- optimizer + weight shadows
  * optim.SGD(params, lr) — prepare_model.py:566-567, perform_training.py:155-158 (no momentum / wd).
  * param -= lr * grad_scale * grad; shadow_bf16 (optional) refreshed in the same pass.            */

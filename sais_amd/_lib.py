@@ -112,6 +112,7 @@ SIGNATURES = {
     "sais_preprocess_run": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "sais_preprocess_plan_destroy": [c_void_p],
     "sais_scale_f32": [c_void_p, c_long, c_float, c_void_p],
+    "sais_touch": [c_void_p, c_long, c_void_p],
     "sais_temporal_prepare_fwd": [c_void_p, c_long, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p],
     "sais_temporal_prepare_bwd": [c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p, c_long, c_long, c_int, c_void_p,

@@ -317,6 +317,24 @@ extern "C" int sais_transpose_batch(const SaisTransposeItem* items_dev, int nite
     return sais_check_launch();
 }
 
+// Pull a byte range towards the GPU (L2 / Infinity Cache) without using it: one discarded 16-B load per lane.  Used in front
+// of the temporal encoder, whose ~70 launches are a few microseconds each and otherwise pay a first-touch HBM round trip for
+// their weights in every one of them (the ViT's gigabytes evicted them since the last step).
+__global__ __launch_bounds__(256) void touch_kernel(const u32x4* p, long n16) {
+    u32x4 acc = {0, 0, 0, 0};
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n16; i += (long)gridDim.x * 256) acc |= p[i];
+    asm volatile("" ::"v"(acc));
+}
+
+extern "C" int sais_touch(const void* p, long bytes, void* stream) {
+    SAIS_ENTER();
+    if (!p || bytes <= 0 || ((uintptr_t)p & 15)) return SAIS_ERR_ARG;
+    const long n16 = bytes / 16;
+    if (n16 == 0) return SAIS_OK;
+    hipLaunchKernelGGL(touch_kernel, dim3(grid_for(n16)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)p, n16);
+    return sais_check_launch();
+}
+
 extern "C" int sais_scale_f32(float* p, long n, float s, void* stream) {
     SAIS_ENTER();
     if (!p || n <= 0) return SAIS_ERR_ARG;

@@ -29,6 +29,7 @@ class FlatParams:
         self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.w16 = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
         self.wt16 = {}                                   # name -> transposed bf16 copy [in, out]
+        self.wt_buf = None                               # the buffer they are views of
         self._tr_key, self._tr_table = None, None         # descriptor table of the batched transpose
         with torch.no_grad():
             for n, p in named:
@@ -93,12 +94,16 @@ class FlatParams:
             return
         if self._tr_key != names:
             entries = []
+            # all transposed shadows live in ONE buffer (a single range to prefetch: ops.touch(self.wt_buf))
+            dt = torch.float32 if self.f32_transposes else torch.bfloat16
+            total = sum((self.params[self._idx[n]].numel() + 7) // 8 * 8 for n in names)
+            self.wt_buf = torch.empty(total, device=self.device, dtype=dt)
+            self.wt16, off = {}, 0
             for n in names:
                 p = self.params[self._idx[n]]
                 rows, cols = p.shape
-                if n not in self.wt16:
-                    self.wt16[n] = torch.empty(cols, rows, device=self.device,
-                                               dtype=torch.float32 if self.f32_transposes else torch.bfloat16)
+                self.wt16[n] = self.wt_buf[off:off + rows * cols].view(cols, rows)
+                off += (rows * cols + 7) // 8 * 8
                 entries.append((self.w32(n), self.wt16[n]))
             self._tr_table = ops.transpose_table(entries, self.device)
             self._tr_key = names

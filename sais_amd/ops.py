@@ -359,6 +359,12 @@ def raft_lookup(pyr, coords, radius=4):
     return out
 
 
+def touch(t):
+    """Prefetch hint: pull a contiguous tensor towards the GPU's caches (include/sais_hip.h, sais_touch)."""
+    if t is not None and t.numel() and t.is_contiguous():
+        L.call("sais_touch", _p(t), t.numel() * t.element_size(), _stream())
+
+
 def patchify(frames_f32, patches):
     """frames f32 [F,3,side,side] -> bf16 [F*(side/16)^2, 768]."""
     _chk(frames_f32, F32, "frames")

@@ -29,6 +29,9 @@ from . import _lib as L
 from . import ops
 from .flat import FlatParams
 
+import os as _os
+
+_PREFETCH = _os.environ.get('SAIS_TEMPORAL_PREFETCH', '0') == '1'        # measured: no net gain (LABNOTES R4.3): off
 D, TH, FF, EMB, NPOS = 384, 4, 2048, 256, 2000
 
 
@@ -331,8 +334,26 @@ class fullModel(nn.Module):
             z = zo
         return z, attn, layers
 
+    def _prefetch(self, backward):
+        """The encoder's ~70 launches per step are a few microseconds each; their weights (35 MB fp32 forward, the same
+        again transposed for the backward) were evicted by the ViT's gigabytes since the last step, so every launch would
+        pay a first-touch HBM round trip of its own.  One streaming read in front pulls them into the Infinity Cache
+        (include/sais_hip.h, sais_touch).  Measured (round 4, two interleaved repetitions on one box): tgemm 11.5 instead of
+        12.2 us per launch, the two touch launches cost what that returns (12.89 / 12.99 vs 12.98 / 12.90 ms per step): the
+        launches are paced by their own dependent latency chain, not by where the weights sit.  Opt-in: SAIS_TEMPORAL_PREFETCH=1."""
+        if not _PREFETCH:
+            return
+        fl = self.flat
+        if backward:
+            ops.touch(fl.wt_buf)
+        else:
+            lo = fl.offsets["transEncoderFrame.layers.0.self_attn.in_proj_weight"]
+            hi = fl.offsets["transEncoderClip.layers.0.self_attn.in_proj_weight"]
+            ops.touch(fl.flat[lo:hi])
+
     def _forward_kernels(self, x, f, xpad, fpad, save, second=None):
         fl = self.flat
+        self._prefetch(False)
         zr = zf = sr = sf = attn = None
         drop = None
         if self.training and self.dropout_p > 0:
@@ -421,6 +442,7 @@ class fullModel(nn.Module):
     def _backward_kernels(self, saved, demb, needs, dimp=None):
         fl = self.flat
         fl.attach_grads()
+        self._prefetch(True)
         B, ns, Sx, Sf = saved["B"], saved["ns"], saved["Sx"], saved["Sf"]
         zr, zf = saved["zr"], saved["zf"]
         dzr = torch.zeros_like(zr) if zr is not None else None
