@@ -216,6 +216,66 @@ typedef struct SaisMlp {
 int sais_mlp_fwd(const SaisMlp* a, void* stream);
 int sais_mlp_bwd(const SaisMlp* a, void* stream);
 
+/* ================================================================ block-level entry points (ABI 8)
+ * One call = one Block of the ViT (dino-main/vision_transformer.py:95-113: x = x + drop_path(attn(norm1(x)));
+ * x = x + drop_path(mlp(norm2(x)))) in either direction: C-side sequencing of the GEMM-level entries above, so that a host
+ * in any language drives the encoder with 12 + 12 calls per step instead of re-implementing the ~25-launch plan of
+ * sais_amd/vit.py.  Conventions as everywhere: raw device pointers owned by the caller, no allocation, no host sync,
+ * asynchronous on `stream`, 0 / negative return.  Scratch comes from the caller: `workspace` of at least
+ * sais_workspace_bytes(op, frames, ntok) bytes, 256-B aligned.  The LayerNorms sit where the kernels fuse them: a forward call
+ * CONSUMES norm1(x_in) (xn1, written by the previous block's call, or by sais_layernorm_fwd for block 0) and PRODUCES the next
+ * block's norm1(x_out) (xn_next; next_norm_g == NULL for the last block).                                               */
+enum SaisOp { SAIS_OP_VIT_BLOCK_FWD = 0, SAIS_OP_VIT_BLOCK_BWD = 1 };
+size_t sais_workspace_bytes(int op, int frames, int ntok);
+
+typedef struct SaisVitBlockParams {
+    /* bf16 weight shadows [out,in] + f32 biases (nn.Linear of Attention :68-92 and Mlp :49-65), f32 LayerNorm parameters */
+    const void* qkv_w;  const float* qkv_b;       /* [1152,384] */
+    const void* proj_w; const float* proj_b;      /* [384,384]  */
+    const void* fc1_w;  const float* fc1_b;       /* [1536,384] */
+    const void* fc2_w;  const float* fc2_b;       /* [384,1536] */
+    const float* norm1_g;                         /* backward only */
+    const float* norm2_g; const float* norm2_b;
+    const float* next_norm_g; const float* next_norm_b;   /* forward: norm1 of the NEXT block, or NULL */
+    /* backward only: transposed bf16 shadows [in,out] (dX = dY . W runs on the same NT kernels) and f32 gradient accumulators */
+    const void* qkv_wt; const void* proj_wt; const void* fc1_wt; const void* fc2_wt;
+    float* d_qkv_w; float* d_qkv_b; float* d_proj_w; float* d_proj_b; float* d_fc1_w; float* d_fc1_b; float* d_fc2_w; float* d_fc2_b;
+    float* d_norm1_g; float* d_norm1_b; float* d_norm2_g; float* d_norm2_b;
+} SaisVitBlockParams;
+
+typedef struct SaisVitBlockFwd {
+    int frames, ntok;                /* M = frames * ntok token rows; ntok = 197 or 37 */
+    const void* xn1;                 /* in : bf16 [M,384] norm1(x_in)                                             */
+    const float* x_in;               /* in : f32 [M,384] residual stream                                          */
+    void* qkv;                       /* out: bf16 [M,1152]   (saved for backward)                                 */
+    void* attn_out;                  /* out: bf16 [M,384]    (saved)                                              */
+    float* lse;                      /* out: f32 [frames,6,ntok] (saved; NULL in inference)                        */
+    float* x_mid;                    /* out: f32 [M,384] x after the attention branch (may alias x_in in inference) */
+    void* xn2;                       /* out: bf16 [M,384] norm2(x_mid) (saved)                                     */
+    float* mean2; float* rstd2;      /* out: f32 [M] (saved; NULL in inference)                                    */
+    void* h;                         /* out: bf16 [M,1536] GELU(u) (saved; NULL in inference: workspace is used)    */
+    void* gelu_grad;                 /* out: bf16 [M,1536] GELU'(u) (saved; NULL in inference: not evaluated)       */
+    float* x_out;                    /* out: f32 [M,384] (may alias x_mid in inference)                            */
+    void* xn_next;                   /* out: bf16 [M,384] next block's norm1(x_out) (with next_norm_g)             */
+    float* mean_next; float* rstd_next;   /* out: f32 [M] (optional)                                              */
+    const float* rowscale_attn; const float* rowscale_mlp;   /* DropPath row scales f32 [M] of the two branches, or NULL */
+} SaisVitBlockFwd;
+int sais_vit_block_fwd(const SaisVitBlockParams* w, const SaisVitBlockFwd* a, void* workspace, size_t ws_bytes, void* stream);
+
+typedef struct SaisVitBlockBwd {
+    int frames, ntok;
+    /* what the forward call saved */
+    const float* x_in; const float* mean1; const float* rstd1; const void* xn1; const void* qkv; const void* attn_out;
+    const float* lse; const float* x_mid; const float* mean2; const float* rstd2; const void* xn2; const void* h;
+    const void* gelu_grad;
+    float* dx;                       /* in/out: f32 [M,384] gradient of the residual stream (x_out's on entry, x_in's on return) */
+    const void* dx16_in;             /* in : bf16 [M,384] = bf16(rowscale_mlp * dx): what enters the MLP branch           */
+    void* dx16_out;                  /* out: bf16 [M,384] = bf16(rowscale_prev * dx on return): the next call's dx16_in    */
+    const float* rowscale_attn;      /* DropPath scale of THIS block's attention branch, or NULL                           */
+    const float* rowscale_prev;      /* DropPath scale of the PREVIOUS block's MLP branch (applied to dx16_out), or NULL   */
+} SaisVitBlockBwd;
+int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBlockBwd* a, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- LayerNorm over dim = 384
  * nn.LayerNorm in Block / final norm (vision_transformer.py:99,103,107-113,212; eps 1e-6 from
  * vit_small :243-247) and norm1/norm2 of the post-norm TransformerEncoderLayer (prepare_model.py:74-81;

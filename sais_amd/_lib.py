@@ -51,6 +51,28 @@ class SaisMlp(ctypes.Structure):
                 ("g", c_void_p), ("ldg", c_int), ("tail", SaisGemmLn)]
 
 
+class SaisVitBlockParams(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "norm1_g", "norm2_g", "norm2_b",
+        "next_norm_g", "next_norm_b", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b",
+        "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_norm1_g", "d_norm1_b", "d_norm2_g", "d_norm2_b")]
+
+
+class SaisVitBlockFwd(ctypes.Structure):
+    _fields_ = [("frames", c_int), ("ntok", c_int)] + [(n, c_void_p) for n in (
+        "xn1", "x_in", "qkv", "attn_out", "lse", "x_mid", "xn2", "mean2", "rstd2", "h", "gelu_grad", "x_out", "xn_next",
+        "mean_next", "rstd_next", "rowscale_attn", "rowscale_mlp")]
+
+
+class SaisVitBlockBwd(ctypes.Structure):
+    _fields_ = [("frames", c_int), ("ntok", c_int)] + [(n, c_void_p) for n in (
+        "x_in", "mean1", "rstd1", "xn1", "qkv", "attn_out", "lse", "x_mid", "mean2", "rstd2", "xn2", "h", "gelu_grad", "dx",
+        "dx16_in", "dx16_out", "rowscale_attn", "rowscale_prev")]
+
+
+OP_VIT_BLOCK_FWD, OP_VIT_BLOCK_BWD = 0, 1
+
+
 class SaisOptChunk(ctypes.Structure):
     _fields_ = [("off", c_long), ("len", c_int), ("seg", c_int)]
 
@@ -80,6 +102,11 @@ SIGNATURES = {
                            c_int, c_void_p],
     "sais_gemm_ln_fwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
     "sais_gemm_ln_bwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
+    "sais_workspace_bytes": [c_int, c_int, c_int],
+    "sais_vit_block_fwd": [ctypes.POINTER(SaisVitBlockParams), ctypes.POINTER(SaisVitBlockFwd), c_void_p, ctypes.c_size_t,
+                           c_void_p],
+    "sais_vit_block_bwd": [ctypes.POINTER(SaisVitBlockParams), ctypes.POINTER(SaisVitBlockBwd), c_void_p, ctypes.c_size_t,
+                           c_void_p],
     "sais_mlp_fwd": [ctypes.POINTER(SaisMlp), c_void_p],
     "sais_mlp_bwd": [ctypes.POINTER(SaisMlp), c_void_p],
     "sais_gemm_tn_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
@@ -186,6 +213,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = c_int
     lib.sais_preprocess_plan_destroy.restype = None
+    lib.sais_workspace_bytes.restype = ctypes.c_size_t
     lib.sais_last_error.restype = ctypes.c_char_p
     lib.sais_last_error.argtypes = []
     _lib = lib

@@ -1,0 +1,163 @@
+// Block-level entry points (include/sais_hip.h, "block-level entry points"): one Block of the DINO ViT
+// (dino-main/vision_transformer.py:95-113) per call, forward or backward, as C-side sequencing of the GEMM-level entries of
+// this library — the launch plan that sais_amd/vit.py otherwise spells out in Python.  Host code only: no kernels here.
+//
+// Two dispatch regimes, chosen by M = frames * ntok exactly as the Python host does (ops.ROW_GEMM_MIN_M): from 8192 rows on
+// the LayerNorms live in the epilogues of the row-owning GEMMs (sais_gemm_ln_fwd / _bwd), below that the stand-alone
+// LayerNorm kernels run behind plain GEMMs.  Both give the reference's Block; only the launch count differs.
+#include <string.h>
+#include "common.hpp"
+#include "../../include/sais_hip.h"
+
+namespace {
+constexpr int D = 384, HID = 1536, QKV = 1152;
+constexpr int ROW_GEMM_MIN_M = 8192;
+constexpr size_t ALIGN = 256;
+
+size_t up(size_t b) { return (b + ALIGN - 1) / ALIGN * ALIGN; }
+
+int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, const float* bias, void* out, int ldo,
+         void* out2, int ldo2, const void* aux, int ldaux, const float* rowscale, void* stream) {
+    SaisGemm g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.epilogue = epi; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.out2 = out2; g.ldo2 = ldo2; g.aux = aux; g.ldaux = ldaux; g.rowscale = rowscale;
+    return sais_gemm_nt(&g, stream);
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != SAIS_OK) return rc_; } while (0)
+}  // namespace
+
+extern "C" size_t sais_workspace_bytes(int op, int frames, int ntok) {
+    if (frames <= 0 || ntok <= 0) return 0;
+    const size_t M = (size_t)frames * ntok;
+    switch (op) {
+        case SAIS_OP_VIT_BLOCK_FWD:                    // GELU(u) when the caller does not keep it (inference)
+            return up(M * HID * 2);
+        case SAIS_OP_VIT_BLOCK_BWD:                    // du, d(mid) bf16, d(attention out), dqkv, dxn (small-M regime)
+            return up(M * HID * 2) + 3 * up(M * D * 2) + up(M * QKV * 2);
+        default:
+            return 0;
+    }
+}
+
+extern "C" int sais_vit_block_fwd(const SaisVitBlockParams* w, const SaisVitBlockFwd* a, void* workspace, size_t ws_bytes,
+                                  void* stream) {
+    SAIS_ENTER();
+    if (!w || !a || a->frames <= 0 || (a->ntok != 197 && a->ntok != 37)) return SAIS_ERR_ARG;
+    if (!a->xn1 || !a->x_in || !a->qkv || !a->attn_out || !a->x_mid || !a->xn2 || !a->x_out) return SAIS_ERR_ARG;
+    if (!w->qkv_w || !w->proj_w || !w->fc1_w || !w->fc2_w || !w->norm2_g || !w->norm2_b) return SAIS_ERR_ARG;
+    if (a->gelu_grad && !a->h) return SAIS_ERR_ARG;
+    if (w->next_norm_g && (!w->next_norm_b || !a->xn_next)) return SAIS_ERR_ARG;
+    const int M = a->frames * a->ntok;
+    void* h = a->h;
+    if (!h) {
+        if (!workspace || ws_bytes < sais_workspace_bytes(SAIS_OP_VIT_BLOCK_FWD, a->frames, a->ntok)) return SAIS_ERR_ARG;
+        h = workspace;
+    }
+    const bool fused = M >= ROW_GEMM_MIN_M;
+    // attention branch: qkv -> softmax(q k^T / 8) v -> proj, + residual (DropPath row scale), then norm2
+    TRY(gemm(a->xn1, D, w->qkv_w, D, M, QKV, D, SAIS_EPI_BIAS_BF16, w->qkv_b, a->qkv, QKV, nullptr, 0, nullptr, 0, nullptr, stream));
+    TRY(sais_vit_attn_fwd(a->qkv, QKV, a->frames, a->ntok, a->attn_out, D, a->lse, nullptr, stream));
+    if (fused) {
+        SaisGemmLn g;
+        memset(&g, 0, sizeof(g));
+        g.A = a->attn_out; g.lda = D; g.W = w->proj_w; g.ldw = D; g.M = M; g.K = D; g.bias = w->proj_b;
+        g.resid = a->x_in; g.ldr = D; g.out32 = a->x_mid; g.ldo32 = D; g.out16 = a->xn2; g.ldo16 = D;
+        g.gamma = w->norm2_g; g.beta = w->norm2_b; g.eps = 1e-6f; g.mean = a->mean2; g.rstd = a->rstd2;
+        g.rowscale = a->rowscale_attn;
+        TRY(sais_gemm_ln_fwd(&g, stream));
+    } else {
+        TRY(gemm(a->attn_out, D, w->proj_w, D, M, D, D, SAIS_EPI_BIAS_RESID_F32, w->proj_b, a->x_mid, D, nullptr, 0, a->x_in, D,
+                 a->rowscale_attn, stream));
+        TRY(sais_layernorm_fwd(a->x_mid, D, M, D, w->norm2_g, w->norm2_b, 1e-6f, a->xn2, D, nullptr, 0, a->mean2, a->rstd2, stream));
+    }
+    // MLP branch: fc1 + GELU (+ GELU' for the backward) -> fc2 + residual (+ the next block's norm1)
+    TRY(gemm(a->xn2, D, w->fc1_w, D, M, HID, D, a->gelu_grad ? SAIS_EPI_BIAS_GELU_GRAD_BF16 : SAIS_EPI_BIAS_GELU_BF16, w->fc1_b,
+             h, HID, a->gelu_grad, HID, nullptr, 0, nullptr, stream));
+    if (fused && w->next_norm_g) {
+        SaisGemmLn g;
+        memset(&g, 0, sizeof(g));
+        g.A = h; g.lda = HID; g.W = w->fc2_w; g.ldw = HID; g.M = M; g.K = HID; g.bias = w->fc2_b;
+        g.resid = a->x_mid; g.ldr = D; g.out32 = a->x_out; g.ldo32 = D; g.out16 = a->xn_next; g.ldo16 = D;
+        g.gamma = w->next_norm_g; g.beta = w->next_norm_b; g.eps = 1e-6f; g.mean = a->mean_next; g.rstd = a->rstd_next;
+        g.rowscale = a->rowscale_mlp;
+        TRY(sais_gemm_ln_fwd(&g, stream));
+    } else {
+        TRY(gemm(h, HID, w->fc2_w, HID, M, D, HID, SAIS_EPI_BIAS_RESID_F32, w->fc2_b, a->x_out, D, nullptr, 0, a->x_mid, D,
+                 a->rowscale_mlp, stream));
+        if (w->next_norm_g)
+            TRY(sais_layernorm_fwd(a->x_out, D, M, D, w->next_norm_g, w->next_norm_b, 1e-6f, a->xn_next, D, nullptr, 0,
+                                   a->mean_next, a->rstd_next, stream));
+    }
+    return SAIS_OK;
+}
+
+extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBlockBwd* a, void* workspace, size_t ws_bytes,
+                                  void* stream) {
+    SAIS_ENTER();
+    if (!w || !a || a->frames <= 0 || (a->ntok != 197 && a->ntok != 37)) return SAIS_ERR_ARG;
+    if (!a->x_in || !a->mean1 || !a->rstd1 || !a->xn1 || !a->qkv || !a->attn_out || !a->lse || !a->x_mid || !a->mean2 ||
+        !a->rstd2 || !a->xn2 || !a->h || !a->gelu_grad || !a->dx || !a->dx16_in || !a->dx16_out)
+        return SAIS_ERR_ARG;
+    if (!w->qkv_wt || !w->proj_wt || !w->fc1_wt || !w->fc2_wt || !w->norm1_g || !w->norm2_g || !w->d_qkv_w || !w->d_proj_w ||
+        !w->d_fc1_w || !w->d_fc2_w || !w->d_norm1_g || !w->d_norm1_b || !w->d_norm2_g || !w->d_norm2_b)
+        return SAIS_ERR_ARG;
+    if (!workspace || ws_bytes < sais_workspace_bytes(SAIS_OP_VIT_BLOCK_BWD, a->frames, a->ntok) || ((uintptr_t)workspace & 15))
+        return SAIS_ERR_ARG;
+    const int M = a->frames * a->ntok;
+    char* ws = (char*)workspace;
+    void* du = ws;             ws += up((size_t)M * HID * 2);
+    void* dxb = ws;            ws += up((size_t)M * D * 2);
+    void* dao = ws;            ws += up((size_t)M * D * 2);
+    void* dxn = ws;            ws += up((size_t)M * D * 2);
+    void* dqkv = ws;
+    const bool fused = M >= ROW_GEMM_MIN_M;
+    // MLP branch: du = (d . W2) * GELU'(u);  d(norm2 out) = du . W1;  norm2's backward adds the residual gradient
+    TRY(gemm(a->dx16_in, D, w->fc2_wt, D, M, HID, D, SAIS_EPI_MUL_BF16, nullptr, du, HID, nullptr, 0, a->gelu_grad, HID, nullptr, stream));
+    if (fused) {
+        SaisGemmLn g;
+        memset(&g, 0, sizeof(g));
+        g.A = du; g.lda = HID; g.W = w->fc1_wt; g.ldw = HID; g.M = M; g.K = HID;
+        g.resid = a->x_mid; g.ldr = D; g.out32 = a->dx; g.ldo32 = D; g.out16 = dxb; g.ldo16 = D;
+        g.gamma = w->norm2_g; g.mean = (float*)a->mean2; g.rstd = (float*)a->rstd2; g.dres = a->dx; g.lddres = D;
+        g.dgamma = w->d_norm2_g; g.dbeta = w->d_norm2_b; g.rowscale16 = a->rowscale_attn;
+        TRY(sais_gemm_ln_bwd(&g, stream));
+    } else {
+        TRY(gemm(du, HID, w->fc1_wt, HID, M, D, HID, SAIS_EPI_BIAS_BF16, nullptr, dxn, D, nullptr, 0, nullptr, 0, nullptr, stream));
+        TRY(sais_layernorm_bwd(dxn, D, nullptr, 0, a->x_mid, D, a->mean2, a->rstd2, w->norm2_g, a->dx, D, M, D, a->dx, D, dxb, D,
+                               w->d_norm2_g, w->d_norm2_b, a->rowscale_attn, nullptr, 0.f, nullptr, 0, stream));
+    }
+    // attention branch
+    TRY(gemm(dxb, D, w->proj_wt, D, M, D, D, SAIS_EPI_BIAS_BF16, nullptr, dao, D, nullptr, 0, nullptr, 0, nullptr, stream));
+    TRY(sais_vit_attn_bwd(a->qkv, QKV, dao, D, a->attn_out, D, a->lse, nullptr, a->frames, a->ntok, dqkv, QKV, stream));
+    // the four weight / bias gradients of the block in one launch
+    SaisTnItem items[4] = {
+        {a->dx16_in, D, a->h, HID, D, HID, w->d_fc2_w, HID, w->d_fc2_b},
+        {du, HID, a->xn2, D, HID, D, w->d_fc1_w, D, w->d_fc1_b},
+        {dxb, D, a->attn_out, D, D, D, w->d_proj_w, D, w->d_proj_b},
+        {dqkv, QKV, a->xn1, D, QKV, D, w->d_qkv_w, D, w->d_qkv_b}};
+    {
+        const int tiles = (D / 128) * (HID / 128) * 2 + (D / 128) * (D / 128) + (QKV / 128) * (D / 128);
+        int nsplit = (432 + tiles - 1) / tiles;
+        const int cap = (M + 255) / 256;
+        if (nsplit > cap) nsplit = cap;
+        if (nsplit < 1) nsplit = 1;
+        TRY(sais_gemm_tn_grouped(items, 4, M, nsplit, stream));
+    }
+    // dX of qkv + norm1's backward: the gradient of the block input
+    if (fused) {
+        SaisGemmLn g;
+        memset(&g, 0, sizeof(g));
+        g.A = dqkv; g.lda = QKV; g.W = w->qkv_wt; g.ldw = QKV; g.M = M; g.K = QKV;
+        g.resid = a->x_in; g.ldr = D; g.out32 = a->dx; g.ldo32 = D; g.out16 = a->dx16_out; g.ldo16 = D;
+        g.gamma = w->norm1_g; g.mean = (float*)a->mean1; g.rstd = (float*)a->rstd1; g.dres = a->dx; g.lddres = D;
+        g.dgamma = w->d_norm1_g; g.dbeta = w->d_norm1_b; g.rowscale16 = a->rowscale_prev;
+        TRY(sais_gemm_ln_bwd(&g, stream));
+    } else {
+        TRY(gemm(dqkv, QKV, w->qkv_wt, QKV, M, D, QKV, SAIS_EPI_BIAS_BF16, nullptr, dxn, D, nullptr, 0, nullptr, 0, nullptr, stream));
+        TRY(sais_layernorm_bwd(dxn, D, nullptr, 0, a->x_in, D, a->mean1, a->rstd1, w->norm1_g, a->dx, D, M, D, a->dx, D,
+                               a->dx16_out, D, w->d_norm1_g, w->d_norm1_b, a->rowscale_prev, nullptr, 0.f, nullptr, 0, stream));
+    }
+    return SAIS_OK;
+}

@@ -316,6 +316,48 @@ def vit_attn_bwd(qkv, dout, out, lse, delta_ws, frames, dqkv, ntok=197):
                           _p(lse), _p(delta_ws), frames, ntok, _p(dqkv), dqkv.stride(0), _stream()))
 
 
+def vit_block_params(f, i, depth):
+    """SaisVitBlockParams of block i from a FlatParams engine (include/sais_hip.h): pointers into the flat parameter /
+    gradient / shadow buffers, valid as long as those buffers live."""
+    p = f"blocks.{i}."
+    nxt = f"blocks.{i + 1}." if i + 1 < depth else None
+    P = L.SaisVitBlockParams()
+    for k, name in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2")):
+        setattr(P, k + "_w", _p(f.w(p + name + ".weight")))
+        setattr(P, k + "_b", _p(f.w32(p + name + ".bias")))
+        setattr(P, k + "_wt", _p(f.wt16[p + name + ".weight"]))
+        setattr(P, "d_" + k + "_w", _p(f.g(p + name + ".weight")))
+        setattr(P, "d_" + k + "_b", _p(f.g(p + name + ".bias")))
+    P.norm1_g, P.norm2_g, P.norm2_b = _p(f.w32(p + "norm1.weight")), _p(f.w32(p + "norm2.weight")), _p(f.w32(p + "norm2.bias"))
+    P.d_norm1_g, P.d_norm1_b = _p(f.g(p + "norm1.weight")), _p(f.g(p + "norm1.bias"))
+    P.d_norm2_g, P.d_norm2_b = _p(f.g(p + "norm2.weight")), _p(f.g(p + "norm2.bias"))
+    if nxt is not None:
+        P.next_norm_g, P.next_norm_b = _p(f.w32(nxt + "norm1.weight")), _p(f.w32(nxt + "norm1.bias"))
+    return P
+
+
+def block_workspace(op, frames, ntok, device):
+    n = L.load().sais_workspace_bytes(op, frames, ntok)
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def vit_block_fwd(P, frames, ntok, xn1, x_in, qkv, attn_out, lse, x_mid, xn2, mean2, rstd2, h, gelu_grad, x_out, xn_next,
+                  mean_next, rstd_next, rs_attn, rs_mlp, ws):
+    """One ViT Block forward as ONE C call (sais_vit_block_fwd: C-side sequencing of the GEMM-level launches)."""
+    a = L.SaisVitBlockFwd(frames, ntok, _p(xn1), _p(x_in), _p(qkv), _p(attn_out), _p(lse), _p(x_mid), _p(xn2), _p(mean2),
+                          _p(rstd2), _p(h), _p(gelu_grad), _p(x_out), _p(xn_next), _p(mean_next), _p(rstd_next), _p(rs_attn),
+                          _p(rs_mlp))
+    L.call("sais_vit_block_fwd", ctypes.byref(P), ctypes.byref(a), _p(ws), 0 if ws is None else ws.numel(), _stream())
+
+
+def vit_block_bwd(P, frames, ntok, s, dx, dx16_in, dx16_out, rs_attn, rs_prev, lse, ws):
+    """One ViT Block backward as ONE C call (sais_vit_block_bwd); s = the tensors the forward saved."""
+    a = L.SaisVitBlockBwd(frames, ntok, _p(s["x_in"]), _p(s["mean1"]), _p(s["rstd1"]), _p(s["xn1"]), _p(s["qkv"]), _p(s["ao"]),
+                          _p(lse), _p(s["x_mid"]), _p(s["mean2"]), _p(s["rstd2"]), _p(s["xn2"]), _p(s["h"]), _p(s["dgelu"]),
+                          _p(dx), _p(dx16_in), _p(dx16_out), _p(rs_attn), _p(rs_prev))
+    L.call("sais_vit_block_bwd", ctypes.byref(P), ctypes.byref(a), _p(ws), ws.numel(), _stream())
+
+
 def vit_attn_cls_fwd(qkv, frames, out_c, ntok=197):
     """The last block's attention for the CLS query only: out_c bf16 [frames, 384] (include/sais_hip.h)."""
     _chk(qkv, BF16, "qkv"); _chk(out_c, BF16, "out")

@@ -133,6 +133,9 @@ class VisionTransformer(nn.Module):
         # parameter gradients are unchanged.  SAIS_VIT_PRUNE_LAST=0 / prune_last_block = False computes every row.
         import os as _os
         self.prune_last_block = _os.environ.get("SAIS_VIT_PRUNE_LAST", "1") != "0"
+        # one C call per Block (sais_vit_block_fwd / _bwd) instead of the per-launch Python sequence; SAIS_VIT_BLOCK_CALLS=0 off
+        self.block_calls = _os.environ.get("SAIS_VIT_BLOCK_CALLS", "1") != "0"
+        self._bp, self._wsbuf = None, {}
         self._rng = None
         self.last_droppath_scales = None
         self.patch_embed = _PatchEmbed()
@@ -284,6 +287,7 @@ class VisionTransformer(nn.Module):
         xn2 = e16(M, D)
         mean1 = rstd1 = None
         prune = self.prune_last_block and len(groups) == 1 and not want_last_attn
+        blockcall = self.block_calls and ops.TIMER is None and len(groups) == 1 and fused
         for i in range(self.depth):
             p = f"blocks.{i}."
             last_attn = want_last_attn and i == self.depth - 1
@@ -297,13 +301,40 @@ class VisionTransformer(nn.Module):
                     xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
                 ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
                                   rstd=rstd1)
-            ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
+            use_block = blockcall and not last_attn and not ops.mlp_fused_enabled(M) and not (prune and i == self.depth - 1)
+            if not use_block:
+                ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
             if prune and i == self.depth - 1:
                 reps, tail = self._cls_tail_fwd(f, i, x, xn, mean1, rstd1, qkv, groups[0], dp, save, e16, e32)
                 if save:
                     saved["blocks"].append(tail)
                     saved.update(x_final=tail["x_out"], meanN=tail["meanN"], rstdN=tail["rstdN"], pruned=True)
                 return reps, saved
+            # One C call per Block (sais_vit_block_fwd: the launches below, sequenced by the library) whenever nothing needs the
+            # per-launch view: no HIP-event instrumentation (bench.py's roofline pass), one resolution group, no probabilities
+            if use_block:
+                g0 = groups[0]
+                lse0 = e32(g0["Fr"], HEADS, g0["ntok"]) if save else None
+                x_mid = e32(M, D) if save else x
+                x_out = e32(M, D) if save else x
+                if save:
+                    xn2 = e16(M, D)
+                mean2, rstd2 = (e32(M), e32(M)) if save else (None, None)
+                u = e16(M, HID) if save else None
+                nxt = i + 1 < self.depth
+                blk = dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=[lse0], x_mid=x_mid, mean2=mean2,
+                           rstd2=rstd2, xn2=xn2, dgelu=u, h=h) if save else None
+                xn_in = xn
+                if nxt and save:
+                    xn, mean1, rstd1 = e16(M, D), e32(M), e32(M)
+                ops.vit_block_fwd(self._block_params(i), g0["Fr"], g0["ntok"], xn_in, x, qkv, ao, lse0, x_mid, xn2, mean2, rstd2,
+                                  h if save else None, u, x_out, xn if nxt else None, mean1 if nxt else None,
+                                  rstd1 if nxt else None, None if dp is None else dp[2 * i],
+                                  None if dp is None else dp[2 * i + 1], None if save else self._ws(L.OP_VIT_BLOCK_FWD, g0, dev))
+                if save:
+                    saved["blocks"].append(blk)
+                x = x_out
+                continue
             lse, probs = [], None
             for g in groups:
                 Fr, ntok, lo = g["Fr"], g["ntok"], g["off"]
@@ -367,6 +398,23 @@ class VisionTransformer(nn.Module):
         if save:
             saved.update(x_final=x, meanN=meanN, rstdN=rstdN)
         return reps, saved
+
+    def _block_params(self, i):
+        """ctypes parameter blocks of the Blocks (pointers into the flat buffers), rebuilt when those are."""
+        f = self.flat
+        key = (f.flat.data_ptr(), f.grad.data_ptr(), f.w16.data_ptr(), 0 if f.wt_buf is None else f.wt_buf.data_ptr())
+        if self._bp is None or self._bp[0] != key:
+            self._bp = (key, [ops.vit_block_params(f, j, self.depth) for j in range(self.depth)])
+        return self._bp[1][i]
+
+    def _ws(self, op, grp, dev):
+        """Scratch for a block-level call (sais_workspace_bytes), kept per (op, shape) outside hipGraph pools."""
+        if torch.cuda.is_current_stream_capturing():
+            return ops.block_workspace(op, grp["Fr"], grp["ntok"], dev)
+        key = (op, grp["Fr"], grp["ntok"], str(dev))
+        if key not in self._wsbuf:
+            self._wsbuf[key] = ops.block_workspace(op, grp["Fr"], grp["ntok"], dev)
+        return self._wsbuf[key]
 
     def _cls_tail_fwd(self, f, i, x, xn1, mean1, rstd1, qkv, grp, dp, save, e16, e32):
         """The last block from its qkv on, restricted to what forward() returns (the CLS rows): attention for the CLS query
@@ -489,6 +537,14 @@ class VisionTransformer(nn.Module):
             s = saved["blocks"][i]
             rs_attn = None if dp is None else dp[2 * i]                        # this block's attention branch
             rs_prev = None if dp is None or i == 0 else dp[2 * (i - 1) + 1]     # the MLP branch of block i - 1
+            if self.block_calls and ops.TIMER is None and len(groups) == 1 and fused and not ops.mlp_fused_enabled(M):
+                g0 = groups[0]
+                ops.vit_block_bwd(self._block_params(i), g0["Fr"], g0["ntok"], s, dx, dxa, dxa, rs_attn, rs_prev, s["lse"][0],
+                                  self._ws(L.OP_VIT_BLOCK_BWD, g0, dev))
+                saved["blocks"][i] = None
+                if self.grad_ready_hook:
+                    self.grad_ready_hook(*self.block_grad_range(i))
+                continue
             # MLP branch
             if fused and ops.mlp_fused_enabled(M):    # dX of fc2 x GELU' -> dX of fc1 -> norm2's backward: ONE launch
                 ops.mlp_bwd(dxa, f.wt16[p + "mlp.fc2.weight"], s["dgelu"], f.wt16[p + "mlp.fc1.weight"], du, s["x_mid"],

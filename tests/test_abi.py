@@ -12,7 +12,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(_lib.LIB_PATH):
         ge.build()
     hdr = open(os.path.join(ROOT, "include", "sais_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|void)\s+(sais_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|size_t)\s+(sais_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 20
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -54,3 +54,17 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_weight_norm_fwd(None, None, 1, 256, None, None, None) == -1
     assert lib.sais_split_bf16x3(None, 256, 1, 256, None, 0, None) == -1
     assert lib.sais_pos_interp_fwd(None, 36, 196, None, 384, None, None) == -1
+    # round 4 (ABI 8): block-level entries, CLS-only attention, split-K finish, RAFT correlation volume
+    assert lib.sais_mlp_fwd(None, None) == -1 and lib.sais_mlp_bwd(ctypes.byref(_lib.SaisMlp()), None) == -1
+    assert lib.sais_vit_block_fwd(None, None, None, 0, None) == -1
+    assert lib.sais_vit_block_bwd(ctypes.byref(_lib.SaisVitBlockParams()), ctypes.byref(_lib.SaisVitBlockBwd()), None, 0, None) == -1
+    M = 256 * 197
+    assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_FWD, 256, 197) >= M * 1536 * 2
+    assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_BWD, 256, 197) >= M * (1536 + 3 * 384 + 1152) * 2
+    assert lib.sais_workspace_bytes(99, 256, 197) == 0
+    assert lib.sais_vit_attn_cls_fwd(None, 1152, 1, 197, None, 384, None) == -1
+    assert lib.sais_vit_attn_cls_bwd(ctypes.c_void_p(16), 1152, ctypes.c_void_p(16), 384, 1, 500, ctypes.c_void_p(16), 1152, None) == -1
+    assert lib.sais_splitk_finish(None, 2, 4, 384, 384, None, None, None, 0, None, 0, None, 0, None) == -1
+    assert lib.sais_touch(None, 64, None) == -1
+    assert lib.sais_raft_corr_pool(None, 64, 1, 8, 8, None, None, None, None) == -1
+    assert lib.sais_raft_lookup(None, 64, None, None, None, None, 1, 8, 8, 4, None, None) == -1

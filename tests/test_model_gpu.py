@@ -391,6 +391,39 @@ def test_sgd_step_matches_oracle_update(gpu):
     assert loss1.item() < loss.item()
 
 
+@pytest.mark.parametrize("rate,train", [(0.0, True), (0.2, True), (0.0, False)])
+def test_block_level_c_calls_equal_the_per_launch_sequence(gpu, rate, train):
+    """sais_vit_block_fwd / _bwd (one C call per Block: SURVEY 8b) issue the same launches in the same order as the
+    per-launch Python sequence: features bit-identical, gradients equal up to the order of the fp32 atomics of the dW
+    kernels; training (everything saved), DropPath, and inference (in place on the residual stream, GELU(u) in the
+    workspace).  48 frames: the LayerNorm-fused regime the block entries dispatch at M >= 8192."""
+    from sais_amd.vit import vit_small
+
+    def run(block_calls):
+        v = vit_small(patch_size=16, drop_path_rate=rate, depth=3)
+        v.load_state_dict(synth.vit_state_dict(seed=0, depth=3), strict=True)
+        v = v.to(DEV)
+        v.block_calls = block_calls
+        v.prune_last_block = False                    # all three blocks through the block entries
+        v.drop_path_seed = 9
+        x = synth.clips(seed=951, B=1, T=48)[0].to(DEV)
+        if not train:
+            with torch.no_grad():
+                return v.eval()(x), None
+        v.train()
+        w = synth.reps(seed=952, B=1, T=48)[0, 0].to(DEV)
+        feat = v(x)
+        (feat * w).sum().backward()
+        return feat.detach(), v.flat.grad.clone()
+
+    f1, g1 = run(True)
+    f0, g0 = run(False)
+    assert torch.equal(f1, f0)
+    if train:
+        assert float(g0.abs().max()) > 0
+        assert float((g1 - g0).norm() / g0.norm()) <= 1e-5
+
+
 @pytest.mark.parametrize("frames,rate", [(6, 0.0), (48, 0.2)])
 def test_pruned_last_block_equals_full_compute(gpu, frames, rate):
     """forward() returns norm(x)[:, 0]: the last block runs on the CLS rows / the CLS query only (sais_amd.vit,
