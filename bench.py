@@ -46,8 +46,8 @@ HBM_BYTES_PER_FRAME = 133e6      # SURVEY §8d / BASELINE.md §4: fused bf16 pla
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)          # 50 x ~13 ms: a timed region of ~0.65 s (round 3's default: 0.27 s)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--clips", type=int, default=8, help="clips per GPU (BASELINE config 2: 8)")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,19 +163,22 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(T, C, threads):
+def cpu_baseline(T, C, threads, weights):
     """CPU oracle (fp32 torch restatement of the reference, pinned to its golden vectors) on bounded samples of the
-    configurations BASELINE.md §3 lists.  `value` = config 2's model on one 32-frame clip, fwd+bwd+SGD (the same
-    figure as round 1); `variants` holds config 1 and the B=8 / forward-only legs."""
+    configurations BASELINE.md §3 lists, with the TIMED model's own weights (`weights` = its ViT / temporal state dicts and
+    prototypes on the host).  `value` = config 2's model on one 32-frame clip, fwd+bwd+SGD (the same figure as round 1);
+    `variants` holds config 1 and the B=8 / forward-only legs."""
     import torch
     import synth
     from oracle import sais_oracle as O
     torch.set_num_threads(threads)
+    w_vit, w_tmp, w_pro = weights
 
     def leg(B, Tn, nlayers, train, budget_s, max_steps):
-        vsd = {k: v.clone().requires_grad_(train) for k, v in synth.vit_state_dict(seed=0).items()}
-        tsd = {k: v.clone().requires_grad_(train) for k, v in synth.temporal_state_dict(seed=1, nlayers=nlayers).items()}
-        pr = {k: v.clone().requires_grad_(train) for k, v in synth.prototypes(2, C).items()}
+        vsd = {k: v.clone().requires_grad_(train) for k, v in w_vit.items()}
+        tsd = {k: v.clone().requires_grad_(train) for k, v in w_tmp.items() if "frame_pos_embeddings" not in k or
+               int(k.rsplit(".", 1)[1]) < Tn}                 # the oracle reads position rows 0..T-1 only
+        pr = {k: v.clone().requires_grad_(train) for k, v in w_pro.items()}
         clips = synth.clips(seed=0, B=B, T=Tn)
         pad = synth.padding_mask([Tn] * B)
         lab = synth.labels(seed=0, B=B, nclasses=C)
@@ -686,7 +689,11 @@ def main():
                 avail = os.cpu_count() or 1
             # fp32 ViT-S on one 32-frame clip stops scaling past a few dozen threads (and oversubscribed
             # hosts get much slower), so use at most 32 of the host's cores; `cores` reports what was used
-            out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)))
+            weights = ({k: v.detach().float().cpu() for k, v in vit.state_dict().items()},
+                       {k: v.detach().float().cpu() for k, v in model.state_dict().items()
+                        if not k.startswith(("clip_", "transEncoderClip", "attention", "finalModules", "linear2"))},
+                       {k: v.detach().float().cpu() for k, v in protos.items()})
+            out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)), weights)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()

@@ -225,8 +225,8 @@ int sais_mlp_bwd(const SaisMlp* a, void* stream);
  * sais_workspace_bytes(op, frames, ntok) bytes, 256-B aligned.  The LayerNorms sit where the kernels fuse them: a forward call
  * CONSUMES norm1(x_in) (xn1, written by the previous block's call, or by sais_layernorm_fwd for block 0) and PRODUCES the next
  * block's norm1(x_out) (xn_next; next_norm_g == NULL for the last block).                                               */
-enum SaisOp { SAIS_OP_VIT_BLOCK_FWD = 0, SAIS_OP_VIT_BLOCK_BWD = 1 };
-size_t sais_workspace_bytes(int op, int frames, int ntok);
+enum SaisOp { SAIS_OP_VIT_BLOCK_FWD = 0, SAIS_OP_VIT_BLOCK_BWD = 1, SAIS_OP_TEMPORAL_LAYER_FWD = 2, SAIS_OP_TEMPORAL_LAYER_BWD = 3 };
+size_t sais_workspace_bytes(int op, int frames, int ntok);   /* temporal ops: (op, sequences B, tokens S) */
 
 typedef struct SaisVitBlockParams {
     /* bf16 weight shadows [out,in] + f32 biases (nn.Linear of Attention :68-92 and Mlp :49-65), f32 LayerNorm parameters */
@@ -275,6 +275,54 @@ typedef struct SaisVitBlockBwd {
     const float* rowscale_prev;      /* DropPath scale of the PREVIOUS block's MLP branch (applied to dx16_out), or NULL   */
 } SaisVitBlockBwd;
 int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBlockBwd* a, void* workspace, size_t ws_bytes, void* stream);
+
+/* One layer of the temporal encoder per call: the torch-1.8 POST-norm nn.TransformerEncoderLayer(d 384, 4 heads, FF 2048,
+ * ReLU, dropout 0.1, LayerNorm eps 1e-5) of prepare_model.py:74-81 as patched by README.md:43-48 (returns the attention map):
+ *   src = norm1(src + dropout1(out_proj(MHA(src))));  src = norm2(src + dropout2(linear2(dropout(relu(linear1(src)))))).
+ * 7 launches forward, 8 backward, sequenced by the library; fp32 tensors, linears on the bf16x3 path (sais_tgemm).
+ * Dropout: p_drop = 0 for eval(); sites site0 .. site0 + 3 = attention weights, dropout1, FFN dropout, dropout2.        */
+typedef struct SaisTemporalLayerParams {
+    const float* in_proj_w;  const float* in_proj_b;    /* [1152,384], [1152] */
+    const float* out_proj_w; const float* out_proj_b;   /* [384,384]          */
+    const float* linear1_w;  const float* linear1_b;    /* [2048,384]         */
+    const float* linear2_w;  const float* linear2_b;    /* [384,2048]         */
+    const float* norm1_g; const float* norm1_b; const float* norm2_g; const float* norm2_b;
+    /* backward only: fp32 transposed copies [in,out] and gradient accumulators */
+    const float* in_proj_wt; const float* out_proj_wt; const float* linear1_wt; const float* linear2_wt;
+    float* d_in_proj_w; float* d_in_proj_b; float* d_out_proj_w; float* d_out_proj_b; float* d_linear1_w; float* d_linear1_b;
+    float* d_linear2_w; float* d_linear2_b; float* d_norm1_g; float* d_norm1_b; float* d_norm2_g; float* d_norm2_b;
+} SaisTemporalLayerParams;
+
+typedef struct SaisTemporalLayerFwd {
+    int B, S;                            /* B sequences of S tokens: M = B * S rows; S <= 96                                */
+    const float* z;                      /* in : f32 [M,384]                                                               */
+    const unsigned char* key_pad;        /* in : u8 [B,S], 1 = masked key                                                  */
+    float* qkv; float* ctx;              /* out: f32 [M,1152], [M,384] (saved for backward)                                */
+    float* attn_avg;                     /* out, optional: f32 [B,S,S] head-averaged attention weights (the returned map)  */
+    float* y1;                           /* out, optional (saved): f32 [M,384] input of norm1                               */
+    float* z1; float* mean1; float* rstd1;   /* out: norm1 output (saved) and its statistics (optional)                     */
+    float* h;                            /* out: f32 [M,2048] drop(relu(linear1(z1))) (saved)                               */
+    float* y2;                           /* out, optional (saved): input of norm2                                           */
+    float* z_out; float* mean2; float* rstd2;
+    float p_drop; const unsigned long long* rng_state; unsigned site0;
+} SaisTemporalLayerFwd;
+int sais_temporal_layer_fwd(const SaisTemporalLayerParams* w, const SaisTemporalLayerFwd* a, void* workspace, size_t ws_bytes,
+                            void* stream);
+
+typedef struct SaisTemporalLayerBwd {
+    int B, S;
+    const float* z; const float* qkv; const float* ctx; const float* y1; const float* mean1; const float* rstd1;
+    const float* z1; const float* h; const float* y2; const float* mean2; const float* rstd2; const unsigned char* key_pad;
+    /* gradient wrt the layer OUTPUT = sum of nslab raw split-K slabs (slab_stride floats apart; the next layer's dx_slabs) +
+     * dz_add; either part may be NULL / 0                                                                                  */
+    const float* dz_slabs; int nslab; long slab_stride; const float* dz_add;
+    /* gradient wrt the layer INPUT, in the same two-part form: dx_slabs f32 [sais_tgemm_nsplit(M,384,1152)][M][384] (raw dX of
+     * in_proj) and dx_add f32 [M,384] (the residual path)                                                                  */
+    float* dx_slabs; float* dx_add;
+    float p_drop; const unsigned long long* rng_state; unsigned site0;
+} SaisTemporalLayerBwd;
+int sais_temporal_layer_bwd(const SaisTemporalLayerParams* w, const SaisTemporalLayerBwd* a, void* workspace, size_t ws_bytes,
+                            void* stream);
 
 /* ---------------------------------------------------------------- LayerNorm over dim = 384
  * nn.LayerNorm in Block / final norm (vision_transformer.py:99,103,107-113,212; eps 1e-6 from

@@ -70,7 +70,28 @@ class SaisVitBlockBwd(ctypes.Structure):
         "dx16_in", "dx16_out", "rowscale_attn", "rowscale_prev")]
 
 
-OP_VIT_BLOCK_FWD, OP_VIT_BLOCK_BWD = 0, 1
+class SaisTemporalLayerParams(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "linear1_w", "linear1_b", "linear2_w", "linear2_b", "norm1_g",
+        "norm1_b", "norm2_g", "norm2_b", "in_proj_wt", "out_proj_wt", "linear1_wt", "linear2_wt", "d_in_proj_w", "d_in_proj_b",
+        "d_out_proj_w", "d_out_proj_b", "d_linear1_w", "d_linear1_b", "d_linear2_w", "d_linear2_b", "d_norm1_g", "d_norm1_b",
+        "d_norm2_g", "d_norm2_b")]
+
+
+class SaisTemporalLayerFwd(ctypes.Structure):
+    _fields_ = [("B", c_int), ("S", c_int)] + [(n, c_void_p) for n in (
+        "z", "key_pad", "qkv", "ctx", "attn_avg", "y1", "z1", "mean1", "rstd1", "h", "y2", "z_out", "mean2", "rstd2")] + \
+        [("p_drop", c_float), ("rng_state", c_void_p), ("site0", ctypes.c_uint)]
+
+
+class SaisTemporalLayerBwd(ctypes.Structure):
+    _fields_ = [("B", c_int), ("S", c_int)] + [(n, c_void_p) for n in (
+        "z", "qkv", "ctx", "y1", "mean1", "rstd1", "z1", "h", "y2", "mean2", "rstd2", "key_pad", "dz_slabs")] + \
+        [("nslab", c_int), ("slab_stride", c_long), ("dz_add", c_void_p), ("dx_slabs", c_void_p), ("dx_add", c_void_p),
+         ("p_drop", c_float), ("rng_state", c_void_p), ("site0", ctypes.c_uint)]
+
+
+OP_VIT_BLOCK_FWD, OP_VIT_BLOCK_BWD, OP_TEMPORAL_LAYER_FWD, OP_TEMPORAL_LAYER_BWD = 0, 1, 2, 3
 
 
 class SaisOptChunk(ctypes.Structure):
@@ -107,6 +128,10 @@ SIGNATURES = {
                            c_void_p],
     "sais_vit_block_bwd": [ctypes.POINTER(SaisVitBlockParams), ctypes.POINTER(SaisVitBlockBwd), c_void_p, ctypes.c_size_t,
                            c_void_p],
+    "sais_temporal_layer_fwd": [ctypes.POINTER(SaisTemporalLayerParams), ctypes.POINTER(SaisTemporalLayerFwd), c_void_p,
+                                ctypes.c_size_t, c_void_p],
+    "sais_temporal_layer_bwd": [ctypes.POINTER(SaisTemporalLayerParams), ctypes.POINTER(SaisTemporalLayerBwd), c_void_p,
+                                ctypes.c_size_t, c_void_p],
     "sais_mlp_fwd": [ctypes.POINTER(SaisMlp), c_void_p],
     "sais_mlp_bwd": [ctypes.POINTER(SaisMlp), c_void_p],
     "sais_gemm_tn_f32": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],

@@ -36,6 +36,17 @@ extern "C" size_t sais_workspace_bytes(int op, int frames, int ntok) {
             return up(M * HID * 2);
         case SAIS_OP_VIT_BLOCK_BWD:                    // du, d(mid) bf16, d(attention out), dqkv, dxn (small-M regime)
             return up(M * HID * 2) + 3 * up(M * D * 2) + up(M * QKV * 2);
+        case SAIS_OP_TEMPORAL_LAYER_FWD: {             // raw split-K slabs of out_proj, then of linear2 (the larger)
+            const int m = frames * ntok;
+            const int ns = sais_tgemm_nsplit(m, D, 2048) > sais_tgemm_nsplit(m, D, D) ? sais_tgemm_nsplit(m, D, 2048)
+                                                                                       : sais_tgemm_nsplit(m, D, D);
+            return up((size_t)ns * M * D * 4);
+        }
+        case SAIS_OP_TEMPORAL_LAYER_BWD: {             // dy2, dt2, dy-drop1, dh, dqkv + the slabs of dh . W1 / dt1 . Wo
+            const int m = frames * ntok;
+            const size_t slabs = (size_t)(sais_tgemm_nsplit(m, D, 2048) + sais_tgemm_nsplit(m, D, D)) * M * D * 4;
+            return 3 * up(M * D * 4) + up(M * 2048 * 4) + up(M * QKV * 4) + up(slabs);
+        }
         default:
             return 0;
     }
@@ -159,5 +170,99 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
         TRY(sais_layernorm_bwd(dxn, D, nullptr, 0, a->x_in, D, a->mean1, a->rstd1, w->norm1_g, a->dx, D, M, D, a->dx, D,
                                a->dx16_out, D, w->d_norm1_g, w->d_norm1_b, a->rowscale_prev, nullptr, 0.f, nullptr, 0, stream));
     }
+    return SAIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- temporal encoder layer
+namespace {
+constexpr int FF = 2048;
+
+int tg(const float* A, const float* W, int M, int N, int K, int epi, int nsplit, const float* bias, const float* aux, float* out,
+       float p, const unsigned long long* rng, unsigned site, void* stream) {
+    SaisTGemm g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.epilogue = epi; g.nsplit = nsplit; g.bias = bias;
+    g.aux = aux; g.ldaux = N; g.out = out; g.ldo = N; g.p_drop = p; g.rng_state = rng; g.site = site;
+    return sais_tgemm(&g, stream);
+}
+}  // namespace
+
+extern "C" int sais_temporal_layer_fwd(const SaisTemporalLayerParams* w, const SaisTemporalLayerFwd* a, void* workspace,
+                                       size_t ws_bytes, void* stream) {
+    SAIS_ENTER();
+    if (!w || !a || a->B <= 0 || a->S <= 0 || !a->z || !a->key_pad || !a->qkv || !a->ctx || !a->z1 || !a->h || !a->z_out)
+        return SAIS_ERR_ARG;
+    if (!w->in_proj_w || !w->out_proj_w || !w->linear1_w || !w->linear2_w || !w->norm1_g || !w->norm1_b || !w->norm2_g || !w->norm2_b)
+        return SAIS_ERR_ARG;
+    if (a->p_drop < 0.f || a->p_drop >= 1.f || (a->p_drop > 0.f && !a->rng_state)) return SAIS_ERR_ARG;
+    if (!workspace || ws_bytes < sais_workspace_bytes(SAIS_OP_TEMPORAL_LAYER_FWD, a->B, a->S) || ((uintptr_t)workspace & 15))
+        return SAIS_ERR_ARG;
+    const int M = a->B * a->S;
+    float* slabs = (float*)workspace;
+    const float p = a->p_drop;
+    const unsigned long long* rng = p > 0.f ? a->rng_state : nullptr;
+    // self-attention: in_proj -> per (sequence, head) softmax(q k^T / sqrt(96)) v with key-padding mask -> out_proj
+    TRY(tg(a->z, w->in_proj_w, M, QKV, D, SAIS_TG_BIAS, 1, w->in_proj_b, nullptr, a->qkv, 0.f, nullptr, 0, stream));
+    TRY(sais_temporal_attn_fwd(a->qkv, a->key_pad, a->B, a->S, a->ctx, a->attn_avg, p, rng, a->site0, stream));
+    int ns = sais_tgemm_nsplit(M, D, D);
+    TRY(tg(a->ctx, w->out_proj_w, M, D, D, SAIS_TG_RAW, ns, nullptr, nullptr, slabs, 0.f, nullptr, 0, stream));
+    TRY(sais_temporal_ln_fwd(slabs, ns, (long)M * D, w->out_proj_b, a->z, M, p, rng, a->site0 + 1, a->y1, w->norm1_g, w->norm1_b,
+                             1e-5f, a->z1, a->mean1, a->rstd1, stream));
+    // feed-forward
+    TRY(tg(a->z1, w->linear1_w, M, FF, D, SAIS_TG_BIAS_RELU, 1, w->linear1_b, nullptr, a->h, p, rng, a->site0 + 2, stream));
+    ns = sais_tgemm_nsplit(M, D, FF);
+    TRY(tg(a->h, w->linear2_w, M, D, FF, SAIS_TG_RAW, ns, nullptr, nullptr, slabs, 0.f, nullptr, 0, stream));
+    TRY(sais_temporal_ln_fwd(slabs, ns, (long)M * D, w->linear2_b, a->z1, M, p, rng, a->site0 + 3, a->y2, w->norm2_g, w->norm2_b,
+                             1e-5f, a->z_out, a->mean2, a->rstd2, stream));
+    return SAIS_OK;
+}
+
+extern "C" int sais_temporal_layer_bwd(const SaisTemporalLayerParams* w, const SaisTemporalLayerBwd* a, void* workspace,
+                                       size_t ws_bytes, void* stream) {
+    SAIS_ENTER();
+    if (!w || !a || a->B <= 0 || a->S <= 0) return SAIS_ERR_ARG;
+    if (!a->z || !a->qkv || !a->ctx || !a->y1 || !a->mean1 || !a->rstd1 || !a->z1 || !a->h || !a->y2 || !a->mean2 || !a->rstd2 ||
+        !a->key_pad || (!a->dz_slabs && !a->dz_add) || !a->dx_slabs || !a->dx_add)
+        return SAIS_ERR_ARG;
+    if (!w->in_proj_wt || !w->out_proj_wt || !w->linear1_wt || !w->linear2_wt || !w->norm1_g || !w->norm2_g || !w->d_in_proj_w ||
+        !w->d_out_proj_w || !w->d_linear1_w || !w->d_linear2_w || !w->d_norm1_g || !w->d_norm1_b || !w->d_norm2_g || !w->d_norm2_b)
+        return SAIS_ERR_ARG;
+    if (a->p_drop < 0.f || a->p_drop >= 1.f || (a->p_drop > 0.f && !a->rng_state)) return SAIS_ERR_ARG;
+    if (!workspace || ws_bytes < sais_workspace_bytes(SAIS_OP_TEMPORAL_LAYER_BWD, a->B, a->S) || ((uintptr_t)workspace & 15))
+        return SAIS_ERR_ARG;
+    const int M = a->B * a->S;
+    const float p = a->p_drop;
+    const unsigned long long* rng = p > 0.f ? a->rng_state : nullptr;
+    char* ws = (char*)workspace;
+    float* dy2 = (float*)ws;   ws += up((size_t)M * D * 4);
+    float* dt2 = (float*)ws;   ws += up((size_t)M * D * 4);          // dropout2's backward of dy2 (p = 0: dy2 itself is used)
+    float* dt1 = (float*)ws;   ws += up((size_t)M * D * 4);
+    float* dh = (float*)ws;    ws += up((size_t)M * FF * 4);
+    float* dqkv = (float*)ws;  ws += up((size_t)M * QKV * 4);
+    float* slab1 = (float*)ws;                                        // dh . W1   [ns1][M][384]
+    const int ns1 = sais_tgemm_nsplit(M, D, FF), nso = sais_tgemm_nsplit(M, D, D), nsq = sais_tgemm_nsplit(M, D, QKV);
+    float* slabo = slab1 + (size_t)ns1 * M * D;                       // dt1 . Wo  [nso][M][384]
+    // norm2 backward (the gradient of the layer output arrives as slabs + add), dropout2 backward as a second output
+    float* g2 = p > 0.f ? dt2 : dy2;
+    TRY(sais_temporal_ln_bwd(a->dz_slabs, a->dz_slabs ? a->nslab : 0, a->slab_stride, a->dz_add, a->y2, a->mean2, a->rstd2,
+                             w->norm2_g, M, dy2, p > 0.f ? dt2 : nullptr, p, rng, a->site0 + 3, w->d_norm2_g, w->d_norm2_b, stream));
+    // FFN: dh = drop'(relu'(.)) (g2 . W2);  d(norm1 out) = dh . W1 + dy2 (residual): left as slabs + add for norm1's backward
+    TRY(tg(g2, w->linear2_wt, M, FF, D, SAIS_TG_DRELU, 1, nullptr, a->h, dh, p, rng, a->site0 + 2, stream));
+    TRY(tg(dh, w->linear1_wt, M, D, FF, SAIS_TG_RAW, ns1, nullptr, nullptr, slab1, 0.f, nullptr, 0, stream));
+    float* g1 = p > 0.f ? dt1 : a->dx_add;
+    TRY(sais_temporal_ln_bwd(slab1, ns1, (long)M * D, dy2, a->y1, a->mean1, a->rstd1, w->norm1_g, M, a->dx_add,
+                             p > 0.f ? dt1 : nullptr, p, rng, a->site0 + 1, w->d_norm1_g, w->d_norm1_b, stream));
+    // attention: d ctx = g1 . Wo (raw slabs, summed on load by the attention backward)
+    TRY(tg(g1, w->out_proj_wt, M, D, D, SAIS_TG_RAW, nso, nullptr, nullptr, slabo, 0.f, nullptr, 0, stream));
+    TRY(sais_temporal_attn_bwd(a->qkv, a->key_pad, a->B, a->S, slabo, nso, (long)M * D, dqkv, p, rng, a->site0, stream));
+    // the four weight / bias gradients of the layer in one launch (one M-split: owner-computes, no atomics)
+    SaisTnItem items[4] = {
+        {g2, D, a->h, FF, D, FF, w->d_linear2_w, FF, w->d_linear2_b},
+        {dh, FF, a->z1, D, FF, D, w->d_linear1_w, D, w->d_linear1_b},
+        {g1, D, a->ctx, D, D, D, w->d_out_proj_w, D, w->d_out_proj_b},
+        {dqkv, QKV, a->z, D, QKV, D, w->d_in_proj_w, D, w->d_in_proj_b}};
+    TRY(sais_gemm_tn_grouped_f32(items, 4, M, 1, stream));
+    // gradient wrt the layer input = dx_add (residual path, written by norm1's backward) + dqkv . Win (raw slabs)
+    TRY(tg(dqkv, w->in_proj_wt, M, D, QKV, SAIS_TG_RAW, nsq, nullptr, nullptr, a->dx_slabs, 0.f, nullptr, 0, stream));
     return SAIS_OK;
 }

@@ -358,6 +358,43 @@ def vit_block_bwd(P, frames, ntok, s, dx, dx16_in, dx16_out, rs_attn, rs_prev, l
     L.call("sais_vit_block_bwd", ctypes.byref(P), ctypes.byref(a), _p(ws), ws.numel(), _stream())
 
 
+def temporal_layer_params(f, prefix):
+    """SaisTemporalLayerParams of the encoder layer whose parameter names start with `prefix` (FlatParams engine)."""
+    P = L.SaisTemporalLayerParams()
+    for k, name in (("in_proj", "self_attn.in_proj_"), ("out_proj", "self_attn.out_proj."), ("linear1", "linear1."),
+                    ("linear2", "linear2.")):
+        setattr(P, k + "_w", _p(f.w32(prefix + name + "weight")))
+        setattr(P, k + "_b", _p(f.w32(prefix + name + "bias")))
+        setattr(P, k + "_wt", _p(f.wt16.get(prefix + name + "weight")))
+        setattr(P, "d_" + k + "_w", _p(f.g(prefix + name + "weight")))
+        setattr(P, "d_" + k + "_b", _p(f.g(prefix + name + "bias")))
+    for k in ("norm1", "norm2"):
+        setattr(P, k + "_g", _p(f.w32(prefix + k + ".weight")))
+        setattr(P, k + "_b", _p(f.w32(prefix + k + ".bias")))
+        setattr(P, "d_" + k + "_g", _p(f.g(prefix + k + ".weight")))
+        setattr(P, "d_" + k + "_b", _p(f.g(prefix + k + ".bias")))
+    return P
+
+
+def temporal_layer_fwd(P, B, S, z, pad, qkv, ctx, attn, y1, z1, m1, r1, h, y2, zo, m2, r2, drop, site0, ws):
+    """One post-norm TransformerEncoderLayer forward as ONE C call (sais_temporal_layer_fwd).  drop = (p, rng) or None."""
+    pd, rng = drop if drop is not None else (0.0, None)
+    a = L.SaisTemporalLayerFwd(B, S, _p(z), _p(pad), _p(qkv), _p(ctx), _p(attn), _p(y1), _p(z1), _p(m1), _p(r1), _p(h), _p(y2),
+                               _p(zo), _p(m2), _p(r2), float(pd), _p(rng), int(site0))
+    L.call("sais_temporal_layer_fwd", ctypes.byref(P), ctypes.byref(a), _p(ws), ws.numel(), _stream())
+
+
+def temporal_layer_bwd(P, B, S, a, pad, slabs, add, dx_slabs, dx_add, drop, site0, ws):
+    """One encoder layer backward as ONE C call (sais_temporal_layer_bwd); a = the tensors the forward saved; the gradient of
+    the layer output comes as raw slabs + add and the gradient of its input leaves the same way (dx_slabs, dx_add)."""
+    pd, rng = drop if drop is not None else (0.0, None)
+    g = L.SaisTemporalLayerBwd(B, S, _p(a["z"]), _p(a["qkv"]), _p(a["ctx"]), _p(a["y1"]), _p(a["m1"]), _p(a["r1"]), _p(a["z1"]),
+                               _p(a["h"]), _p(a["y2"]), _p(a["m2"]), _p(a["r2"]), _p(pad), _p(slabs),
+                               0 if slabs is None else slabs.shape[0], 0 if slabs is None else slabs.stride(0), _p(add),
+                               _p(dx_slabs), _p(dx_add), float(pd), _p(rng), int(site0))
+    L.call("sais_temporal_layer_bwd", ctypes.byref(P), ctypes.byref(g), _p(ws), ws.numel(), _stream())
+
+
 def vit_attn_cls_fwd(qkv, frames, out_c, ntok=197):
     """The last block's attention for the CLS query only: out_c bf16 [frames, 384] (include/sais_hip.h)."""
     _chk(qkv, BF16, "qkv"); _chk(out_c, BF16, "out")

@@ -31,6 +31,7 @@ from .flat import FlatParams
 
 import os as _os
 
+_LAYER_CALLS = _os.environ.get('SAIS_TEMPORAL_LAYER_CALLS', '1') != '0'      # one C call per encoder layer and direction
 _PREFETCH = _os.environ.get('SAIS_TEMPORAL_PREFETCH', '0') == '1'        # measured: no net gain (LABNOTES R4.3): off
 D, TH, FF, EMB, NPOS = 384, 4, 2048, 256, 2000
 
@@ -307,9 +308,20 @@ class fullModel(nn.Module):
             p = self._lnames(l, enc)
             last = l == self.nlayers - 1
             qkv, ctx = e32(M, 3 * D), e32(M, D)
-            ops.tgemm(z, fl.w32(p + "self_attn.in_proj_weight"), L.TG_BIAS, qkv, bias=fl.w32(p + "self_attn.in_proj_bias"))
             if want_attn and last:
                 attn = e32(B, S, S)
+            if _LAYER_CALLS and ops.TIMER is None:       # one C call per layer (sais_temporal_layer_fwd: the launches below)
+                y1, y2 = (e32(M, D), e32(M, D)) if save else (None, None)
+                z1, zo, h = e32(M, D), e32(M, D), e32(M, FF)
+                m1, r1, m2, r2 = (e32(M), e32(M), e32(M), e32(M)) if save else (None, None, None, None)
+                ops.temporal_layer_fwd(self._layer_params(p), B, S, z, pad, qkv, ctx, attn if last else None, y1, z1, m1, r1, h,
+                                       y2, zo, m2, r2, drop, (sidx * self.nlayers + l) * 4,
+                                       self._ws(L.OP_TEMPORAL_LAYER_FWD, B, S, dev))
+                if save:
+                    layers.append(dict(z=z, qkv=qkv, ctx=ctx, y1=y1, m1=m1, r1=r1, z1=z1, h=h, y2=y2, m2=m2, r2=r2))
+                z = zo
+                continue
+            ops.tgemm(z, fl.w32(p + "self_attn.in_proj_weight"), L.TG_BIAS, qkv, bias=fl.w32(p + "self_attn.in_proj_bias"))
             # train mode: dropout sites 0-3 of this layer (attention weights, dropout1, dropout, dropout2)
             site = (sidx * self.nlayers + l) * 4
             pd, rng = drop if drop is not None else (0.0, None)
@@ -333,6 +345,26 @@ class fullModel(nn.Module):
                 layers.append(dict(z=z, qkv=qkv, ctx=ctx, y1=y1, m1=m1, r1=r1, z1=z1, h=h, y2=y2, m2=m2, r2=r2))
             z = zo
         return z, attn, layers
+
+    def _layer_params(self, prefix):
+        """ctypes parameter block of one encoder layer (pointers into the flat buffers), rebuilt when those are."""
+        f = self.flat
+        key = (f.flat.data_ptr(), f.grad.data_ptr(), 0 if f.wt_buf is None else f.wt_buf.data_ptr())
+        if getattr(self, "_lp_key", None) != key:
+            self._lp_key, self._lp = key, {}
+        if prefix not in self._lp:
+            self._lp[prefix] = ops.temporal_layer_params(f, prefix)
+        return self._lp[prefix]
+
+    def _ws(self, op, B, S, dev):
+        if torch.cuda.is_current_stream_capturing():
+            return ops.block_workspace(op, B, S, dev)
+        key = (op, B, S, str(dev))
+        if not hasattr(self, "_wsbuf"):
+            self._wsbuf = {}
+        if key not in self._wsbuf:
+            self._wsbuf[key] = ops.block_workspace(op, B, S, dev)
+        return self._wsbuf[key]
 
     def _prefetch(self, backward):
         """The encoder's ~70 launches per step are a few microseconds each; their weights (35 MB fp32 forward, the same
@@ -407,6 +439,13 @@ class fullModel(nn.Module):
             site = (s.get("sidx", 0) * self.nlayers + l) * 4
             pd, rng = drop if drop is not None else (0.0, None)
             dsite = (lambda k: None if drop is None else (pd, rng, site + k))
+            if _LAYER_CALLS and ops.TIMER is None:       # one C call per layer (sais_temporal_layer_bwd)
+                ns = L.load().sais_tgemm_nsplit(M, D, 3 * D)
+                dx_slabs, dy1 = e32(ns, M, D), e32(M, D)
+                ops.temporal_layer_bwd(self._layer_params(p), B, S, a, s["pad"], slabs, add, dx_slabs, dy1, drop, site,
+                                       self._ws(L.OP_TEMPORAL_LAYER_BWD, B, S, dev))
+                slabs, add = dx_slabs, dy1
+                continue
             dy2 = e32(M, D)
             dt2 = dy2 if drop is None else e32(M, D)
             ops.temporal_ln_bwd(slabs, add, a["y2"], a["m2"], a["r2"], fl.w32(p + "norm2.weight"), dy2,

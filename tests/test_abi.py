@@ -62,6 +62,11 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_FWD, 256, 197) >= M * 1536 * 2
     assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_BWD, 256, 197) >= M * (1536 + 3 * 384 + 1152) * 2
     assert lib.sais_workspace_bytes(99, 256, 197) == 0
+    assert lib.sais_workspace_bytes(_lib.OP_TEMPORAL_LAYER_FWD, 8, 33) >= 8 * 264 * 384 * 4
+    assert lib.sais_workspace_bytes(_lib.OP_TEMPORAL_LAYER_BWD, 8, 33) >= 264 * (3 * 384 + 2048 + 1152) * 4
+    assert lib.sais_temporal_layer_fwd(None, None, None, 0, None) == -1
+    assert lib.sais_temporal_layer_bwd(ctypes.byref(_lib.SaisTemporalLayerParams()), ctypes.byref(_lib.SaisTemporalLayerBwd()),
+                                       None, 0, None) == -1
     assert lib.sais_vit_attn_cls_fwd(None, 1152, 1, 197, None, 384, None) == -1
     assert lib.sais_vit_attn_cls_bwd(ctypes.c_void_p(16), 1152, ctypes.c_void_p(16), 384, 1, 500, ctypes.c_void_p(16), 1152, None) == -1
     assert lib.sais_splitk_finish(None, 2, 4, 384, 384, None, None, None, 0, None, 0, None, 0, None) == -1

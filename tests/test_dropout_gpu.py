@@ -182,6 +182,42 @@ def test_graph_replays_draw_fresh_masks_and_match_eager(ops):
     assert rel_l2(m.flat.grad, g_graph) <= 1e-5
 
 
+@pytest.mark.parametrize("train", [True, False])
+def test_layer_level_c_calls_equal_the_per_launch_sequence(ops, train):
+    """sais_temporal_layer_fwd / _bwd (one C call per encoder layer: SURVEY 8b) vs the per-launch Python sequence: the same
+    launches in the same order — embeddings and loss bit-identical, the head-averaged attention map up to the order of its four
+    atomic head additions, gradients equal (the layer's dW launch is owner-computes), in train mode with dropout (same Philox
+    state) and in eval()."""
+    import sais_amd.temporal as TM
+    from sais_amd.loss import calcNCELoss
+    lens, T = [9, 4, 7, 9], 9
+    x, f, pad = _inputs(lens, T)
+    lab = synth.labels(seed=912, B=4)
+
+    def run(layer_calls):
+        old = TM._LAYER_CALLS
+        TM._LAYER_CALLS = layer_calls
+        try:
+            m = _model("RGB-Flow")
+            m = m.train() if train else m.eval()
+            m.dropout_seed = 31
+            xg, fg = x.to(DEV).requires_grad_(True), f.to(DEV).requires_grad_(True)
+            protos = torch.nn.ParameterDict({k: torch.nn.Parameter(v.clone().to(DEV)) for k, v in synth.prototypes(2, 2).items()})
+            emb, attn = m(xg, fg, lens, lens, 'Prototypes', pad.to(DEV), pad.to(DEV), None)
+            loss = calcNCELoss(0, emb, lab, [f"v{b}" for b in range(4)], protos, None)
+            loss.backward()
+            return emb.detach(), attn.detach(), float(loss), m.flat.grad.clone(), xg.grad.clone(), fg.grad.clone()
+        finally:
+            TM._LAYER_CALLS = old
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) and a[2] == b[2]
+    assert float((a[1] - b[1]).abs().max()) <= 1e-6
+    assert float(b[3].abs().max()) > 0
+    for u, v in zip(a[3:], b[3:]):
+        assert float((u - v).norm() / v.norm()) <= 1e-6
+
+
 # ------------------------------------------------------------------ DropPath (stochastic depth) of the ViT blocks
 def _vit(depth, rate):
     from sais_amd.vit import vit_small
