@@ -279,7 +279,10 @@ def gemm_tn_grouped(items, M, nsplit=None):
         nbytes += 2 * M * (N1 + N2) + 4 * N1 * N2
     if nsplit is None:
         nsplit = max(1, min((M + 255) // 256, (432 + tiles - 1) // tiles))
-    _timed("gemm_tn_grouped_f32" if f32 else "gemm_tn_grouped", flops, nbytes,
+    # one tag per distinct launch shape: the full four-GEMM dW of a block, the last block's qkv-only and compact launches and
+    # the temporal layers' are different kernels in all but name, and a pooled average would describe none of them
+    tag = ("gemm_tn_grouped_f32" if f32 else "gemm_tn_grouped") + ("" if f32 else f"[{len(items)} GEMMs,M{M}]")
+    _timed(tag, flops, nbytes,
            lambda: L.call("sais_gemm_tn_grouped_f32" if f32 else "sais_gemm_tn_grouped", arr, len(items), M, nsplit, _stream()))
 
 

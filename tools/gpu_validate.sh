@@ -19,9 +19,9 @@ SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-n
 SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 \
     bench.py --workload dino --gpus 1 --steps 10 --warmup 3 > $O/force_dist_world1_dino.log 2>&1; tail -c 1200 $O/force_dist_world1_dino.log | head -c 400; echo
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --parity-clips 0 > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dino -- python3 $R/bench.py --workload dino --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_dino.log 2>&1
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --sustain-seconds 0"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --sustain-seconds 0 --parity-clips 0"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
           SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1

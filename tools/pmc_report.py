@@ -29,8 +29,9 @@ ROW_NAMES = {0: "gemm_nt<bias_bf16>(row)", 1: "gemm_nt<resid_f32>(row)", 2: "gem
 
 # the row kernel runs two shapes per family and the name does not carry K: dispatches of a family follow the training
 # step's launch order (vit.py), so K is read off the position inside the step
-ROW_K_PATTERN = {"gemm_ln_fwd": [384, 1536] * 11 + [384],          # proj + norm2, fc2 + next norm1 (the last fc2 is plain)
-                 "gemm_ln_bwd": [1536, 1152] * 12}                 # dX fc1 + norm2', dX qkv + norm1'
+# (round 4: the last block runs on the CLS rows only — no row-kernel launches forward, only dX qkv + norm1' backward)
+ROW_K_PATTERN = {"gemm_ln_fwd": [384, 1536] * 11,                  # proj + norm2, fc2 + next norm1 of blocks 0..10
+                 "gemm_ln_bwd": [1152] + [1536, 1152] * 11}        # block 11: dX qkv + norm1'; then dX fc1 + norm2', dX qkv + norm1'
 
 
 def timer_name(kernel):
@@ -40,7 +41,8 @@ def timer_name(kernel):
     m = re.search(r"gemm_nt(?:_w8p)?_kernel<(\d+)>|gemm_nt(?:_w8p)?_kernelILi(\d+)E", kernel)
     if m:
         return "gemm_nt<%s>" % NT_NAMES[int(m.group(1) or m.group(2))]
-    for key, name in (("gemm_tn_pp_kernel", "gemm_tn_grouped"), ("gemm_tn_wide_kernel", "gemm_tn_grouped"), ("gemm_tn_grouped_kernel", "gemm_tn_grouped"),
+    for key, name in (("gemm_tn_pp_kernel", "gemm_tn_grouped"), ("gemm_tn_wide_kernel", "gemm_tn_grouped"), ("gemm_tn_grouped_kernel", "gemm_tn_grouped[compact]"),
+                      ("attn_cls_fwd_kernel", "vit_attn_cls_fwd"), ("attn_cls_bwd_kernel", "vit_attn_cls_bwd"),
                       ("attn_fwd_kernel", "vit_attn_fwd"), ("attn_bwd_dq_kernel", "vit_attn_bwd_dq"),
                       ("attn_bwd_dkv_kernel", "vit_attn_bwd_dkv"), ("attn_bwd_kernel", "vit_attn_bwd"),
                       ("tln_fwd_kernel", "temporal_ln_fwd"), ("tln_bwd_kernel", "temporal_ln_bwd"), ("tgemm_kernel", "tgemm"),
@@ -66,6 +68,11 @@ def collect(folder):
                 ordinal = seen[n].setdefault(r["Dispatch_Id"], len(seen[n]))
                 pat = ROW_K_PATTERN[n]
                 n = "%s[K%d]" % (n, pat[ordinal % len(pat)])
+            elif n == "gemm_tn_grouped":
+                # per step: the last block's qkv-only launch first, then the four-GEMM launch of blocks 10..0 (round 4)
+                ordinal = seen[n].setdefault(r["Dispatch_Id"], len(seen[n]))
+                if ordinal % 12 == 0:
+                    n = "gemm_tn_grouped[qkv only]"
             agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
@@ -102,7 +109,7 @@ def main():
                  "note": "separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled (gfx950 correction)"}
     # whole-step HBM bytes by counters: launches per step x bytes per launch over every family that was matched (steps in
     # the profiled run = dW launches / 12 blocks)
-    nsteps = max(1, len(fetch.get("gemm_tn_grouped", {}).get("FETCH_SIZE", [])) // 12)
+    nsteps = max(1, len(fetch.get("gemm_tn_grouped", {}).get("FETCH_SIZE", [])) // 11)
     per_step = {n: round(v["launches_sampled"] / nsteps, 2) for n, v in tr.items()}
     step_bytes = sum(tr[n]["hbm_bytes_per_launch"] * per_step[n] for n in tr)
     tr["_step"] = {"step_hbm_bytes": int(step_bytes), "steps_profiled": nsteps, "launches_per_step": per_step,
