@@ -215,7 +215,7 @@ def cpu_baseline(T, C, threads, weights):
             "config1_B1_T16_1layer_fwd": (1, 16, 1, False, 2.0, 5),
             "config1_B1_T16_1layer_fwd_bwd": (1, 16, 1, True, 3.0, 5),
             f"config2_B1_T{T}_fwd": (1, T, 4, False, 3.0, 5),
-            f"config2_B8_T{T}_fwd_bwd_sgd": (8, T, 4, True, 1.0, 1)}.items():
+            f"config2_B8_T{T}_fwd_bwd_sgd": (8, T, 4, True, 25.0, 2)}.items():
         v, n = leg(B, Tn, nl, train, budget, mx)
         variants[name] = {"frames_per_s": v, "timed_steps": n}
     return dict(value=main, unit="frames/s", cores=threads, kind="port", cpu=cpu_model_name(),
