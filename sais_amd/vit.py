@@ -596,9 +596,9 @@ class VisionTransformer(nn.Module):
                 dpos = torch.zeros(ntok, D, dtype=torch.float32, device=dev)
                 ops.vit_embed_bwd(dxg, Fr, f.g("cls_token"), dpos, dpg, ntok=ntok)
                 ops.pos_interp_bwd(g["interp"], dpos, f.g("pos_embed").view(NTOK, D))
-        # one-item grouped call: at M >= 8192 it takes the ping-pong 128 x 384 dW kernel (about half the plain kernel's time)
-        ops.gemm_tn_grouped([(dpatch, saved["patches"], f.g("patch_embed.proj.weight").view(D, PATCH_K),
-                              f.g("patch_embed.proj.bias"))], dpatch.shape[0])
+        # (the ping-pong 128 x 384 dW kernel is no better here: 6 wide tiles x 42 row splits, 77 us against 65-68 us)
+        ops.gemm_tn(dpatch, saved["patches"], f.g("patch_embed.proj.weight").view(D, PATCH_K),
+                    f.g("patch_embed.proj.bias"))
         if self.grad_ready_hook:
             self.grad_ready_hook(0, f.offsets["blocks.0.norm1.weight"])
 

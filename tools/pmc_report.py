@@ -69,13 +69,10 @@ def collect(folder):
                 pat = ROW_K_PATTERN[n]
                 n = "%s[K%d]" % (n, pat[ordinal % len(pat)])
             elif n == "gemm_tn_grouped":
-                # per step: the last block's qkv-only launch first, then the four-GEMM launch of blocks 10..0, then the
-                # patch embedding's dW (round 4)
+                # per step: the last block's qkv-only launch first, then the four-GEMM launch of blocks 10..0 (round 4)
                 ordinal = seen[n].setdefault(r["Dispatch_Id"], len(seen[n]))
-                if ordinal % 13 == 0:
+                if ordinal % 12 == 0:
                     n = "gemm_tn_grouped[qkv only]"
-                elif ordinal % 13 == 12:
-                    n = "gemm_tn_grouped[patch embed]"
             agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
