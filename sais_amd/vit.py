@@ -286,7 +286,7 @@ class VisionTransformer(nn.Module):
         xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
         xn2 = e16(M, D)
         mean1 = rstd1 = None
-        prune = self.prune_last_block and len(groups) == 1 and not want_last_attn
+        prune = self.prune_last_block and not want_last_attn
         blockcall = self.block_calls and ops.TIMER is None and len(groups) == 1 and fused
         for i in range(self.depth):
             p = f"blocks.{i}."
@@ -305,7 +305,7 @@ class VisionTransformer(nn.Module):
             if not use_block:
                 ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
             if prune and i == self.depth - 1:
-                reps, tail = self._cls_tail_fwd(f, i, x, xn, mean1, rstd1, qkv, groups[0], dp, save, e16, e32)
+                reps, tail = self._cls_tail_fwd(f, i, x, xn, mean1, rstd1, qkv, groups, dp, save, e16, e32)
                 if save:
                     saved["blocks"].append(tail)
                     saved.update(x_final=tail["x_out"], meanN=tail["meanN"], rstdN=tail["rstdN"], pruned=True)
@@ -416,32 +416,36 @@ class VisionTransformer(nn.Module):
             self._wsbuf[key] = ops.block_workspace(op, grp["Fr"], grp["ntok"], dev)
         return self._wsbuf[key]
 
-    def _cls_tail_fwd(self, f, i, x, xn1, mean1, rstd1, qkv, grp, dp, save, e16, e32):
+    def _cls_tail_fwd(self, f, i, x, xn1, mean1, rstd1, qkv, groups, dp, save, e16, e32):
         """The last block from its qkv on, restricted to what forward() returns (the CLS rows): attention for the CLS query
-        (sais_vit_attn_cls_fwd), then proj + residual, norm2, fc1 + GELU, fc2 + residual and the final norm on [frames, 384]
-        tensors.  The residual input is the strided view x[::ntok]."""
-        Fr, ntok = grp["Fr"], grp["ntok"]
+        (sais_vit_attn_cls_fwd, one launch per resolution group), then proj + residual, norm2, fc1 + GELU, fc2 + residual and
+        the final norm on [frames, 384] tensors (all groups together).  The residual input is the strided view x[::ntok]."""
         p = f"blocks.{i}."
-        ao = e16(Fr, D)
-        ops.vit_attn_cls_fwd(qkv, Fr, ao, ntok)
-        x_cls = x.view(Fr, ntok, D)[:, 0]
-        rs_attn = None if dp is None else dp[2 * i].view(Fr, ntok)[:, 0].contiguous()
-        rs_mlp = None if dp is None else dp[2 * i + 1].view(Fr, ntok)[:, 0].contiguous()
-        x_mid, xn2, x_out = e32(Fr, D), e16(Fr, D), e32(Fr, D)
-        mean2, rstd2 = (e32(Fr), e32(Fr)) if save else (None, None)
+        Ftot = sum(g["Fr"] for g in groups)
+        ao = e16(Ftot, D)
+        for g in groups:
+            Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
+            ops.vit_attn_cls_fwd(qkv[lo:lo + Fr * ntok], Fr, ao[fo:fo + Fr], ntok)
+        cls_rows = lambda t, w: [t[g["off"]:g["off"] + g["Fr"] * g["ntok"]].view(g["Fr"], g["ntok"], *w)[:, 0] for g in groups]
+        one = len(groups) == 1
+        x_cls = cls_rows(x, (D,))[0] if one else torch.cat(cls_rows(x, (D,)))
+        rs_attn = None if dp is None else torch.cat(cls_rows(dp[2 * i], ())).contiguous()
+        rs_mlp = None if dp is None else torch.cat(cls_rows(dp[2 * i + 1], ())).contiguous()
+        x_mid, xn2, x_out = e32(Ftot, D), e16(Ftot, D), e32(Ftot, D)
+        mean2, rstd2 = (e32(Ftot), e32(Ftot)) if save else (None, None)
         # [frames, 384] outputs: 6 tiles of 128 x 128 — the K loop is cut over workgroups (deterministic split-K)
         ops.gemm_nt_splitk(ao, f.w(p + "attn.proj.weight"), 6, bias=f.w32(p + "attn.proj.bias"), rowscale=rs_attn, aux=x_cls,
                            out32=x_mid)
-        ops.layernorm_fwd(x_mid, Fr, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2, mean=mean2,
+        ops.layernorm_fwd(x_mid, Ftot, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2, mean=mean2,
                           rstd=rstd2)
-        h, u = e16(Fr, HID), (e16(Fr, HID) if save else None)
+        h, u = e16(Ftot, HID), (e16(Ftot, HID) if save else None)
         ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
                     bias=f.w32(p + "mlp.fc1.bias"), out2=u)
         ops.gemm_nt_splitk(h, f.w(p + "mlp.fc2.weight"), 12, bias=f.w32(p + "mlp.fc2.bias"), rowscale=rs_mlp, aux=x_mid,
                            out32=x_out)
-        reps = e32(Fr, D)
-        meanN, rstdN = (e32(Fr), e32(Fr)) if save else (None, None)
-        ops.layernorm_fwd(x_out, Fr, D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN, rstd=rstdN)
+        reps = e32(Ftot, D)
+        meanN, rstdN = (e32(Ftot), e32(Ftot)) if save else (None, None)
+        ops.layernorm_fwd(x_out, Ftot, D, f.w32("norm.weight"), f.w32("norm.bias"), 1e-6, y32=reps, mean=meanN, rstd=rstdN)
         tail = dict(cls=True, x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn1, qkv=qkv, ao=ao, x_mid=x_mid, mean2=mean2, rstd2=rstd2,
                     xn2=xn2, dgelu=u, h=h, rs_attn=rs_attn, rs_mlp=rs_mlp, x_out=x_out, meanN=meanN, rstdN=rstdN) if save else None
         return reps, tail
@@ -450,44 +454,53 @@ class VisionTransformer(nn.Module):
         """Backward of _cls_tail_fwd: the gradient enters on the CLS rows only.  Everything row-local stays on [frames, 384]
         tensors; the attention backward (sais_vit_attn_cls_bwd) writes the whole dqkv (dk, dv of every token, dq of the CLS
         rows, zeros elsewhere); the dX of qkv + norm1's backward then writes EVERY row of dx / dxa, taking the residual-stream
-        gradient from the compact CLS tensor (dres_period) — no zero-filled [M, 384] buffer, no full-size cast."""
+        gradient from the compact CLS tensor (dres_period) — no zero-filled [M, 384] buffer, no full-size cast.  With several
+        resolution groups the two token-count-dependent launches run once per group on its rows."""
         i = self.depth - 1
         p = f"blocks.{i}."
         s = saved["blocks"][i]
-        grp = saved["groups"][0]
-        Fr, ntok, M = grp["Fr"], grp["ntok"], saved["M"]
+        groups, M = saved["groups"], saved["M"]
+        Ftot = sum(g["Fr"] for g in groups)
         dev = dreps.device
         e16 = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=dev)
-        dx_c = torch.empty(Fr, D, dtype=torch.float32, device=dev)
-        ops.layernorm_bwd(s["x_out"], D, s["meanN"], s["rstdN"], f.w32("norm.weight"), Fr, dy32=dreps, dx32=dx_c,
+        dx_c = torch.empty(Ftot, D, dtype=torch.float32, device=dev)
+        ops.layernorm_bwd(s["x_out"], D, s["meanN"], s["rstdN"], f.w32("norm.weight"), Ftot, dy32=dreps, dx32=dx_c,
                           dgamma=f.g("norm.weight"), dbeta=f.g("norm.bias"))
         if self.grad_ready_hook:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
-        dxa_c, du, dxn, dxb_c, dao = e16(Fr, D), e16(Fr, HID), e16(Fr, D), e16(Fr, D), e16(Fr, D)
+        dxa_c, du, dxn, dxb_c, dao = e16(Ftot, D), e16(Ftot, HID), e16(Ftot, D), e16(Ftot, D), e16(Ftot, D)
         if s["rs_mlp"] is None:
             ops.cast_bf16(dx_c, dxa_c)
         else:
             ops.cast_bf16_rows(dx_c, s["rs_mlp"], dxa_c)
         ops.gemm_nt(dxa_c, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
         ops.gemm_nt_splitk(du, f.wt16[p + "mlp.fc1.weight"], 12, out16=dxn)
-        ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), Fr, dy16=dxn, dres=dx_c, dx32=dx_c,
+        ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), Ftot, dy16=dxn, dres=dx_c, dx32=dx_c,
                           dx16=dxb_c, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"), rowscale16=s["rs_attn"])
         ops.gemm_nt_splitk(dxb_c, f.wt16[p + "attn.proj.weight"], 6, out16=dao)
-        ops.vit_attn_cls_bwd(s["qkv"], dao, Fr, dqkv, ntok)
+        for g in groups:
+            Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
+            ops.vit_attn_cls_bwd(s["qkv"][lo:lo + Fr * ntok], dao[fo:fo + Fr], Fr, dqkv[lo:lo + Fr * ntok], ntok)
         ops.gemm_tn_grouped([
             (dxa_c, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
             (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
-            (dxb_c, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias"))], Fr)
+            (dxb_c, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias"))], Ftot)
         ops.gemm_tn_grouped([(dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
         dp = saved.get("dp")
         rs_prev = None if dp is None or i == 0 else dp[2 * (i - 1) + 1]
-        if fused:
-            ops.gemm_ln_bwd(dqkv, f.wt16[p + "attn.qkv.weight"], s["x_in"], s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"),
-                            dres=dx_c, dres_period=ntok, dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"),
-                            dbeta=f.g(p + "norm1.bias"), rowscale16=rs_prev)
+        if fused and all(g["Fr"] * g["ntok"] >= ops.ROW_GEMM_MIN_M for g in groups):
+            for g in groups:
+                Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
+                hi = lo + Fr * ntok
+                ops.gemm_ln_bwd(dqkv[lo:hi], f.wt16[p + "attn.qkv.weight"], s["x_in"][lo:hi], s["mean1"][lo:hi], s["rstd1"][lo:hi],
+                                f.w32(p + "norm1.weight"), dres=dx_c[fo:fo + Fr], dres_period=ntok, dx32=dx[lo:hi],
+                                dx16=dxa[lo:hi], dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"),
+                                rowscale16=None if rs_prev is None else rs_prev[lo:hi])
         else:                                         # small M: scatter the CLS gradient into a zeroed residual-stream gradient
             dx.zero_()
-            dx.view(Fr, ntok, D)[:, 0].copy_(dx_c)
+            for g in groups:
+                Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
+                dx[lo:lo + Fr * ntok].view(Fr, ntok, D)[:, 0].copy_(dx_c[fo:fo + Fr])
             dxn_full = e16(M, D)
             ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn_full)
             ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn_full, dres=dx,

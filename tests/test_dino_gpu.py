@@ -280,6 +280,42 @@ def test_multigroup_pass_equals_separate_passes():
     assert rel(g_multi, g_sep) < 1e-5
 
 
+@pytest.mark.parametrize("B,n_local", [(5, 2), (24, 11)])
+def test_multigroup_cls_only_last_block_equals_full_compute(B, n_local):
+    """The multi-crop pass also runs its last block on the CLS rows only (one CLS-attention launch and one dX qkv + norm1'
+    launch per resolution, the row-local half on all frames together): features and the flat gradient must equal the pass
+    that computes every row, DropPath draws shared.  (5, 2): stand-alone kernels; (24, 11): both groups >= 8192 rows, the
+    row-owning kernels with the compact residual gradient (dres_period) per group."""
+    from sais_amd import vit
+
+    def run(prune):
+        model = vit.vit_small(patch_size=16, depth=2, drop_path_rate=0.1)
+        model.load_state_dict(synth.vit_state_dict(seed=27, depth=2))
+        model = model.to(DEV).train()
+        model.prune_last_block = prune
+        model.drop_path_seed = 5
+        crops = synth.dino_crops(seed=341, B=B, n_local=n_local)
+        a, b = torch.cat(crops[:2]).to(DEV), torch.cat(crops[2:]).to(DEV)
+        model._engine(a.device)
+        dfeat = rnd(2 * B + n_local * B, 384, seed=16)
+        with torch.no_grad():
+            rep, saved = model._forward_kernels([a, b], save=True)
+            assert bool(saved.get("pruned")) == prune
+            model.flat.grad.zero_()
+            model._backward_kernels(saved, dfeat)
+            ev, _ = model.eval()._forward_kernels([a, b], save=False)
+        return rep.clone(), model.flat.grad.clone(), ev.clone(), model.flat
+
+    r1, g1, e1, flat = run(True)
+    r0, g0, e0, _ = run(False)
+    scale = float(r0.abs().max())
+    assert float((r1 - r0).abs().max()) <= 5e-3 * scale and float((e1 - e0).abs().max()) <= 5e-3 * scale
+    for n in flat.names:
+        o, k = flat.offsets[n], flat.params[flat.names.index(n)].numel()
+        e = rel(g1[o:o + k], g0[o:o + k])
+        assert e <= 1e-2, (n, e)
+
+
 # ------------------------------------------------------------------ optimizer tail
 def test_adamw_clip_ema_vs_oracle():
     """Four steps of the fused clip + AdamW + EMA kernel on a small two-buffer model against oracle.adamw_update /
