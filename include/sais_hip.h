@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 8
+#define SAIS_ABI_VERSION 9
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -136,7 +136,7 @@ int sais_gemm_tn(const void* P, int ldp, const void* Q, int ldq, int M, int N1, 
                  float* dW, int ldw, float* db, int nsplit, void* stream);
 /* Several weight-gradient GEMMs over the same M rows in ONE launch (all bf16): the four nn.Linear of a ViT
  * block give 108 output tiles, so a few M-splits fill the chip and the atomic traffic shrinks accordingly. */
-#define SAIS_TN_MAX_ITEMS 8
+#define SAIS_TN_MAX_ITEMS 16
 typedef struct SaisTnItem {
     const void* P; int ldp;        /* bf16 [M,N1]  (dY)  */
     const void* Q; int ldq;        /* bf16 [M,N2]  (X)   */
@@ -320,6 +320,11 @@ typedef struct SaisTemporalLayerBwd {
      * in_proj) and dx_add f32 [M,384] (the residual path)                                                                  */
     float* dx_slabs; float* dx_add;
     float p_drop; const unsigned long long* rng_state; unsigned site0;
+    /* optional (ABI 9): SaisTnItem[4] on the HOST.  When set, the layer's four weight / bias gradient GEMMs are NOT launched:
+     * their items (operands inside `workspace` and the saved tensors) are written here, and the caller launches them later
+     * with sais_gemm_tn_grouped_f32(items, n, B * S, 1, stream) — e.g. all layers of an encoder in ONE launch — and must keep
+     * this call's `workspace` untouched until then (one workspace per layer).                                              */
+    SaisTnItem* dw_items_out;
 } SaisTemporalLayerBwd;
 int sais_temporal_layer_bwd(const SaisTemporalLayerParams* w, const SaisTemporalLayerBwd* a, void* workspace, size_t ws_bytes,
                             void* stream);

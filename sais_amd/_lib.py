@@ -31,6 +31,9 @@ class SaisTGemm(ctypes.Structure):
                 ("site", ctypes.c_uint)]
 
 
+TN_MAX_ITEMS = 16            # SAIS_TN_MAX_ITEMS
+
+
 class SaisTnItem(ctypes.Structure):
     _fields_ = [("P", c_void_p), ("ldp", c_int), ("Q", c_void_p), ("ldq", c_int), ("N1", c_int), ("N2", c_int),
                 ("dW", c_void_p), ("ldw", c_int), ("db", c_void_p)]
@@ -88,7 +91,7 @@ class SaisTemporalLayerBwd(ctypes.Structure):
     _fields_ = [("B", c_int), ("S", c_int)] + [(n, c_void_p) for n in (
         "z", "qkv", "ctx", "y1", "mean1", "rstd1", "z1", "h", "y2", "mean2", "rstd2", "key_pad", "dz_slabs")] + \
         [("nslab", c_int), ("slab_stride", c_long), ("dz_add", c_void_p), ("dx_slabs", c_void_p), ("dx_add", c_void_p),
-         ("p_drop", c_float), ("rng_state", c_void_p), ("site0", ctypes.c_uint)]
+         ("p_drop", c_float), ("rng_state", c_void_p), ("site0", ctypes.c_uint), ("dw_items_out", c_void_p)]
 
 
 OP_VIT_BLOCK_FWD, OP_VIT_BLOCK_BWD, OP_TEMPORAL_LAYER_FWD, OP_TEMPORAL_LAYER_BWD = 0, 1, 2, 3

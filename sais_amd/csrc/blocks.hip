@@ -261,7 +261,11 @@ extern "C" int sais_temporal_layer_bwd(const SaisTemporalLayerParams* w, const S
         {dh, FF, a->z1, D, FF, D, w->d_linear1_w, D, w->d_linear1_b},
         {g1, D, a->ctx, D, D, D, w->d_out_proj_w, D, w->d_out_proj_b},
         {dqkv, QKV, a->z, D, QKV, D, w->d_in_proj_w, D, w->d_in_proj_b}};
-    TRY(sais_gemm_tn_grouped_f32(items, 4, M, 1, stream));
+    if (a->dw_items_out) {                     // deferred: the caller batches the layers' weight gradients into one launch
+        for (int i = 0; i < 4; ++i) a->dw_items_out[i] = items[i];
+    } else {
+        TRY(sais_gemm_tn_grouped_f32(items, 4, M, 1, stream));
+    }
     // gradient wrt the layer input = dx_add (residual path, written by norm1's backward) + dqkv . Win (raw slabs)
     TRY(tg(dqkv, w->in_proj_wt, M, D, QKV, SAIS_TG_RAW, nsq, nullptr, nullptr, a->dx_slabs, 0.f, nullptr, 0, stream));
     return SAIS_OK;

@@ -387,15 +387,33 @@ def temporal_layer_fwd(P, B, S, z, pad, qkv, ctx, attn, y1, z1, m1, r1, h, y2, z
     L.call("sais_temporal_layer_fwd", ctypes.byref(P), ctypes.byref(a), _p(ws), ws.numel(), _stream())
 
 
-def temporal_layer_bwd(P, B, S, a, pad, slabs, add, dx_slabs, dx_add, drop, site0, ws):
+def temporal_layer_bwd(P, B, S, a, pad, slabs, add, dx_slabs, dx_add, drop, site0, ws, dw_items=None):
     """One encoder layer backward as ONE C call (sais_temporal_layer_bwd); a = the tensors the forward saved; the gradient of
-    the layer output comes as raw slabs + add and the gradient of its input leaves the same way (dx_slabs, dx_add)."""
+    the layer output comes as raw slabs + add and the gradient of its input leaves the same way (dx_slabs, dx_add).
+    dw_items = (SaisTnItem array, first index): the layer's four weight-gradient GEMMs are written there instead of being
+    launched (temporal_dw_deferred launches them; `ws` must stay untouched until then)."""
     pd, rng = drop if drop is not None else (0.0, None)
+    items_ptr = None
+    if dw_items is not None:
+        arr, first = dw_items
+        items_ptr = ctypes.addressof(arr) + first * ctypes.sizeof(L.SaisTnItem)
     g = L.SaisTemporalLayerBwd(B, S, _p(a["z"]), _p(a["qkv"]), _p(a["ctx"]), _p(a["y1"]), _p(a["m1"]), _p(a["r1"]), _p(a["z1"]),
                                _p(a["h"]), _p(a["y2"]), _p(a["m2"]), _p(a["r2"]), _p(pad), _p(slabs),
                                0 if slabs is None else slabs.shape[0], 0 if slabs is None else slabs.stride(0), _p(add),
-                               _p(dx_slabs), _p(dx_add), float(pd), _p(rng), int(site0))
+                               _p(dx_slabs), _p(dx_add), float(pd), _p(rng), int(site0), items_ptr)
     L.call("sais_temporal_layer_bwd", ctypes.byref(P), ctypes.byref(g), _p(ws), ws.numel(), _stream())
+
+
+def tn_items(n):
+    return (L.SaisTnItem * n)()
+
+
+def temporal_dw_deferred(arr, n, M):
+    """The weight / bias gradients temporal_layer_bwd deferred: ONE launch for up to SAIS_TN_MAX_ITEMS (16) GEMMs."""
+    for lo in range(0, n, L.TN_MAX_ITEMS):
+        k = min(L.TN_MAX_ITEMS, n - lo)
+        first = ctypes.cast(ctypes.addressof(arr) + lo * ctypes.sizeof(L.SaisTnItem), ctypes.POINTER(L.SaisTnItem))
+        L.call("sais_gemm_tn_grouped_f32", first, k, M, 1, _stream())
 
 
 def vit_attn_cls_fwd(qkv, frames, out_c, ntok=197):

@@ -33,6 +33,7 @@ import os as _os
 
 _LAYER_CALLS = _os.environ.get('SAIS_TEMPORAL_LAYER_CALLS', '1') != '0'      # one C call per encoder layer and direction
 _PREFETCH = _os.environ.get('SAIS_TEMPORAL_PREFETCH', '0') == '1'        # measured: no net gain (LABNOTES R4.3): off
+_DW_DEFER = _os.environ.get('SAIS_TEMPORAL_DW_DEFER', '1') != '0'       # all layers' weight gradients in ONE launch after the dX chain
 D, TH, FF, EMB, NPOS = 384, 4, 2048, 256, 2000
 
 
@@ -356,10 +357,12 @@ class fullModel(nn.Module):
             self._lp[prefix] = ops.temporal_layer_params(f, prefix)
         return self._lp[prefix]
 
-    def _ws(self, op, B, S, dev):
+    def _ws(self, op, B, S, dev, slot=0):
+        """Scratch of a layer-level call; `slot` keeps the backward's per-layer workspaces apart (their weight-gradient
+        operands are read by ONE deferred launch after the last layer)."""
         if torch.cuda.is_current_stream_capturing():
             return ops.block_workspace(op, B, S, dev)
-        key = (op, B, S, str(dev))
+        key = (op, B, S, str(dev), slot)
         if not hasattr(self, "_wsbuf"):
             self._wsbuf = {}
         if key not in self._wsbuf:
@@ -429,6 +432,9 @@ class fullModel(nn.Module):
         S, M = T + 1, B * (T + 1)
         e32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
         slabs, add = None, dz                      # the gradient entering a layer = sum of `slabs` (raw dX GEMM output) + add
+        layer_calls = _LAYER_CALLS and ops.TIMER is None
+        dw_items = ops.tn_items(4 * self.nlayers) if layer_calls and _DW_DEFER else None
+        keep = []                                  # per-layer gradients the deferred launch still reads
         for l in reversed(range(self.nlayers)):
             p = self._lnames(l)
             a = s["layers"][l]
@@ -439,11 +445,13 @@ class fullModel(nn.Module):
             site = (s.get("sidx", 0) * self.nlayers + l) * 4
             pd, rng = drop if drop is not None else (0.0, None)
             dsite = (lambda k: None if drop is None else (pd, rng, site + k))
-            if _LAYER_CALLS and ops.TIMER is None:       # one C call per layer (sais_temporal_layer_bwd)
+            if layer_calls:                              # one C call per layer (sais_temporal_layer_bwd)
                 ns = L.load().sais_tgemm_nsplit(M, D, 3 * D)
                 dx_slabs, dy1 = e32(ns, M, D), e32(M, D)
-                ops.temporal_layer_bwd(self._layer_params(p), B, S, a, s["pad"], slabs, add, dx_slabs, dy1, drop, site,
-                                       self._ws(L.OP_TEMPORAL_LAYER_BWD, B, S, dev))
+                ws = self._ws(L.OP_TEMPORAL_LAYER_BWD, B, S, dev, slot=l)
+                ops.temporal_layer_bwd(self._layer_params(p), B, S, a, s["pad"], slabs, add, dx_slabs, dy1, drop, site, ws,
+                                       dw_items=None if dw_items is None else (dw_items, 4 * l))
+                keep += [ws, dy1]
                 slabs, add = dx_slabs, dy1
                 continue
             dy2 = e32(M, D)
@@ -470,6 +478,9 @@ class fullModel(nn.Module):
                 (dqkv, a["z"], fl.g(p + "self_attn.in_proj_weight"), fl.g(p + "self_attn.in_proj_bias"))], M, nsplit=1)
             # gradient wrt the layer input = dy1 (residual) + dqkv . Win: left as slabs for the next consumer
             slabs, add = self._raw(dqkv, fl.wt16[p + "self_attn.in_proj_weight"]), dy1
+        if dw_items is not None:       # the 4 x nlayers weight / bias gradient GEMMs of the encoder in ONE launch (they are off the dX chain)
+            ops.temporal_dw_deferred(dw_items, 4 * self.nlayers, M)
+        del keep
         x = s["x"]
         dx = torch.empty_like(x) if need_dx else None
         self._touched_T = max(self._touched_T, T)
