@@ -36,9 +36,11 @@ HBM_PEAK_GBPS = 8000.0           # HBM3E spec (same guide; ~6.3 TB/s achievable)
 FLOP_PER_FRAME_FWD_BWD = 27.475e9   # 3 x 9.197 GF - 0.1156 GF (no dX for pixels)
 # The last ViT block runs on the CLS rows / the CLS query only (sais_amd.vit, prune_last_block: forward() returns x[:, 0], so
 # the other rows of that block feed nothing): its proj, MLP and query-side attention products are not executed.  Per frame:
-# 3 x (proj .058098 + fc1 .232391 + fc2 .232391) + attention (fwd .059610, bwd 2.5 x) = 1.777 GF.  The roofline fractions
-# below are computed from the EXECUTED flops, so the pruning does not inflate them.
+# 3 x (proj .058098 + fc1 .232391 + fc2 .232391) + attention (fwd .059610, bwd 2.5 x) + the query third of the qkv GEMM
+# and of its weight gradient (2 x .058098; its dX still runs, on zeros) = 1.893 GF.  The roofline fractions below are
+# computed from the EXECUTED flops, so the pruning does not inflate them.
 FLOP_PRUNED_PER_FRAME = 3 * (0.058098e9 + 2 * 0.232391e9) + 3.5 * 0.059610e9
+FLOP_PRUNED_Q_PER_FRAME = 2 * 0.058098e9       # SAIS_VIT_PRUNE_Q (default on)
 FLOP_TEMPORAL_PER_CLIP = 3 * 0.57764e9
 HBM_BYTES_PER_FRAME = 133e6      # SURVEY §8d / BASELINE.md §4: fused bf16 plan, fwd+bwd
 
@@ -641,7 +643,9 @@ def main():
         fps = world * B * T * args.steps / dt
         nstream = 2 if two else 1
         pruned = bool(getattr(vit, "prune_last_block", False))
-        per_frame = FLOP_PER_FRAME_FWD_BWD - (FLOP_PRUNED_PER_FRAME if pruned else 0.0)
+        from sais_amd import vit as _vitmod
+        per_frame = FLOP_PER_FRAME_FWD_BWD - (FLOP_PRUNED_PER_FRAME + (FLOP_PRUNED_Q_PER_FRAME if _vitmod._PRUNE_Q else 0.0)
+                                              if pruned else 0.0)
         step_flops = nstream * (B * T * per_frame + B * FLOP_TEMPORAL_PER_CLIP)
         if roof is not None:
             roof["hbm_frac"] = round(nstream * B * T * HBM_BYTES_PER_FRAME * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)

@@ -19,6 +19,7 @@ rates linspace(0, drop_path_rate, depth); SAIS itself only ever runs the ViT in 
 (`drop_path_seed`, this library's stream, not torch's): `last_droppath_scales` holds what a forward used.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -29,6 +30,7 @@ from . import ops
 from .flat import FlatParams
 
 D, NTOK, HEADS, HID, PATCH_K = 384, 197, 6, 1536, 768
+_PRUNE_Q = os.environ.get("SAIS_VIT_PRUNE_Q", "1") != "0"     # the CLS-only last block computes q for the CLS rows only
 SIDES = {224: 197, 96: 37}          # supported frame sizes -> tokens (the attention kernels are instantiated per count)
 
 
@@ -302,7 +304,15 @@ class VisionTransformer(nn.Module):
                 ops.layernorm_fwd(x, M, D, f.w32(p + "norm1.weight"), f.w32(p + "norm1.bias"), 1e-6, y16=xn, mean=mean1,
                                   rstd=rstd1)
             use_block = blockcall and not last_attn and not ops.mlp_fused_enabled(M) and not (prune and i == self.depth - 1)
-            if not use_block:
+            if prune and i == self.depth - 1 and len(groups) == 1 and _PRUNE_Q:
+                # CLS-only last block: keys and values of every token, the query of the CLS rows only (the other rows' q
+                # columns of `qkv` stay unwritten: nothing reads them)
+                Wq, bq = f.w(p + "attn.qkv.weight"), f.w32(p + "attn.qkv.bias")
+                ops.gemm_nt(xn, Wq[D:], L.EPI_BIAS_BF16, qkv[:, D:], bias=bq[D:])
+                g0 = groups[0]
+                ops.gemm_nt(xn.view(g0["Fr"], g0["ntok"], D)[:, 0], Wq[:D], L.EPI_BIAS_BF16,
+                            qkv.view(g0["Fr"], g0["ntok"], 3 * D)[:, 0, :D], bias=bq[:D])
+            elif not use_block:
                 ops.gemm_nt(xn, f.w(p + "attn.qkv.weight"), L.EPI_BIAS_BF16, qkv, bias=f.w32(p + "attn.qkv.bias"))
             if prune and i == self.depth - 1:
                 reps, tail = self._cls_tail_fwd(f, i, x, xn, mean1, rstd1, qkv, groups, dp, save, e16, e32)
@@ -481,11 +491,19 @@ class VisionTransformer(nn.Module):
         for g in groups:
             Fr, ntok, lo, fo = g["Fr"], g["ntok"], g["off"], g["foff"]
             ops.vit_attn_cls_bwd(s["qkv"][lo:lo + Fr * ntok], dao[fo:fo + Fr], Fr, dqkv[lo:lo + Fr * ntok], ntok)
-        ops.gemm_tn_grouped([
+        compact = [
             (dxa_c, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
             (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
-            (dxb_c, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias"))], Ftot)
-        ops.gemm_tn_grouped([(dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
+            (dxb_c, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias"))]
+        gW, gb = f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias")
+        if len(groups) == 1 and _PRUNE_Q:      # dq is zero off the CLS rows: its weight gradient is a [frames, 384] GEMM too
+            Fr, ntok = groups[0]["Fr"], groups[0]["ntok"]
+            compact.append((dqkv.view(Fr, ntok, 3 * D)[:, 0, :D], s["xn1"].view(Fr, ntok, D)[:, 0], gW[:D], gb[:D]))
+            ops.gemm_tn_grouped(compact, Ftot)
+            ops.gemm_tn_grouped([(dqkv[:, D:], s["xn1"], gW[D:], gb[D:])], M)
+        else:
+            ops.gemm_tn_grouped(compact, Ftot)
+            ops.gemm_tn_grouped([(dqkv, s["xn1"], gW, gb)], M)
         dp = saved.get("dp")
         rs_prev = None if dp is None or i == 0 else dp[2 * (i - 1) + 1]
         if fused and all(g["Fr"] * g["ntok"] >= ops.ROW_GEMM_MIN_M for g in groups):
