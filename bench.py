@@ -67,6 +67,9 @@ def parse_args():
     ap.add_argument("--dino-batch", type=int, default=64, help="--workload dino: images per GPU (batch_size_per_gpu)")
     ap.add_argument("--dino-local-crops", type=int, default=8)
     ap.add_argument("--dino-out-dim", type=int, default=65536)
+    ap.add_argument("--dino-graph", action="store_true",
+                    help="--workload dino: replay forward + loss + backward as one hipGraph (sais_amd.dino.GraphedTrainStep). "
+                         "Off by default: the eager DINO step is device-bound and measured 0.5 %% FASTER (LABNOTES R4.3)")
     ap.add_argument("--parity-clips", type=int, default=1,
                     help="clips of the timed batch that also go through the CPU oracle (with the draws the GPU forward "
                          "used) for the in-line parity gate; 0 = skip")
@@ -283,9 +286,22 @@ def dino_main(args):
     images = [torch.randn(B, 3, 224, 224, device=dev, generator=g) for _ in range(2)] + \
              [torch.randn(B, 3, 96, 96, device=dev, generator=g) for _ in range(nl)]
 
-    def step(it):
+    def eager_step(it):
         return dino.train_step(student, teacher, loss_mod, opt, images, it, 1, lr_s, wd_s, mom_s, clip_grad=3.0,
                                freeze_last_layer=1)[0]
+
+    # --dino-graph: everything up to the optimizer tail replayed as one hipGraph (sais_amd.dino.GraphedTrainStep)
+    step, launch = eager_step, "eager"
+    if args.dino_graph:
+        try:
+            graphed = dino.GraphedTrainStep(student, teacher, loss_mod, opt, images, clip_grad=3.0)
+            graphed(0, 1, lr_s, wd_s, mom_s, 1)                      # captures (and runs iteration 0)
+            step = lambda it: graphed(it, 1, lr_s, wd_s, mom_s, 1)[0]
+            launch = "hipGraph replay (forward, loss, backward, gradient exchange, norms) + eager optimizer tail"
+        except Exception as e:                                      # e.g. a RCCL build that refuses stream capture
+            sys.stderr.write(f"bench.py[rank {rank}]: graph capture of the DINO step failed ({type(e).__name__}: {e}); "
+                             "running eagerly\n")
+            torch.cuda.synchronize()
 
     for it in range(args.warmup):
         loss = step(it)
@@ -304,8 +320,8 @@ def dino_main(args):
     ms = dt.item() / args.steps * 1e3
     lv = loss.item()
     comm_bytes = 4 * (student.backbone.flat.numel + student.head.flat.numel) if dist_on else 0
-    ops.TIMER = ops.KernelTimer()                                    # instrumented pass after the timed region
-    step(args.warmup + args.steps)
+    ops.TIMER = ops.KernelTimer()                                    # instrumented pass after the timed region (eager)
+    eager_step(args.warmup + args.steps)
     torch.cuda.synchronize()
     summ, ops.TIMER = ops.TIMER.summary(), None
     top = max(summ.items(), key=lambda kv: kv[1]["total_ms"])
@@ -317,7 +333,7 @@ def dino_main(args):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"DINO ViT-S/16 pre-training step (main_dino.py defaults): {B} images per GPU, "
                                       f"{crops} crops, out_dim {out_dim}, drop_path {args.vit_drop_path}, clip 3.0, AdamW, "
-                                      f"EMA teacher", "parallelism": f"dp{world}",
+                                      f"EMA teacher", "parallelism": f"dp{world}", "launch": launch,
                           "student_token_rows_per_gpu": B * (2 * 197 + nl * 37), "teacher_token_rows_per_gpu": B * 2 * 197},
                "loss": round(lv, 4), "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                "roofline": {"kernel": top[0], "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_PEAK_TFLOPS,

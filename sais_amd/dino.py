@@ -325,6 +325,9 @@ class _FlatAdamW:
         self.partial = torch.empty(self.nchunks, dtype=F32, device=dev)
         self.norms = torch.zeros(self.nseg, dtype=F32, device=dev)
         self.flags = flags
+        # segments that have a gradient, as a DEVICE index (a Python-list index would be a host -> device copy per call,
+        # which a hipGraph capture cannot hold)
+        self.keep_idx = torch.tensor([i for i, fl in enumerate(flags) if not fl & L.OPT_NO_GRAD], dtype=torch.int64, device=dev)
 
     def grad_norms(self, scale=1.0):
         ops.grad_norms(self.flat.grad, self.chunks, self.nchunks, self.seg_first, self.nseg, self.partial, self.norms, scale)
@@ -389,9 +392,7 @@ class DINOOptimizer:
             self._build()
         out = []
         for part, _ in self._parts:
-            norms = part.grad_norms(self.grad_scale)
-            keep = [i for i, fl in enumerate(part.flags) if not fl & L.OPT_NO_GRAD]
-            out.append(norms[keep])
+            out.append(part.grad_norms(self.grad_scale).index_select(0, part.keep_idx))
         self._norms_fresh = True
         return torch.cat(out)
 
@@ -490,14 +491,17 @@ def build_student_teacher(out_dim=65536, drop_path_rate=0.1, norm_last_layer=Tru
     return student, teacher
 
 
-def train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_schedule, wd_schedule, momentum_schedule,
-               clip_grad=3.0, freeze_last_layer=1, want_norms=False):
-    """One iteration of train_one_epoch's loop body (main_dino.py:521-566).  Returns (loss 0-dim device tensor,
-    per-parameter gradient norms or None).  Nothing here synchronises with the host."""
+def _set_schedules(optimizer, it, lr_schedule, wd_schedule):
     for i, g in enumerate(optimizer.param_groups):                   # :523-529
         g["lr"] = float(lr_schedule[it])
         if i == 0:
             g["weight_decay"] = float(wd_schedule[it])
+
+
+def _forward_backward(student, teacher, dino_loss, optimizer, images, epoch, clip_grad, want_norms):
+    """main_dino.py:535-549: teacher / student forward, loss + centre update, zero_grad, backward (with the data-parallel
+    gradient exchange), per-parameter norms.  No kernel argument in here changes from one iteration to the next inside an
+    epoch (the teacher temperature is per EPOCH), which is what lets GraphedTrainStep capture it."""
     with torch.no_grad():
         groups = student._groups(images)         # one concatenation per resolution, shared by both networks
         two_global = groups[0] if groups[0].shape[0] == 2 * images[0].shape[0] else images[:2]
@@ -519,9 +523,77 @@ def train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_sch
         norms = None
         if clip_grad or want_norms:
             norms = clip_gradients(optimizer, clip_grad)                             # :548-549
+    return loss, norms
+
+
+def train_step(student, teacher, dino_loss, optimizer, images, it, epoch, lr_schedule, wd_schedule, momentum_schedule,
+               clip_grad=3.0, freeze_last_layer=1, want_norms=False):
+    """One iteration of train_one_epoch's loop body (main_dino.py:521-566).  Returns (loss 0-dim device tensor,
+    per-parameter gradient norms or None).  Nothing here synchronises with the host."""
+    _set_schedules(optimizer, it, lr_schedule, wd_schedule)
+    loss, norms = _forward_backward(student, teacher, dino_loss, optimizer, images, epoch, clip_grad, want_norms)
+    with torch.no_grad():
         optimizer.step(clip_grad=clip_grad or 0.0, frozen_last_layer=epoch < freeze_last_layer,      # :550-552
                        ema_momentum=float(momentum_schedule[it]))                    # :563-566
     return loss, norms
+
+
+class GraphedTrainStep:
+    """train_step with everything up to the optimizer replayed as ONE hipGraph: the two forward passes, the loss and centre
+    update, zero_grad, the backward with its gradient exchange and the per-parameter norms (~350 launches) are captured; the
+    optimizer tail (two fused clip + AdamW + EMA launches, the shadow refresh), whose lr / weight decay / momentum / bias
+    corrections are kernel ARGUMENTS that change every iteration, stays eager.  The teacher temperature is a kernel argument
+    too, but a per-EPOCH one: the graph is captured again when it changes (once per warm-up epoch).
+
+    `images` are static device tensors: copy each new batch into them (`tensor.copy_`) before the call.  Capturing runs the
+    step once for real (allocator, lazily built tables); the state that run touches — the centre, the DropPath RNG — is
+    put back afterwards, so a graphed loop computes what the eager loop computes."""
+
+    def __init__(self, student, teacher, dino_loss, optimizer, images, clip_grad=3.0, want_norms=False):
+        self.student, self.teacher, self.dino_loss, self.optimizer = student, teacher, dino_loss, optimizer
+        self.images, self.clip_grad, self.want_norms = list(images), clip_grad, want_norms
+        self._graph, self._temp, self._out = None, None, None
+
+    def _capture(self, epoch):
+        fn = lambda: _forward_backward(self.student, self.teacher, self.dino_loss, self.optimizer, self.images, epoch,
+                                       self.clip_grad, self.want_norms)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()                                              # warm-up (its side effects are undone by the caller)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        # RCCL collectives inside: ProcessGroupNCCL's watchdog thread makes HIP calls of its own while this thread captures
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        with torch.cuda.graph(self._graph, capture_error_mode=mode):
+            self._out = fn()
+        self._temp = float(self.dino_loss.teacher_temp_schedule[epoch])
+
+    def __call__(self, it, epoch, lr_schedule, wd_schedule, momentum_schedule, freeze_last_layer=1):
+        _set_schedules(self.optimizer, it, lr_schedule, wd_schedule)
+        temp = float(self.dino_loss.teacher_temp_schedule[epoch])
+        if self._graph is None or temp != self._temp:
+            dev = self.images[0].device
+            bb = self.student.backbone
+            if self.dino_loss.center.device != dev:           # first call ever: DINOLoss would move it in the warm-up
+                self.dino_loss.center = self.dino_loss.center.to(dev, F32)
+            pre_c = self.dino_loss.center.clone()
+            pre_r = None if bb._rng is None else bb._rng.clone()
+            self._capture(epoch)
+            with torch.no_grad():                             # undo the warm-up run: centre EMA and DropPath draws
+                self.dino_loss.center.copy_(pre_c)
+                if bb._rng is not None:
+                    if pre_r is not None:
+                        bb._rng.copy_(pre_r)
+                    else:                                     # the RNG state was created by the warm-up: back to its seed
+                        bb._rng.copy_(ops.rng_state(bb.drop_path_seed, dev))
+        self._graph.replay()
+        loss, norms = self._out
+        self.optimizer._norms_fresh = norms is not None       # the replay computed them for THESE gradients
+        with torch.no_grad():
+            self.optimizer.step(clip_grad=self.clip_grad or 0.0, frozen_last_layer=epoch < freeze_last_layer,
+                                ema_momentum=float(momentum_schedule[it]))
+        return loss, norms
 
 
 # --------------------------------------------------------------------------- checkpoints (main_dino.py:485-494)

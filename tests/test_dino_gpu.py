@@ -316,6 +316,60 @@ def test_multigroup_cls_only_last_block_equals_full_compute(B, n_local):
         assert e <= 1e-2, (n, e)
 
 
+def test_graphed_train_step_equals_eager():
+    """dino.GraphedTrainStep (forward, loss + centre, backward, norms as one hipGraph; optimizer tail eager) against
+    dino.train_step: five iterations over two epochs of a teacher-temperature warm-up (so the graph is captured twice), new
+    crops, lr, weight decay and momentum every iteration, DropPath 0.1, clipping on, last layer frozen in epoch 0.  Loss,
+    gradient norms, centre and every student / teacher parameter must agree (what differs is the order of fp32 atomics)."""
+    from sais_amd import dino
+    out_dim, n_local, B, depth = 2048, 2, 4, 2
+    sd = {"backbone." + k: v for k, v in synth.vit_state_dict(seed=23, depth=depth).items()}
+    sd.update({"head." + k: v for k, v in synth.dino_head_state_dict(seed=24, out_dim=out_dim).items()})
+    lr_s = dino.cosine_scheduler(2e-4, 1e-6, 2, 3)
+    wd_s = dino.cosine_scheduler(0.04, 0.4, 2, 3)
+    mom_s = dino.cosine_scheduler(0.99, 1.0, 2, 3)
+    batches = [[t.to(DEV) for t in synth.dino_crops(seed=360 + it, B=B, n_local=n_local)] for it in range(5)]
+
+    def run(graphed):
+        student, teacher = dino.build_student_teacher(out_dim=out_dim, drop_path_rate=0.1, device=DEV, depth=depth)
+        student.load_state_dict(sd)
+        teacher.load_state_dict(student.state_dict())
+        student.train()
+        student.backbone.drop_path_seed = 11
+        loss_mod = dino.DINOLoss(out_dim, n_local + 2, 0.04, 0.07, 2, 4).to(DEV)      # temperature 0.04 -> 0.07 over 2 epochs
+        opt = dino.DINOOptimizer(student, teacher)
+        static = [t.clone() for t in batches[0]]
+        step = dino.GraphedTrainStep(student, teacher, loss_mod, opt, static, clip_grad=0.3) if graphed else None
+        rec = []
+        for it in range(5):
+            epoch = it // 3
+            if graphed:
+                for d, src in zip(static, batches[it]):
+                    d.copy_(src)
+                loss, norms = step(it, epoch, lr_s, wd_s, mom_s, freeze_last_layer=1)
+            else:
+                loss, norms = dino.train_step(student, teacher, loss_mod, opt, batches[it], it, epoch, lr_s, wd_s, mom_s,
+                                              clip_grad=0.3, freeze_last_layer=1)
+            rec.append((float(loss), norms.clone(), loss_mod.center.clone()))
+        params = {"s." + n: p.detach().clone() for n, p in student.named_parameters()}
+        params.update({"t." + n: p.detach().clone() for n, p in teacher.named_parameters()})
+        return rec, params, opt.steps
+
+    rg, pg, sg = run(True)
+    re_, pe, se = run(False)
+    assert sg == se == [5, 2]
+    for it, ((lg, ng, cg), (le, ne, ce)) in enumerate(zip(rg, re_)):
+        assert abs(lg - le) <= 2e-5 * abs(le), (it, lg, le)
+        assert rel(ng, ne) < 1e-3, (it, rel(ng, ne))
+        assert float((cg - ce).abs().max()) <= 1e-6 + 1e-3 * float(ce.abs().max()), it      # the weights drift apart by ~lr (below)
+    for n in pe:
+        # AdamW moves an element by ~lr whatever the gradient's size: where the sign of a rounding-noise gradient differs between
+        # two summation orders the runs part by up to 2 lr per step; the bulk must agree to a fraction of one step
+        d = (pg[n] - pe[n]).abs()
+        assert float(d.max()) <= 2.2 * 2e-4 * 5 + 1e-6, (n, float(d.max()))
+        assert float(d.float().median()) <= 2e-5, (n, float(d.float().median()))
+
+
 # ------------------------------------------------------------------ optimizer tail
 def test_adamw_clip_ema_vs_oracle():
     """Four steps of the fused clip + AdamW + EMA kernel on a small two-buffer model against oracle.adamw_update /
