@@ -264,9 +264,17 @@ __device__ unsigned long long g_nt_stamps[8][16];
 #else
 #define NTSTAMP(i) do { } while (0)
 #endif
+// SAIS_NT_ABL (timing ablations, results are WRONG when set; LABNOTES R4.4): 1 no K loop (no operand loads, no MFMAs),
+// 2 no epilogue (no epilogue loads, arithmetic, stores), 4 / 8 role split — even / odd workgroups (4) or the lower / upper
+// 256 workgroups (8) run ONLY the K loops resp. ONLY the epilogues of their tiles: do the two phases overlap on a CU at all?
+#ifndef SAIS_NT_ABL
+#define SAIS_NT_ABL 0
+#endif
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
+    [[maybe_unused]] const int abl_role = (SAIS_NT_ABL & 4) ? (blockIdx.x & 1) : (SAIS_NT_ABL & 8) ? ((blockIdx.x >> 8) & 1) : -1;
+    const bool do_k = !(SAIS_NT_ABL & 1) && abl_role != 1, do_e = !(SAIS_NT_ABL & 2) && abl_role != 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
@@ -327,9 +335,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
     int v = blockIdx.x, m0, n0;
     if (v >= ntiles) return;
     set_tile(v, m0, n0);
-    issue_a(0);
-    issue_w(0);
-    if (nk > 1) issue_a(1);
+    if (do_k) {
+        issue_a(0);
+        issue_w(0);
+        if (nk > 1) issue_a(1);
+    }
     if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     [[maybe_unused]] int titer = -1;
@@ -348,12 +358,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
         // whole workgroup waits for at the next barrier.  fc1 + GELU' 124 -> 117-120 us, dX fc2 114 -> 108-112, qkv 67 -> 63-65
         // on two boxes; priorities 1, 2 and 3 measure the same.
         __builtin_amdgcn_s_setprio(2);
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < (do_k ? nk : 0); ++kt) {
             if (kt + 1 < nk) issue_w(kt + 1);
             if (kt + 2 < nk) issue_a(kt + 2);
             const char* sa = smem + (kt % 3) * TILE_BYTES;
             const char* sb = sW + (kt & 1) * TILE_BYTES;
-            if (kt == nk - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
+            if (kt == nk - 1 && do_e) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 fa[4], fb[2];
@@ -381,13 +391,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
         asm volatile("" ::"v"(pf_keep));                               // the previous prefetch has been retired by now
         if (more) {
             set_tile(nv, m0, n0);
-            issue_a(0);
-            issue_w(0);
-            if (nk > 1) issue_a(1);
-            if (do_pf) prefetch_a(m0, xcd_remap(nv, ntiles) % ntn);
+            if (do_k) {
+                issue_a(0);
+                issue_w(0);
+                if (nk > 1) issue_a(1);
+                if (do_pf) prefetch_a(m0, xcd_remap(nv, ntiles) % ntn);
+            }
+        }
+        if (SAIS_NT_ABL) {
+            if (!do_k) epilogue_loads8<EPI>(p, cm0 + wr * 64, li, cn0 + wc * 32 + 8 * g, bias, aux);
+            if (!do_e) {                                               // keep the MFMAs alive
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) asm volatile("" ::"v"(acc[mt][nt]));
+            }
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < (do_e ? 4 : 0); ++mt) {
             const int m = cm0 + wr * 64 + mt * 16 + li;
             if (m >= p.M) continue;
             float vv[8];
