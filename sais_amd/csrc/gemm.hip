@@ -1038,6 +1038,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
 
 extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream);      // gemm_row.hip: row-owning tiles, N = 384
 
+
 extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     SAIS_ENTER();
     if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
