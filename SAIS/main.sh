@@ -12,13 +12,20 @@ do
 done
 SYN=""
 if [ -n "$synthetic" ]; then SYN="--synthetic_frames $synthetic"; fi
+# RAFT weights of the flow stage (ptlflow's "things" state dict; not shipped: no network here).  Without the file the stage
+# only accepts flows the user has put under ./SAIS/flows/<video>/ and exits non-zero otherwise; a synthetic smoke run (-s)
+# asks for seeded random weights explicitly — its folder is marked and regenerated once a checkpoint exists.
+RAFT_CHECKPOINT=${RAFT_CHECKPOINT:-./SAIS/scripts/raft_things.pth}
+if [ -f "$RAFT_CHECKPOINT" ]; then RAFT="--raft_checkpoint $RAFT_CHECKPOINT"
+elif [ -n "$synthetic" ]; then RAFT="--raft_random_weights"
+else RAFT=""; fi
 
 
 # generate paths to frames and flows and save as csv files
 python ./SAIS/scripts/generate_paths.py -f $videoname -p ./SAIS/ $SYN || exit 1
 
-# generate flow maps (skipped for a video whose ./SAIS/flows/<video>/ already exists, as in the reference)
-python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 2 --data_path ./SAIS/ --data_list Custom --save_type h5 --optical_flow --video $videoname $SYN || exit 1
+# generate flow maps (skipped for a video whose ./SAIS/flows/<video>/ is already complete, as in the reference)
+python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 2 --data_path ./SAIS/ --data_list Custom --save_type h5 --optical_flow --video $videoname $SYN $RAFT || exit 1
 
 # extract representations of rgb images
 python ./SAIS/scripts/extract_representations.py --arch vit_small --patch_size 16 --model_type ViT_SelfSupervised_ImageNet --batch_size_per_gpu 1024 --data_path ./SAIS/ --data_list Custom --save_type h5 --video $videoname $SYN || exit 1

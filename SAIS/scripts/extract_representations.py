@@ -18,6 +18,9 @@ from SAIS.scripts._features_io import save_reps  # noqa: E402
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)          # :148
 
 
+FLOW_MARKER = '.flows_complete.json'                               # written by --optical_flow when a video's flows are all saved
+
+
 class FrameError(Exception):
     """A frame this rank's shard cannot use.  Raised locally, reported collectively (every rank leaves together)."""
 
@@ -60,28 +63,70 @@ def extract_flows(args, t0):
     paths/<dataset>_FlowPaths.csv (frames 15 apart, written by generate_paths.py) estimate the flow with RAFT, colour-code it
     (flow_to_rgb) and save flows/<label>/flows_<nflow:08d>.jpg with nflow = frame number // jump_size.  RAFT runs on the GPU
     (sais_amd.raft: correlation volume on the HIP kernels); PARITY UNPINNED — ptlflow 0.2.5 / the 'things' checkpoint are
-    absent, so without --raft_checkpoint the weights are seeded random.  Videos whose flows folder exists are skipped, as in
-    the reference (:487)."""
+    absent.  Without --raft_checkpoint the stage REFUSES to generate anything (exit 2) unless --raft_random_weights asks
+    for seeded random weights explicitly (smoke runs): flow maps of an untrained RAFT are noise, and they would land in the
+    folder the flow stream reads.
+
+    A video is skipped, as in the reference (:487), when its flows folder is COMPLETE: it either carries this stage's marker
+    (`.flows_complete.json`: count + which weights) with as many flows_*.jpg as the CSV asks for, or — no marker — it holds
+    exactly that many files (flows the user supplied).  A folder without marker and with fewer files (an interrupted run)
+    is regenerated, and so is a folder whose marker says "random" once a real checkpoint is given."""
     import csv
+    import json
     from PIL import Image
-    from sais_amd.raft import RAFT, flow_image_uint8, flow_to_rgb
     dev = torch.device('cuda', args.local_rank)
-    torch.manual_seed(0)
-    model = RAFT(iters=args.raft_iters)
-    if args.raft_checkpoint:
-        sd = torch.load(args.raft_checkpoint, map_location='cpu')
-        model.load_state_dict({k.replace('module.', '', 1): v for k, v in sd.items()}, strict=True)
-    else:
-        print('[flow] no --raft_checkpoint: seeded random RAFT weights (parity unpinned; see sais_amd/raft.py)')
-    model = model.to(dev).eval()
+    weights = ('checkpoint:' + os.path.basename(args.raft_checkpoint)) if args.raft_checkpoint else 'random-seed-0'
+    model = None
+
+    def get_model():
+        from sais_amd.raft import RAFT
+        torch.manual_seed(0)
+        m = RAFT(iters=args.raft_iters)
+        if args.raft_checkpoint:
+            sd = torch.load(args.raft_checkpoint, map_location='cpu')
+            m.load_state_dict({k.replace('module.', '', 1): v for k, v in sd.items()}, strict=True)
+        else:
+            print('[flow] --raft_random_weights: seeded random RAFT weights, the flow maps are NOT optical flow '
+                  '(parity unpinned; see sais_amd/raft.py)')
+        return m.to(dev).eval()
+
+    def complete(label, want):
+        folder = os.path.join(args.data_path, 'flows', label)
+        if not os.path.isdir(folder):
+            return False
+        have = len(glob.glob(os.path.join(folder, 'flows_*.jpg')))
+        marker = os.path.join(folder, FLOW_MARKER)
+        if not os.path.exists(marker):
+            return have >= want                      # user-supplied flows; a partial folder of an interrupted run is not
+        with open(marker) as fh:
+            info = json.load(fh)
+        if info.get('weights', '').startswith('random') and args.raft_checkpoint:
+            return False                             # junk of a smoke run: regenerate with the real weights
+        return have >= want and info.get('count') == want
+
+    from sais_amd.raft import flow_image_uint8, flow_to_rgb
     for dataset in args.data_list:
         jump = 30 if dataset in ('VUA_Lab', 'DVC_UCL') else 15                       # :488-493
         with open(os.path.join(args.data_path, 'paths', '%s_FlowPaths.csv' % dataset)) as fh:
             rows = list(csv.DictReader(fh))
         if args.video:
             rows = [r for r in rows if r['label'] == args.video]
-        done = {lab for lab in {r['label'] for r in rows} if os.path.exists(os.path.join(args.data_path, 'flows', lab))}
+        want = {}
+        for r in rows:
+            want[r['label']] = want.get(r['label'], 0) + 1
+        done = {lab for lab, n in want.items() if complete(lab, n)}
         rows = [r for r in rows if r['label'] not in done]
+        if rows and not args.raft_checkpoint and not args.raft_random_weights:
+            raise SystemExit('[flow] %d flow maps of %s are missing and no --raft_checkpoint was given.  Pass the RAFT "things" '
+                             'state dict (main.sh: RAFT_CHECKPOINT=...), put your own flows_*.jpg under flows/<video>/, or ask '
+                             'for seeded random weights explicitly with --raft_random_weights (smoke runs only).'
+                             % (len(rows), sorted(set(want) - done)))
+        if rows and model is None:
+            model = get_model()
+        for lab in set(want) - done:                 # a stale marker / partial folder must not survive a failed run
+            mk = os.path.join(args.data_path, 'flows', lab, FLOW_MARKER)
+            if os.path.exists(mk):
+                os.remove(mk)
         bs = max(1, args.batch_size_per_gpu)
         nsaved = 0
         for i in range(0, len(rows), bs):
@@ -114,6 +159,9 @@ def extract_flows(args, t0):
                     os.makedirs(out, exist_ok=True)
                     img.save(os.path.join(out, 'flows_%08d.jpg' % nflows[k]))         # :254-262
                     nsaved += 1
+        for lab in set(want) - done:                 # every row of the video is on disk: the folder now counts as complete
+            with open(os.path.join(args.data_path, 'flows', lab, FLOW_MARKER), 'w') as fh:
+                json.dump({'count': want[lab], 'weights': weights, 'iters': args.raft_iters}, fh)
         print(f'[flow] {dataset}: {nsaved} flow maps saved' + (f' ({len(done)} videos already had flows)' if done else ''))
     print('All Flows Saved!')
     print('Time taken (s): %.3f' % (time.time() - t0))
@@ -140,6 +188,9 @@ def main():
     ap.add_argument('--raft_checkpoint', default=None, type=str,
                     help='--optical_flow: a RAFT state dict with the published key names (e.g. raft-things.pth); default: '
                          'seeded random weights (ptlflow and its checkpoint are unreachable offline: parity unpinned)')
+    ap.add_argument('--raft_random_weights', action='store_true',
+                    help='--optical_flow without a checkpoint: generate with seeded random weights anyway (smoke runs; the '
+                         'folder is marked so that a later run with a checkpoint regenerates it)')
     ap.add_argument('--raft_iters', default=12, type=int)
     args = ap.parse_args()
     if args.arch != 'vit_small' or args.patch_size != 16:

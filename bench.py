@@ -61,9 +61,17 @@ def parse_args():
     ap.add_argument("--vit-drop-path", type=float, default=0.1,
                     help="stochastic-depth rate of the ViT in train mode (the reference constructs it with 0.1: "
                          "extract_representations.py:201, main_dino.py:57)")
-    ap.add_argument("--workload", choices=("train", "dino"), default="train",
+    ap.add_argument("--workload", choices=("train", "dino", "extract"), default="train",
                     help="train = the headline step above (BASELINE.json); dino = one DINO pre-training step "
-                         "(SURVEY §8f-4: main_dino.py defaults, 64 images per GPU, 2 x 224 + 8 x 96 crops, out_dim 65536)")
+                         "(SURVEY §8f-4: main_dino.py defaults, 64 images per GPU, 2 x 224 + 8 x 96 crops, out_dim 65536); "
+                         "extract = BASELINE config 5, long-video inference: one 512-frame video per step through the frozen "
+                         "ViT (hipGraph, batches of 64), its 34 flow maps, then the 34 sliding windows x 3 TTA versions "
+                         "through the temporal encoder with the attention maps exported to the host")
+    ap.add_argument("--video-frames", type=int, default=512, help="--workload extract: frames of the synthetic video")
+    ap.add_argument("--extract-batch", type=int, default=64, help="--workload extract: frames per hipGraph replay")
+    ap.add_argument("--window-batch", type=int, default=2, help="--workload extract: windows per batch (main.sh: -bs 2)")
+    ap.add_argument("--grad-payload", choices=("fp32", "bf16"), default="fp32",
+                    help="N > 1: what the gradient all-reduce carries (bf16 = half the xGMI bytes, sums rounded to bf16)")
     ap.add_argument("--dino-batch", type=int, default=64, help="--workload dino: images per GPU (batch_size_per_gpu)")
     ap.add_argument("--dino-local-crops", type=int, default=8)
     ap.add_argument("--dino-out-dim", type=int, default=65536)
@@ -168,7 +176,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(T, C, threads, weights):
+def cpu_baseline(T, C, threads, weights, Bfull=8):
     """CPU oracle (fp32 torch restatement of the reference, pinned to its golden vectors) on bounded samples of the
     configurations BASELINE.md §3 lists, with the TIMED model's own weights (`weights` = its ViT / temporal state dicts and
     prototypes on the host).  `value` = config 2's model on one 32-frame clip, fwd+bwd+SGD (the same figure as round 1);
@@ -214,18 +222,20 @@ def cpu_baseline(T, C, threads, weights):
         dt = (time.time() - t0) / n
         return round(B * Tn / dt, 2), n
 
-    main, n_main = leg(1, T, 4, True, 12.0, 10)
+    # the headline leg IS the benchmarked configuration (B clips of T frames, fwd+bwd+SGD): 3 timed steps after one warm-up
+    # (~15 s each on 32 cores: BASELINE.md §3 asks for >= 3); the other legs are a few seconds each
+    main, n_main = leg(Bfull, T, 4, True, 1e9, 3)
     variants = {}
     for name, (B, Tn, nl, train, budget, mx) in {
-            "config1_B1_T16_1layer_fwd": (1, 16, 1, False, 2.0, 5),
-            "config1_B1_T16_1layer_fwd_bwd": (1, 16, 1, True, 3.0, 5),
-            f"config2_B1_T{T}_fwd": (1, T, 4, False, 3.0, 5),
-            f"config2_B8_T{T}_fwd_bwd_sgd": (8, T, 4, True, 25.0, 2)}.items():
+            "config1_B1_T16_1layer_fwd": (1, 16, 1, False, 1.5, 3),
+            "config1_B1_T16_1layer_fwd_bwd": (1, 16, 1, True, 2.5, 3),
+            f"config2_B1_T{T}_fwd": (1, T, 4, False, 2.0, 3),
+            f"config2_B1_T{T}_fwd_bwd_sgd": (1, T, 4, True, 6.0, 4)}.items():
         v, n = leg(B, Tn, nl, train, budget, mx)
         variants[name] = {"frames_per_s": v, "timed_steps": n}
     return dict(value=main, unit="frames/s", cores=threads, kind="port", cpu=cpu_model_name(),
-                sample=f"1 clip x {T} frames (B=1), 4-layer temporal encoder, fwd+bwd+SGD, fp32, {n_main} timed steps "
-                       f"after 1 warm-up, torch {torch.__version__} CPU oracle",
+                sample=f"{Bfull} clips x {T} frames (the timed batch shape), 4-layer temporal encoder, fwd+bwd+SGD, fp32, "
+                       f"{n_main} timed steps after 1 warm-up, torch {torch.__version__} CPU oracle",
                 variants=variants)
 
 
@@ -357,6 +367,206 @@ def dino_main(args):
         dist.destroy_process_group()
 
 
+FLOP_PER_FRAME_FWD = 9.197e9          # ViT-S/16 forward, 197 tokens
+
+
+def extract_cpu_baseline(threads, vsd, tsd, window_batch):
+    """Forward-only CPU leg of config 5 on a bounded sample: a 60-frame video (4 flow maps, 4 windows x 3 TTA versions)
+    through the oracle's ViT and temporal encoder with the timed model's weights; value = RGB frames per second."""
+    import torch
+    import synth
+    from oracle import sais_oracle as O
+    from sais_amd.inference import gesture_windows, sample_window
+    torch.set_num_threads(threads)
+    N = 60
+    frames = synth.clips(seed=5, B=1, T=N)[0]
+    flow_frames = synth.clips(seed=6, B=1, T=N // 15)[0]
+
+    def video():
+        with torch.no_grad():
+            reps = torch.cat([O.vit_forward(vsd, frames[i:i + 30]) for i in range(0, N, 30)])
+            freps = O.vit_forward(vsd, flow_frames)
+            for s, e in gesture_windows(N):
+                xs, fs = sample_window(reps, freps, s, e)
+                for x, f in zip(xs, fs):
+                    x, f = x.unsqueeze(0), f.unsqueeze(0)
+                    O.temporal_forward(tsd, x, f, torch.zeros(1, 1, x.shape[2] + 1, dtype=torch.bool),
+                                       torch.zeros(1, 1, f.shape[2] + 1, dtype=torch.bool), "RGB-Flow")
+    video()
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < 8.0 and n < 10):
+        video()
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=round(N / dt, 2), unit="frames/s", cores=threads, kind="port", cpu=cpu_model_name(),
+                sample=f"a {N}-frame video (+ {N // 15} flow maps, {len(gesture_windows(N))} windows x 3 TTA versions), "
+                       f"forward only, fp32, {n} timed passes after 1 warm-up, torch {torch.__version__} CPU oracle")
+
+
+def extract_main(args):
+    """--workload extract = BASELINE config 5 (long-video inference, TP = 1).  One step = one synthetic video resident in
+    HBM: N frames (default 512) and their N // 15 flow maps through the frozen ViT-S/16 (extract_representations.py:351-378;
+    fixed batches of 64 replayed from one hipGraph), then every sliding window of prepare_dataset.py:1711-1725 (34 of
+    them) x 3 test-time-augmentation index sets through the two-stream temporal encoder, embeddings and the [34, 16, 16]
+    attention maps copied to the host as the reference saves them (train.py:113-119).  value = RGB frames per second.
+    N > 1: every rank runs its own video (independent shards, no collective on the data path: weak scaling)."""
+    import torch
+    import torch.distributed as dist
+    import synth
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    backend = os.environ.get("SAIS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist_on = world > 1
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    from sais_amd import ops
+    from sais_amd.inference import FeatureExtractor, gesture_windows, run_windows
+    from sais_amd.temporal import fullModel
+    from sais_amd.vit import vit_small
+    N, bs = args.video_frames, args.extract_batch
+    torch.manual_seed(0)
+    vit = vit_small(patch_size=16).to(dev).eval()
+    model = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB-Flow').to(dev).eval()
+    frames = synth.clips(seed=5 + rank, B=1, T=N)[0].to(dev)                     # resident in HBM
+    flow_frames = synth.clips(seed=1000 + rank, B=1, T=max(1, N // 15))[0].to(dev)
+    fx = FeatureExtractor(vit, batch_size=bs, use_graph=not args.no_graph)
+    nwin = len(gesture_windows(N))
+
+    def step():
+        reps = fx(frames)
+        freps = fx(flow_frames)
+        out, attention, _ = run_windows(model, reps, freps, videoname="synthetic", batch_size=args.window_batch)
+        return reps, freps, out, attention
+
+    for _ in range(max(1, args.warmup)):
+        reps, freps, out, attention = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        reps, freps, out, attention = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        tmax = torch.tensor([dt], device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    if rank != 0:
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    # where the step's time goes: the two halves timed separately (same inputs, after the timed region)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        fx(frames); fx(flow_frames)
+    torch.cuda.synchronize()
+    ms_vit = (time.perf_counter() - t1) / 5 * 1e3
+    t1 = time.perf_counter()
+    for _ in range(5):
+        run_windows(model, reps, freps, videoname="synthetic", batch_size=args.window_batch)
+    torch.cuda.synchronize()
+    ms_win = (time.perf_counter() - t1) / 5 * 1e3
+    # parity gate: four frames of the timed video and three windows against the CPU oracle, same weights
+    from oracle import sais_oracle as O
+    from sais_amd.inference import sample_window
+    vsd = {k: v.detach().float().cpu() for k, v in vit.state_dict().items()}
+    tsd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    idx = sorted({0, min(bs - 1, N - 1), min(bs, N - 1), N - 1})
+    with torch.no_grad():
+        ref = O.vit_forward(vsd, frames[idx].cpu())
+    feat_rel = float((reps[idx].cpu() - ref).abs().max() / ref.abs().max())
+    wins = gesture_windows(N)
+    rc, fc = reps.cpu(), freps.cpu()
+    attn = torch.cat(attention)
+    pr = synth.prototypes(2, 2)
+    dl = da = 0.0
+    for w in sorted({0, 1, nwin - 1}):
+        xs, fs = sample_window(rc, fc, *wins[w])
+        for v in range(3):
+            x, f = xs[v].unsqueeze(0), fs[v].unsqueeze(0)
+            with torch.no_grad():
+                e_ref, a_ref = O.temporal_forward(tsd, x, f, torch.zeros(1, 1, x.shape[2] + 1, dtype=torch.bool),
+                                                  torch.zeros(1, 1, f.shape[2] + 1, dtype=torch.bool), "RGB-Flow")
+            dl = max(dl, float((O.cosine_logits(out["reps"][v][w].unsqueeze(0), pr) - O.cosine_logits(e_ref, pr)).abs().max()))
+            if v == 0:
+                da = max(da, float((attn[w] - a_ref[0]).abs().max()))
+    parity = dict(max_abs_feature_rel=round(feat_rel, 6), max_abs_logit=round(dl, 7), max_abs_attn=round(da, 7),
+                  tolerance_logit=1e-3, frames_checked=len(idx), windows_checked=len({0, 1, nwin - 1}),
+                  what="features of the timed video (hipGraph replay) and the temporal half at the GPU's own features vs "
+                       "the fp32 CPU oracle, same weights; logits = cosines against seeded prototypes")
+    parity["pass"] = bool(dl <= 1e-3 and da <= 2e-3 and feat_rel <= 2e-2)
+    # instrumented pass: HIP events around every MFMA kernel of one eager video (the replayed graph holds the same launches)
+    ops.TIMER = ops.KernelTimer()
+    fe = FeatureExtractor(vit, batch_size=bs, use_graph=False)
+    fe(frames); fe(flow_frames)
+    torch.cuda.synchronize()
+    summ, ops.TIMER = ops.TIMER.summary(), None
+    kern = max(summ, key=lambda t: summ[t]["total_ms"])
+    k = summ[kern]
+    ach = k["flops"] / (k["avg_ms"] * 1e-3) / 1e12
+    fps = world * N * args.steps / dt
+    nvit = N + max(1, N // 15)
+    out_line = {
+        "metric": "frames/sec ViT-S/16 long-video inference (extraction + sliding windows + attention export)",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 5: {N}-frame synthetic video per GPU, frozen ViT-S/16 forward in hipGraph-replayed "
+                               f"batches of {bs} (+ {nvit - N} flow maps), {nwin} sliding windows x 3 TTA versions through the "
+                               f"two-stream 4-layer temporal encoder (window batch {args.window_batch}, main.sh's -bs), embeddings "
+                               f"+ attention maps [{nwin},16,16] exported to the host; random-init weights",
+                   "video_frames": N, "vit_frames_per_step": nvit, "windows": nwin, "parallelism": f"shards{world}",
+                   "launch": "hipGraph replay (ViT) + eager windows" if not args.no_graph else "eager"},
+        "split_ms": {"vit_extraction": round(ms_vit, 3), "windows_and_export": round(ms_win, 3)},
+        "vit_forward_tflops": round(nvit * FLOP_PER_FRAME_FWD / (ms_vit * 1e-3) / 1e12, 1),
+        "frac_of_mfma_roofline": round(nvit * FLOP_PER_FRAME_FWD * args.steps / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
+        "parity": parity,
+        "roofline": {"bound": "mfma", "kernel": kern, "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_bytes": int(k["bytes"]),
+                     "hbm_gbps_algorithmic": round(k["bytes"] / (k["avg_ms"] * 1e-3) / 1e9, 1),
+                     "avg_launch_us": round(k["avg_ms"] * 1e3, 1), "launches_per_step": k["launches"],
+                     "timing": "raw HIP-event interval per launch in one eager pass over the video after the timed region",
+                     "all_kernels": {n: dict(ms_per_step=round(v["total_ms"], 3), launches_per_step=v["launches"],
+                                             avg_us=round(v["avg_ms"] * 1e3, 1),
+                                             tflops=round(v["flops"] / (v["avg_ms"] * 1e-3) / 1e12, 1),
+                                             gbps=round(v["bytes"] / (v["avg_ms"] * 1e-3) / 1e9, 1)) for n, v in summ.items()}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        out_line["cpu_baseline"] = extract_cpu_baseline(max(1, min(avail, 32)), vsd, tsd, args.window_batch)
+    if not parity["pass"]:
+        out_line["invalid"] = True
+        sys.stderr.write(f"bench.py: PARITY GATE FAILED: {parity}\n")
+    print(json.dumps(out_line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not parity["pass"]:
+        sys.exit(3)
+
+
 def parity_gate(vit, model, protos, frames, pad, labels, B, T, C, two, nclips):
     """BASELINE.md §3 / perform_training.py:119-127: the TIMED model on the TIMED inputs against the CPU oracle, in the same
     run.  One train-mode forward of the whole batch on the GPU (temporal dropout and ViT DropPath on, as timed); the draws
@@ -438,6 +648,8 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     if args.workload == "dino":
         return dino_main(args)
+    if args.workload == "extract":
+        return extract_main(args)
 
     import torch
     import torch.distributed as dist
@@ -477,7 +689,7 @@ def main():
     pad = synth.padding_mask([T] * B).to(dev)
     labels = synth.labels(seed=rank, B=B, nclasses=C)
     from sais_amd.parallel import GradSync
-    sync = GradSync(world, active=dist_on)
+    sync = GradSync(world, active=dist_on, payload_dtype=torch.bfloat16 if args.grad_payload == "bf16" else None)
     comm_events = CommEvents() if dist_on else None
     step = make_step(vit, model, protos, opt, sync, frames, pad, labels, B, T, world, dist_on, comm_events, two_stream=two)
     vit(frames[:2])                                          # builds the flat buffers
@@ -586,7 +798,7 @@ def main():
                     exposed_comm_ms_per_step=round(sum(a.elapsed_time(b) for a, b, _, _ in r) / len(r), 3),
                     exposed_comm_measured_in="eager instrumented passes after the timed region (HIP events around the "
                                              "join; events cannot be timed inside a captured graph)",
-                    payload_dtype="fp32",
+                    payload_dtype=args.grad_payload,
                     buckets=[dict(kind=k, mbytes=round(b / 2 ** 20, 2), slices=n) for k, b, n in sync.last_buckets],
                     bucket_rule=f">= {sync.bucket_bytes >> 20} MiB of adjacent flat-gradient slices per all-reduce, in "
                                 f"backward (reverse-layer) order; slices < {sync.small_bytes >> 20} MiB packed into one",
@@ -612,6 +824,7 @@ def main():
                     traffic=(pmc or {}).get("hbm_bytes_per_launch"),
                     traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, collected "
                                    "offline; NOT a live counter)",
+                    traffic_collected=(load_pmc("pmc_traffic.json") or {}).get("_provenance"),
                     algorithmic_bytes=int(nbytes),
                     hbm_gbps_algorithmic=round(nbytes / (avg_ms * 1e-3) / 1e9, 1),
                     avg_launch_us=round(avg_ms * 1e3, 1), launches_per_step=k["launches"] // NPASS,
@@ -713,10 +926,21 @@ def main():
                        {k: v.detach().float().cpu() for k, v in model.state_dict().items()
                         if not k.startswith(("clip_", "transEncoderClip", "attention", "finalModules", "linear2"))},
                        {k: v.detach().float().cpu() for k, v in protos.items()})
-            out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)), weights)
+            out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)), weights, Bfull=B)
+        # a number from a numerically wrong step is not a result: the line says so and the exit code is non-zero
+        bad = (parity is not None and not parity["pass"]) or bool(graph_check and graph_check.get("mismatch"))
+        if bad:
+            out["invalid"] = True
         print(json.dumps(out), flush=True)
+    else:
+        bad = False
     if dist_on:
+        flag = torch.tensor([1 if bad else 0], device=dev)
+        dist.broadcast(flag, src=0)                       # every rank leaves with rank 0's verdict
+        bad = bool(flag.item())
         dist.destroy_process_group()
+    if bad:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 9
+#define SAIS_ABI_VERSION 10
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -145,6 +145,14 @@ typedef struct SaisTnItem {
     float* db;                     /* f32 [N1] or NULL         */
 } SaisTnItem;
 int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream);
+/* ABI 10: the same launch with a caller-provided slab workspace.  For the wide-tile regime (every N2 % 384 == 0, M % 64 == 0,
+ * M >= 8192) the M-splits then store their raw partial tiles into `slabs` and a second launch sums them in a FIXED order into
+ * dW / db: no fp32 atomics (7 splits x 7.1 MB of them per ViT block before), bit-reproducible weight gradients.
+ * sais_gemm_tn_grouped_slab_bytes returns the bytes that launch needs (0: the regime does not apply, slabs is ignored);
+ * slabs 16-B aligned; NULL = the atomic form.  The slab form is OPT-IN: it runs only with SAIS_TN_SLABS=1 in the environment
+ * (deterministic gradients; measured ~5 % slower than the atomics on MI355X, LABNOTES R5.1), otherwise `slabs` is ignored.  */
+size_t sais_gemm_tn_grouped_slab_bytes(const SaisTnItem* items, int nitems, int M);
+int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int M, int nsplit, void* slabs, size_t slab_bytes, void* stream);
 /* the same with FP32 P and Q (rounded to bf16 while staging, like sais_gemm_tn_f32): one launch for the four weight
  * gradients of a temporal-encoder layer                                                                        */
 int sais_gemm_tn_grouped_f32(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream);

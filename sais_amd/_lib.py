@@ -141,6 +141,8 @@ SIGNATURES = {
     "sais_transpose_f32": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_gemm_tn_grouped": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p],
     "sais_gemm_tn_grouped_f32": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p],
+    "sais_gemm_tn_grouped_ws": [ctypes.POINTER(SaisTnItem), c_int, c_int, c_int, c_void_p, ctypes.c_size_t, c_void_p],
+    "sais_gemm_tn_grouped_slab_bytes": [ctypes.POINTER(SaisTnItem), c_int, c_int],
     "sais_gemm_tn": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "sais_layernorm_fwd": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p,
                            c_long, c_void_p, c_void_p, c_void_p],
@@ -242,6 +244,7 @@ def load():
         fn.restype = c_int
     lib.sais_preprocess_plan_destroy.restype = None
     lib.sais_workspace_bytes.restype = ctypes.c_size_t
+    lib.sais_gemm_tn_grouped_slab_bytes.restype = ctypes.c_size_t
     lib.sais_last_error.restype = ctypes.c_char_p
     lib.sais_last_error.argtypes = []
     _lib = lib

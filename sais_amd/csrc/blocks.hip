@@ -28,14 +28,23 @@ int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, in
 #define TRY(x) do { int rc_ = (x); if (rc_ != SAIS_OK) return rc_; } while (0)
 }  // namespace
 
+// slab workspace of the block's grouped weight-gradient launch (sais_gemm_tn_grouped_ws; 0 outside its wide-tile regime)
+static size_t block_dw_slab_bytes(int M) {
+    const SaisTnItem shape[4] = {{nullptr, D, nullptr, HID, D, HID, nullptr, HID, nullptr},
+                                 {nullptr, HID, nullptr, D, HID, D, nullptr, D, nullptr},
+                                 {nullptr, D, nullptr, D, D, D, nullptr, D, nullptr},
+                                 {nullptr, QKV, nullptr, D, QKV, D, nullptr, D, nullptr}};
+    return sais_gemm_tn_grouped_slab_bytes(shape, 4, M);
+}
+
 extern "C" size_t sais_workspace_bytes(int op, int frames, int ntok) {
     if (frames <= 0 || ntok <= 0) return 0;
     const size_t M = (size_t)frames * ntok;
     switch (op) {
         case SAIS_OP_VIT_BLOCK_FWD:                    // GELU(u) when the caller does not keep it (inference)
             return up(M * HID * 2);
-        case SAIS_OP_VIT_BLOCK_BWD:                    // du, d(mid) bf16, d(attention out), dqkv, dxn (small-M regime)
-            return up(M * HID * 2) + 3 * up(M * D * 2) + up(M * QKV * 2);
+        case SAIS_OP_VIT_BLOCK_BWD:                    // du, d(mid) bf16, d(attention out), dqkv, dxn (small-M regime), dW slabs
+            return up(M * HID * 2) + 3 * up(M * D * 2) + up(M * QKV * 2) + up(block_dw_slab_bytes((int)M));
         case SAIS_OP_TEMPORAL_LAYER_FWD: {             // raw split-K slabs of out_proj, then of linear2 (the larger)
             const int m = frames * ntok;
             const int ns = sais_tgemm_nsplit(m, D, 2048) > sais_tgemm_nsplit(m, D, D) ? sais_tgemm_nsplit(m, D, 2048)
@@ -122,7 +131,9 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
     void* dxb = ws;            ws += up((size_t)M * D * 2);
     void* dao = ws;            ws += up((size_t)M * D * 2);
     void* dxn = ws;            ws += up((size_t)M * D * 2);
-    void* dqkv = ws;
+    void* dqkv = ws;           ws += up((size_t)M * QKV * 2);
+    void* slabs = ws;
+    const size_t slab_bytes = block_dw_slab_bytes(M);
     const bool fused = M >= ROW_GEMM_MIN_M;
     // MLP branch: du = (d . W2) * GELU'(u);  d(norm2 out) = du . W1;  norm2's backward adds the residual gradient
     TRY(gemm(a->dx16_in, D, w->fc2_wt, D, M, HID, D, SAIS_EPI_MUL_BF16, nullptr, du, HID, nullptr, 0, a->gelu_grad, HID, nullptr, stream));
@@ -154,7 +165,7 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
         const int cap = (M + 255) / 256;
         if (nsplit > cap) nsplit = cap;
         if (nsplit < 1) nsplit = 1;
-        TRY(sais_gemm_tn_grouped(items, 4, M, nsplit, stream));
+        TRY(sais_gemm_tn_grouped_ws(items, 4, M, nsplit, slab_bytes ? slabs : nullptr, slab_bytes, stream));
     }
     // dX of qkv + norm1's backward: the gradient of the block input
     if (fused) {

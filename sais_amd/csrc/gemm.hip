@@ -436,6 +436,148 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Four workgroups per CU (round 5).  LABNOTES R4.4: a workgroup of the eight-wave kernel above is a latency CHAIN (K loop ->
+// epilogue -> K loop; neither phase is slowed by what the CU's other workgroup does), so the launch takes tiles-per-workgroup x
+// chain length and what shortens it is more chains per CU.  Same 128 x 128 tile, same fill bytes per flop, but FOUR waves of
+// 64 x 64 (16 MFMAs per wave between barriers, as before; 8 instead of 12 fragment reads for them) and K in steps of 32:
+// 8-KiB stages, A ring of three + W ring of two = 40 KiB per workgroup, <= 128 VGPRs -> four workgroups = four chains per CU,
+// and no two waves of a workgroup share a SIMD (the barrier skew of the eight-wave form was the SIMD sibling).
+// LDS image: 64-B rows; the 16-B chunk c of row r sits at position c ^ qmap(r), which makes the ds_read_b128 fragment reads
+// conflict-free for the hardware's lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS).
+constexpr int QK = 32;
+constexpr int QTILE = 128 * QK * 2;              // 8 KiB per operand per stage
+DEVINL int qmap(int r) { const int q = (r >> 2) & 3; return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1); }
+DEVINL int swz64(int row, int chunk) { return row * 64 + ((chunk ^ qmap(row)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 4) void gemm_nt_w4q_kernel(NtParams p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 8 KiB, then W: 2 x 8 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, g = lane >> 4, li = lane & 15;
+    const int ntn = p.N / BN;
+    const int srow = lane >> 2, spos = lane & 3;
+    const bf16* asrc[2]; const bf16* bsrc[2];
+    auto set_tile = [&](int v, int& m0, int& n0) {
+        const int tile = xcd_remap(v, ntiles);
+        n0 = (tile % ntn) * BN; m0 = (tile / ntn) * BM;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 16 * (2 * wid + j) + srow;
+            const int c = spos ^ qmap(r);
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            asrc[j] = p.A + (size_t)m * p.lda + c * 8;
+            bsrc[j] = p.B + (size_t)(n0 + perm_row(r)) * p.ldb + c * 8;
+        }
+    };
+    char* const sW = smem + 3 * QTILE;
+    auto issue_a = [&](int kt) {
+        char* s = smem + (kt % 3) * QTILE + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(asrc[j] + kt * QK, s + j * 1024);
+    };
+    auto issue_w = [&](int kt) {
+        char* s = sW + (kt & 1) * QTILE + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bsrc[j] + kt * QK, s + j * 1024);
+    };
+    const int nk = p.K / QK;
+    constexpr bool LATE = EPI == SAIS_EPI_MUL_BF16 || EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16;
+    [[maybe_unused]] const int tk = nk >= 4 ? nk - 4 : 0;
+    [[maybe_unused]] unsigned pf_keep = 0;
+    constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32 || EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_PATCH_F32) ? 4
+                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 4 : 2;
+    const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 2 : 0));
+    int v = blockIdx.x, m0, n0;
+    if (v >= ntiles) return;
+    set_tile(v, m0, n0);
+    issue_a(0);
+    issue_w(0);
+    issue_a(1);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (;;) {
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        float bias[16];
+        EpiAux aux;
+        __builtin_amdgcn_s_setprio(2);
+        for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (LATE) {
+                // the bf16 aux tile of this wave (64 rows x 128 B) is first-touch HBM data and there are no registers to hold
+                // it during the K loop (64 accumulators + 32 fragment registers): one discarded dword per row pulls the 64
+                // lines into L2 three steps early (retired by this step's counted wait), the real loads follow the loop
+                if (kt == tk) {
+                    int m = m0 + wr * 64 + lane;
+                    m = m < p.M ? m : p.M - 1;
+                    const bf16* q = (const bf16*)p.aux + (size_t)m * p.ldaux + n0 + wc * 64;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_keep) : "v"(q) : "memory");
+                }
+            }
+            if (kt + 1 < nk) issue_w(kt + 1);
+            if (kt + 2 < nk) issue_a(kt + 2);
+            const char* sa = smem + (kt % 3) * QTILE;
+            const char* sb = sW + (kt & 1) * QTILE;
+            if constexpr (!LATE) {
+                if (kt == nk - 1) epilogue_loads<EPI>(p, m0 + wr * 64, li, n0 + wc * 64 + 16 * g, bias, aux);
+            }
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                fa[t] = *(const bf16x8*)(sa + swz64(wr * 64 + t * 16 + li, g));
+                fb[t] = *(const bf16x8*)(sb + swz64(wc * 64 + t * 16 + li, g));
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: only the epilogue's loads are out
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        const int cm0 = m0, cn0 = n0;
+        const int nv = v + gridDim.x;
+        const bool more = nv < ntiles;
+        if constexpr (LATE) {
+            asm volatile("" ::"v"(pf_keep));
+            epilogue_loads<EPI>(p, cm0 + wr * 64, li, cn0 + wc * 64 + 16 * g, bias, aux);
+        }
+        if (more) {
+            set_tile(nv, m0, n0);
+            issue_a(0);
+            issue_w(0);
+            issue_a(1);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = cm0 + wr * 64 + mt * 16 + li;
+            if (m >= p.M) continue;
+            float vv[16];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[4 * nt + r] = acc[mt][nt][r];
+            epilogue<EPI>(p, m, cn0 + wc * 64 + 16 * g, vv, bias, aux, mt);
+        }
+        if (!more) break;
+        v = nv;
+        // A'(0) and W'(0) must have landed; the two A'(1) pieces and this epilogue's stores may stay in flight
+        const int allow = (cm0 + BM <= p.M) ? nstores + 2 : 0;
+        if (allow == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (allow == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (allow == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
 #ifdef SAIS_NT_STAMP
 extern "C" int sais_debug_nt_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -2;
@@ -893,7 +1035,12 @@ struct TnWideGroup {
 // (212 -> 197 us per block inside the step.  Measured and dropped on this kernel: one bias MFMA per wave instead of four
 // on the wc = 0 waves, hand-counted vmcnt(12) instead of the compiler's vmcnt(7..4): no change either way — the kernel
 // is paced by the global fill stream, LABNOTES.md 4.2.)
-__global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
+// SLAB (round 5): instead of 96 fp32 atomicAdd instructions per wave at the very end (7 M-splits x 7.1 MB = 49.8 MB of
+// atomics that all 252 workgroups issue at the same moment; the chip retires ~1.3 TB/s of them), every workgroup stores its
+// raw 128 x 384 partial tile ONCE, in register order (16 B per lane, 1 KiB per wave-instruction), into the slab of its split;
+// tn_slab_finish_kernel sums the splits in a fixed order and adds the result to dW / db: deterministic gradients.
+template <bool SLAB>
+__global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp, float* slabs) {
     extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int split = wg / gp.ntiles;
@@ -1005,6 +1152,20 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
         if (st + 1 < nsteps) step(1, st + 1, stg[0]);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    if constexpr (SLAB) {
+        const int tg = (wg - split * gp.ntiles), zt = split * gp.ntiles + tg;
+        f32x4* o = (f32x4*)slabs + ((size_t)zt * 8 + wid) * (24 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) o[(i * 6 + j) * 64] = acc[i][j];
+        if (do_bias && li == 0) {
+            float* ob = slabs + (size_t)gridDim.x * (8 * 24 * 64 * 4) + (size_t)zt * 128 + wr * 64 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(ob + i * 16) = accb[i];
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1017,11 +1178,49 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp) {
         }
 }
 
+// grid (tiles, 8): block (t, w) sums wave w's part of tile t over the nsplit slabs (fixed order) and adds it to dW; block
+// (t, 0) also finishes the bias gradient of a tile in the first column block
+__global__ __launch_bounds__(256) void tn_slab_finish_kernel(TnWideGroup gp, const float* slabs, int nsplit) {
+    int t = blockIdx.x, it0 = 0;
+    const int tg = t, w = blockIdx.y;
+    while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;
+    if (it0 > 0) t -= gp.tile_end[it0 - 1];
+    const TnParams& p = gp.item[it0];
+    const int nt2 = p.N2 / WQ;
+    const int n1_0 = (t / nt2) * 128, n2_0 = (t % nt2) * WQ;
+    const int wr = w >> 2, wc = w & 3;
+    const size_t zstride = (size_t)gp.ntiles * 8 * (24 * 64);                 // f32x4 per split
+    const f32x4* base = (const f32x4*)slabs + ((size_t)tg * 8 + w) * (24 * 64);
+    for (int e = threadIdx.x; e < 24 * 64; e += 256) {
+        f32x4 sum = base[e];
+        for (int z = 1; z < nsplit; ++z) sum += base[z * zstride + e];
+        const int lane = e & 63, ij = e >> 6, i = ij / 6, j = ij - 6 * i, g = lane >> 4, li = lane & 15;
+        float* row = p.dW + (size_t)(n1_0 + wr * 64 + i * 16 + 4 * g) * p.ldw + n2_0 + wc * 96 + j * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[(size_t)r * p.ldw] += sum[r];
+    }
+    if (w == 0 && n2_0 == 0 && p.db && threadIdx.x < 128) {
+        const float* bb = slabs + (size_t)nsplit * zstride * 4 + (size_t)tg * 128 + threadIdx.x;
+        float sum = 0.f;
+        for (int z = 0; z < nsplit; ++z) sum += bb[(size_t)z * gp.ntiles * 128];
+        p.db[n1_0 + threadIdx.x] += sum;
+    }
+}
+
 }  // namespace
 
+// epilogues the four-workgroups-per-CU kernel is built for (the fp32-aux ones need 64 more registers than it has)
+static constexpr bool w4_epi(int e) {
+    return e == SAIS_EPI_BIAS_BF16 || e == SAIS_EPI_BIAS_GELU_GRAD_BF16 || e == SAIS_EPI_MUL_BF16 || e == SAIS_EPI_BIAS_GELU_BF16 ||
+           e == SAIS_EPI_BIAS_RELU_BF16;
+}
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        if (big) {                                                                          \
+        if (big && nt_w4 && w4_epi(E) && g->K >= 2 * QK) {                                  \
+            const int nt_ = (int)grid.x;                                                    \
+            hipLaunchKernelGGL(gemm_nt_w4q_kernel<E>, dim3(nt_ < 1024 ? nt_ : 1024), dim3(256), 5 * QTILE, \
+                               (hipStream_t)stream, p, nt_);                                \
+        } else if (big) {                                                                   \
             static thread_local bool set8p = false;                                         \
             if (!set8p) {                                                                   \
                 if (hipFuncSetAttribute((const void*)gemm_nt_w8p_kernel<E>,                 \
@@ -1056,6 +1255,7 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
     // four-wave A-ring) were measured slower inside the step and are gone from the library (LABNOTES.md 4.1).
     const bool big = g->M >= 8192;
+    static const bool nt_w4 = [] { const char* e = getenv("SAIS_NT_W4"); return e ? atoi(e) != 0 : false; }();
     if (g->epilogue == SAIS_EPI_RAW_SLABS_F32) {                // split-K over grp_in slices: small M only, raw fp32 slabs
         if (big || g->grp_in < 1 || g->grp_in > g->K / BK || g->ldo % 4) return SAIS_ERR_ARG;
         hipLaunchKernelGGL(gemm_nt_kernel<SAIS_EPI_RAW_SLABS_F32>, dim3(grid.x, g->grp_in), dim3(256), 0, (hipStream_t)stream, p);
@@ -1190,7 +1390,25 @@ static int launch_tn(const void* P, int ldp, const void* Q, int ldq, int M, int 
     return sais_check_launch();
 }
 
+extern "C" size_t sais_gemm_tn_grouped_slab_bytes(const SaisTnItem* items, int nitems, int M) {
+    if (!items || nitems <= 0 || nitems > SAIS_TN_MAX_ITEMS || M % TK || M < 8192) return 0;
+    int wt = 0;
+    for (int i = 0; i < nitems; ++i) {
+        if (items[i].N1 % 128 || items[i].N2 % WQ) return 0;
+        wt += (items[i].N1 / 128) * (items[i].N2 / WQ);
+    }
+    int wns = 256 / wt < 1 ? 1 : 256 / wt;
+    const int wrows = ((M + wns - 1) / wns + TK - 1) / TK * TK;
+    wns = (M + wrows - 1) / wrows;
+    return wns > 1 ? (size_t)wt * wns * (8 * 24 * 64 * 16 + 128 * 4) : 0;
+}
+
 extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream) {
+    return sais_gemm_tn_grouped_ws(items, nitems, M, nsplit, nullptr, 0, stream);
+}
+
+extern "C" int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int M, int nsplit, void* slabs, size_t slab_bytes,
+                                       void* stream) {
     SAIS_ENTER();
     if (!items || nitems <= 0 || nitems > SAIS_TN_MAX_ITEMS || M <= 0 || nsplit <= 0) return SAIS_ERR_ARG;
     int rows = (M + nsplit - 1) / nsplit;
@@ -1224,14 +1442,24 @@ extern "C" int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, 
         int wrows = ((M + wns - 1) / wns + TK - 1) / TK * TK;
         wns = (M + wrows - 1) / wrows;
         for (int i = 0; i < nitems; ++i) { wg.item[i] = gp.item[i]; wg.item[i].rows_per_split = wrows; }
-        auto* kern = gemm_tn_pp_kernel;
         static thread_local bool lds_set = false;
         if (!lds_set) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE) != hipSuccess)
+            if (hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE) != hipSuccess)
                 return SAIS_ERR_LAUNCH;
             lds_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg);
+        const size_t need = (size_t)wt * wns * (8 * 24 * 64 * 16 + 128 * 4);
+        // opt-in (SAIS_TN_SLABS=1): bit-reproducible weight gradients.  Measured SLOWER than the atomics (LABNOTES R5.1: 254 vs 240 us
+        // stand-alone, 12.86 vs 12.76 ms per step) — the atomic tail this was built to remove is not there.
+        static const bool use_slabs = [] { const char* e = getenv("SAIS_TN_SLABS"); return e ? atoi(e) != 0 : false; }();
+        if (slabs && wns > 1 && use_slabs) {
+            if (slab_bytes < need || ((uintptr_t)slabs & 15)) return SAIS_ERR_ARG;
+            hipLaunchKernelGGL(gemm_tn_pp_kernel<true>, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)slabs);
+            hipLaunchKernelGGL(tn_slab_finish_kernel, dim3(wt, 8), dim3(256), 0, (hipStream_t)stream, wg, (const float*)slabs, wns);
+        } else {
+            hipLaunchKernelGGL(gemm_tn_pp_kernel<false>, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)nullptr);
+        }
         return sais_check_launch();
     }
     hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total * ns), dim3(256), 0, (hipStream_t)stream, gp);

@@ -282,8 +282,27 @@ def gemm_tn_grouped(items, M, nsplit=None):
     # one tag per distinct launch shape: the full four-GEMM dW of a block, the last block's qkv-only and compact launches and
     # the temporal layers' are different kernels in all but name, and a pooled average would describe none of them
     tag = ("gemm_tn_grouped_f32" if f32 else "gemm_tn_grouped") + ("" if f32 else f"[{len(items)} GEMMs,M{M}]")
+    if f32:
+        _timed(tag, flops, nbytes, lambda: L.call("sais_gemm_tn_grouped_f32", arr, len(items), M, nsplit, _stream()))
+        return
+    # wide-tile regime (the dW of a ViT block at training size): raw split slabs + a fixed-order finish instead of fp32 atomics
+    need = L.load().sais_gemm_tn_grouped_slab_bytes(arr, len(items), M)
+    ws = _tn_slabs(need, items[0][0].device) if need else None
     _timed(tag, flops, nbytes,
-           lambda: L.call("sais_gemm_tn_grouped_f32" if f32 else "sais_gemm_tn_grouped", arr, len(items), M, nsplit, _stream()))
+           lambda: L.call("sais_gemm_tn_grouped_ws", arr, len(items), M, nsplit, _p(ws), need, _stream()))
+
+
+_TN_SLABS = {}
+
+
+def _tn_slabs(nbytes, device):
+    """One slab workspace per device, grown on demand (launches on a stream are ordered, so consecutive dW launches share it);
+    allocated outside any hipGraph capture pool by the eager warm-up steps that precede a capture."""
+    buf = _TN_SLABS.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _TN_SLABS[device] = buf
+    return buf
 
 
 def layernorm_fwd(x, rows, ldx, gamma, beta, eps, y16=None, y32=None, mean=None, rstd=None, ldy16=384, ldy32=384):

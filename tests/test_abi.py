@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib.sais_abi_version.restype = ctypes.c_int
-    assert lib.sais_abi_version() == 9
+    assert lib.sais_abi_version() == 10
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():
@@ -62,6 +62,15 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_FWD, 256, 197) >= M * 1536 * 2
     assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_BWD, 256, 197) >= M * (1536 + 3 * 384 + 1152) * 2
     assert lib.sais_workspace_bytes(99, 256, 197) == 0
+    # round 5 (ABI 10): slab workspace of the grouped weight-gradient launch (argument checks only: no GPU here)
+    items = (_lib.SaisTnItem * 4)()
+    for it, (n1, n2) in zip(items, ((384, 1536), (1536, 384), (384, 384), (1152, 384))):
+        it.N1, it.N2 = n1, n2
+    lib.sais_gemm_tn_grouped_slab_bytes.restype = ctypes.c_size_t
+    assert lib.sais_gemm_tn_grouped_slab_bytes(items, 4, M) == 36 * 7 * (128 * 384 * 4 + 512)      # 36 wide tiles x 7 M-splits
+    assert lib.sais_gemm_tn_grouped_slab_bytes(items, 4, 300) == 0 and lib.sais_gemm_tn_grouped_slab_bytes(None, 4, M) == 0
+    assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_BWD, 256, 197) >= M * (1536 + 3 * 384 + 1152) * 2 + 36 * 7 * 128 * 384 * 4
+    assert lib.sais_gemm_tn_grouped_ws(None, 4, M, 7, None, 0, None) == -1
     assert lib.sais_workspace_bytes(_lib.OP_TEMPORAL_LAYER_FWD, 8, 33) >= 8 * 264 * 384 * 4
     assert lib.sais_workspace_bytes(_lib.OP_TEMPORAL_LAYER_BWD, 8, 33) >= 264 * (3 * 384 + 2048 + 1152) * 4
     assert lib.sais_temporal_layer_fwd(None, None, None, 0, None) == -1

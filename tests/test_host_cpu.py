@@ -277,6 +277,47 @@ def test_replicas_start_from_rank0_state_and_agree_on_scalars_gloo_world2(tmp_pa
         assert (same, int(tmax), float(mean), raised) == ("True", 11, 1.5, "True")
 
 
+def _staged_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sais_amd.parallel import GradSync
+    g = torch.Generator().manual_seed(7 + rank)
+    flat = torch.randn(6_000_000, generator=g)                 # 24 MB "ViT" buffer: one bucket
+    small1, small2, small3 = (torch.randn(n, generator=g) for n in (300, 500, 77))
+    ref = [t.clone() for t in (flat, small1, small2, small3)]
+    for r in ref:
+        dist.all_reduce(r)
+    # (a) flush() -> another small slice -> wait(): TWO packs in flight, both must be scattered back
+    sync = GradSync(world)
+    f, a, b, c = flat.clone(), small1.clone(), small2.clone(), small3.clone()
+    sync._reduce(f); sync._reduce(a); sync._reduce(b)
+    sync.flush()
+    sync._reduce(c)                                            # a second backward call / TTA list element
+    sync.wait()
+    plan = [k for k, _, _ in sync.last_buckets]
+    exact = all(torch.equal(x, r) for x, r in zip((f, a, b, c), ref))
+    # (b) bf16 payload: half the bytes, sums within bf16 rounding of the fp32 exchange
+    lo = GradSync(world, payload_dtype=torch.bfloat16)
+    f2, a2 = flat.clone(), small1.clone()
+    lo._reduce(f2); lo._reduce(a2)
+    nbytes = lo.wait()
+    rel = float((f2 - ref[0]).norm() / ref[0].norm()), float((a2 - ref[1]).norm() / ref[1].norm())
+    open(out + f".{rank}", "w").write(f"{exact} {','.join(plan)} {nbytes} {rel[0]:.3e} {rel[1]:.3e} {f2.dtype == torch.float32}")
+    dist.destroy_process_group()
+
+
+def test_gradsync_two_packs_in_flight_and_bf16_payload_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res")
+    mp.spawn(_staged_worker, args=(2, 33500 + (os.getpid() % 2000), out), nprocs=2, join=True)
+    for r in range(2):
+        exact, plan, nbytes, rel_f, rel_a, f32 = open(out + f".{r}").read().split()
+        assert exact == "True" and plan == "bucket,packed,packed"
+        assert int(nbytes) == 2 * (6_000_000 + 300) and f32 == "True"          # bf16 on the wire, fp32 in the buffers
+        assert float(rel_f) <= 1e-2 and float(rel_a) <= 1e-2 and float(rel_f) > 0.0
+
+
 class _StubModel:
     """Stands in for fullModel in the CPU test of the sharded window loop: deterministic host arithmetic on the batch."""
     modalities, importance_loss = "RGB-Flow", False

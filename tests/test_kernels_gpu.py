@@ -534,6 +534,44 @@ def test_gemm_tn_grouped_matches_individual(ops, M):
             assert_close(db, rb, atol=1e-3 * math.sqrt(M))
 
 
+_SLAB_SCRIPT = r"""
+import math, sys, torch
+sys.path.insert(0, sys.argv[1])
+from sais_amd import ops
+M = 197 * 64
+g = torch.Generator().manual_seed(3)
+mk = lambda n: (torch.randn(M, n, generator=g)).to(torch.bfloat16).cuda()
+shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]
+ops_in = [(mk(a), mk(b)) for a, b in shapes]
+def run(times):
+    items = [(p, q, torch.zeros(p.shape[1], q.shape[1], device="cuda"), torch.zeros(p.shape[1], device="cuda")) for p, q in ops_in]
+    for _ in range(times):
+        ops.gemm_tn_grouped(items, M)
+    torch.cuda.synchronize()
+    return items
+a, b, twice = run(1), run(1), run(2)
+for (p, q, dW, db), (_, _, dW2, db2), (_, _, dW3, db3) in zip(a, b, twice):
+    assert torch.equal(dW, dW2) and torch.equal(db, db2), "slab mode must be bit-reproducible"
+    ref = p.float().t() @ q.float()
+    assert (dW - ref).abs().max().item() <= 2e-3 * math.sqrt(M) + 1e-4 * ref.abs().max().item()
+    assert (db - p.float().sum(0)).abs().max().item() <= 1e-3 * math.sqrt(M)
+    assert torch.allclose(dW3, 2 * dW, rtol=1e-6, atol=1e-4) and torch.allclose(db3, 2 * db, rtol=1e-6, atol=1e-4)   # accumulates (+=)
+print("SLAB_OK")
+"""
+
+
+def test_gemm_tn_grouped_slab_mode_deterministic_and_accumulating(ops):
+    """SAIS_TN_SLABS=1 (sais_gemm_tn_grouped_ws, ABI 10): the M-splits of the wide dW kernel write raw slabs and a fixed-order
+    finish adds them to dW / db: two runs are bit-identical, a second call accumulates.  The switch is read once per
+    process, so the check runs in a child."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _SLAB_SCRIPT, root], env=dict(os.environ, SAIS_TN_SLABS="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SLAB_OK" in r.stdout, r.stdout + r.stderr
+
+
 # ------------------------------------------------------------------ row-owning GEMM with LayerNorm in the epilogue
 def _ln_ref(x, gamma, beta, eps):
     return F.layer_norm(x, (384,), gamma, beta, eps)

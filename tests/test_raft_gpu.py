@@ -94,8 +94,18 @@ def test_optical_flow_stage_writes_the_flow_images(gpu, tmp_path):
     cmd = [sys.executable, sc("extract_representations.py"), "--arch", "vit_small", "--patch_size", "16", "--model_type",
            "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "2", "--data_path", data, "--data_list", "Custom",
            "--save_type", "h5", "--optical_flow", "--raft_iters", "3"]
+    # no checkpoint and no explicit request for random weights: refuse (non-zero), write nothing
+    r0 = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True)
+    assert r0.returncode != 0 and "--raft_checkpoint" in (r0.stderr + r0.stdout) and not (root / "flows").exists()
+    # a partial folder of an interrupted run does not count as done
+    (root / "flows" / "vid_01").mkdir(parents=True)
+    Image.fromarray(np.zeros((h, w, 3), np.uint8)).save(root / "flows" / "vid_01" / "flows_00000000.jpg")
+    cmd = cmd + ["--raft_random_weights"]
     r = subprocess.run(cmd, check=True, env=env, cwd=ROOT, capture_output=True, text=True)
-    assert "All Flows Saved!" in r.stdout
+    assert "All Flows Saved!" in r.stdout and "3 flow maps saved" in r.stdout
+    import json
+    mk = json.load(open(root / "flows" / "vid_01" / ".flows_complete.json"))
+    assert mk["count"] == 3 and mk["weights"].startswith("random")
     files = sorted(os.listdir(root / "flows" / "vid_01"))
     assert files == ["flows_00000000.jpg", "flows_00000001.jpg", "flows_00000002.jpg"]       # frames 0, 15, 30 (+15 each)
     first = np.asarray(Image.open(root / "flows" / "vid_01" / files[0]))
