@@ -805,6 +805,14 @@ def main():
                     payload="flat gradient slices handed over by the backward hooks (temporal encoder, then ViT blocks "
                             "last..first) and coalesced into buckets, captured into the step's hipGraph"
                             + ("" if use_graph else " (eager launch path)"))
+    # tests only (SAIS_BENCH_RANK_DUMP=<dir>): every rank leaves its own view of the exchange — the bucket plan must be the
+    # same list on every rank (collectives are matched by order), the data must differ (rank-seeded), the loss is its own
+    dump_dir = os.environ.get("SAIS_BENCH_RANK_DUMP")
+    if dump_dir:
+        with open(os.path.join(dump_dir, f"rank{rank}.json"), "w") as fh:
+            json.dump({"rank": rank, "world": world, "buckets": [list(b) for b in sync.last_buckets],
+                       "frames_checksum": float(frames.double().sum()), "loss": timed_loss,
+                       "payload": args.grad_payload}, fh)
     if rank == 0:
         summ = ops.TIMER.summary()
         ops.TIMER = None

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* qkv, long ldq
                                                        float* probs, float scale) {
     constexpr int NTOK = G::NTOK, NKT = G::NKT, NKS = G::NKS, MAT_BYTES = G::MAT_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    CLK_STAMP(10);
     char* sK = smem;
     char* sV = smem + MAT_BYTES;
     const int h = blockIdx.x, f = blockIdx.y;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
     constexpr int DQ_FIRST = NWAVES >= 16 ? 8 : 0, DQ_WAVES = NWAVES - DQ_FIRST;
     static_assert(NKT <= NWAVES, "one key tile per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    CLK_STAMP(11);
     char* const sQ = smem;
     char* const sO = smem + MAT_BYTES;
     char* const sK = smem + 2 * MAT_BYTES;
@@ -440,3 +442,5 @@ extern "C" int sais_vit_attn_bwd(const void* qkv, long ldqkv, const void* dout, 
     if (ntok == 37) return launch_bwd<Geo<37>>(qkv, ldqkv, dout, lddo, out, ldout, lse, frames, dqkv, lddqkv, stream);
     return SAIS_ERR_ARG;
 }
+
+CLK_EXPORT(attn)

@@ -162,3 +162,26 @@ static inline int sais_check_launch() {
     if (e != hipSuccess) sais_set_last_error((int)e);
     return e == hipSuccess ? SAIS_OK : SAIS_ERR_LAUNCH;
 }
+
+// SAIS_CLK_STAMP (diagnostic builds only, tools/clk_probe.py; MI355X_MICROARCH.md "DVFS give-back" item 6): workgroup 0 of a
+// stamped kernel records the shader-clock and the 100-MHz real-time ticks of its own lifetime, so that
+// in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz.  The values go to a table no kernel reads.
+#ifdef SAIS_CLK_STAMP
+static __device__ unsigned long long g_sais_clk[16][2];
+struct ClkStamp {
+    int id; unsigned long long t0, r0;
+    __device__ explicit ClkStamp(int i) : id(i), t0(__builtin_amdgcn_s_memtime()), r0(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ ~ClkStamp() {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            g_sais_clk[id][0] = __builtin_amdgcn_s_memtime() - t0;
+            g_sais_clk[id][1] = __builtin_amdgcn_s_memrealtime() - r0;
+        }
+    }
+};
+#define CLK_STAMP(id) ClkStamp clk_stamp_(id)
+#define CLK_EXPORT(name) extern "C" int sais_debug_clk_##name(unsigned long long* host_out) { \
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_sais_clk), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2; }
+#else
+#define CLK_STAMP(id) do { } while (0)
+#define CLK_EXPORT(name)
+#endif

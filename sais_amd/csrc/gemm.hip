@@ -273,6 +273,7 @@ __device__ unsigned long long g_nt_stamps[8][16];
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 3 x 16 KiB, then W: 2 x 16 KiB
+    CLK_STAMP(EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16 ? 1 : EPI == SAIS_EPI_MUL_BF16 ? 2 : 0);
     [[maybe_unused]] const int abl_role = (SAIS_NT_ABL & 4) ? (blockIdx.x & 1) : (SAIS_NT_ABL & 8) ? ((blockIdx.x >> 8) & 1) : -1;
     const bool do_k = !(SAIS_NT_ABL & 1) && abl_role != 1, do_e = !(SAIS_NT_ABL & 2) && abl_role != 0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1042,6 +1043,7 @@ struct TnWideGroup {
 template <bool SLAB>
 __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp, float* slabs) {
     extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
+    CLK_STAMP(3);
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int split = wg / gp.ntiles;
     int t = wg - split * gp.ntiles, it0 = 0;
@@ -1229,13 +1231,14 @@ static constexpr bool w4_epi(int e) {
                 set8p = true;                                                               \
             }                                                                               \
             const int nt_ = (int)grid.x;                                                    \
-            hipLaunchKernelGGL(gemm_nt_w8p_kernel<E>, dim3(nt_ < 512 ? nt_ : 512), dim3(512), 5 * TILE_BYTES, \
+            hipLaunchKernelGGL(gemm_nt_w8p_kernel<E>, dim3(nt_ < nt_grid ? nt_ : nt_grid), dim3(512), 5 * TILE_BYTES, \
                                (hipStream_t)stream, p, nt_);                                \
         } else                                                                              \
             hipLaunchKernelGGL(gemm_nt_kernel<E>, grid, dim3(256), 0, (hipStream_t)stream, p);  \
         break;
 
 extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream);      // gemm_row.hip: row-owning tiles, N = 384
+CLK_EXPORT(gemm)
 
 
 extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
@@ -1255,6 +1258,8 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     // (M >= 8192).  Round 1's other variants (wave-specialised, register-stationary, non-persistent eight-wave,
     // four-wave A-ring) were measured slower inside the step and are gone from the library (LABNOTES.md 4.1).
     const bool big = g->M >= 8192;
+    // persistent workgroups of the eight-wave kernel (2 per CU); SAIS_NT_GRID=256 = one per CU (diagnostic: LABNOTES R5.2)
+    static const int nt_grid = [] { const char* e = getenv("SAIS_NT_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
     static const bool nt_w4 = [] { const char* e = getenv("SAIS_NT_W4"); return e ? atoi(e) != 0 : false; }();
     if (g->epilogue == SAIS_EPI_RAW_SLABS_F32) {                // split-K over grp_in slices: small M only, raw fp32 slabs
         if (big || g->grp_in < 1 || g->grp_in > g->K / BK || g->ldo % 4) return SAIS_ERR_ARG;

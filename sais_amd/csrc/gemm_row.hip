@@ -65,6 +65,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_nt_row_kernel(RowParams p) {
     static_assert(!SPEC || NW == 8, "role-split staging needs the two wave groups");
     constexpr int ASLOTS = SPEC ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    CLK_STAMP(4 + (EPI == 2 ? 0 : EPI == 3 ? 1 : 2) * 2 + (p.K > 1200 ? 1 : 0));    // LN_FWD 4/5, LN_BWD 6/7, plain 8/9 (K <= / > 1200)
     constexpr int HALVES = NW / 4;                   // 112-row halves of the tile
     constexpr int ATILE = HALVES * RTILE;            // one A slot: 128 LDS rows per half
     constexpr int WP = 16 / NW;                      // LDS-DMA pieces (8 rows) of a W chunk per wave
@@ -374,3 +375,5 @@ extern "C" int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream) {
     p.rowscale = g->rowscale16;
     return launch_row<ROW_LN_BWD>(p, stream);
 }
+
+CLK_EXPORT(row)

@@ -554,6 +554,29 @@ class GraphedTrainStep:
         self.images, self.clip_grad, self.want_norms = list(images), clip_grad, want_norms
         self._graph, self._temp, self._out = None, None, None
 
+    def step_state(self):
+        """Snapshot of EVERYTHING the captured part of a step mutates besides the gradients (rebuilt every step): the DINO
+        centre (EMA), the student's DropPath RNG state, the gradient exchange's byte / log counters.  One list, one place:
+        whatever the captured region learns to mutate is added HERE, and test_graphed_train_step_equals_eager
+        compares a graphed loop across a re-capture with the eager loop."""
+        st = {"center": self.dino_loss.center.clone()}
+        bb = self.student.backbone
+        if bb._rng is not None:
+            st["student_droppath_rng"] = bb._rng.clone()
+        sync = getattr(self.optimizer, "_sync", None)
+        if sync is not None:
+            st["sync_counters"] = (sync.bytes, list(sync.log), list(sync.last_buckets))
+        return st
+
+    def load_step_state(self, st):
+        with torch.no_grad():
+            self.dino_loss.center.copy_(st["center"])
+            if "student_droppath_rng" in st:
+                self.student.backbone._rng.copy_(st["student_droppath_rng"])
+        sync = getattr(self.optimizer, "_sync", None)
+        if sync is not None and "sync_counters" in st:
+            sync.bytes, sync.log, sync.last_buckets = st["sync_counters"][0], list(st["sync_counters"][1]), list(st["sync_counters"][2])
+
     def _capture(self, epoch):
         fn = lambda: _forward_backward(self.student, self.teacher, self.dino_loss, self.optimizer, self.images, epoch,
                                        self.clip_grad, self.want_norms)
@@ -563,8 +586,10 @@ class GraphedTrainStep:
             fn()                                              # warm-up (its side effects are undone by the caller)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
-        # RCCL collectives inside: ProcessGroupNCCL's watchdog thread makes HIP calls of its own while this thread captures
-        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        # RCCL collectives inside (a gradient exchange is active): ProcessGroupNCCL's watchdog thread makes HIP calls of its own
+        # while this thread captures.  A process group that merely exists (world 1, no exchange) keeps the strict mode.
+        sync = getattr(self.optimizer, "_sync", None)
+        mode = "thread_local" if (sync is not None and getattr(sync, "active", False)) else "global"
         with torch.cuda.graph(self._graph, capture_error_mode=mode):
             self._out = fn()
         self._temp = float(self.dino_loss.teacher_temp_schedule[epoch])
@@ -577,16 +602,12 @@ class GraphedTrainStep:
             bb = self.student.backbone
             if self.dino_loss.center.device != dev:           # first call ever: DINOLoss would move it in the warm-up
                 self.dino_loss.center = self.dino_loss.center.to(dev, F32)
-            pre_c = self.dino_loss.center.clone()
-            pre_r = None if bb._rng is None else bb._rng.clone()
+            had_rng = bb._rng is not None
+            pre = self.step_state()
             self._capture(epoch)
-            with torch.no_grad():                             # undo the warm-up run: centre EMA and DropPath draws
-                self.dino_loss.center.copy_(pre_c)
-                if bb._rng is not None:
-                    if pre_r is not None:
-                        bb._rng.copy_(pre_r)
-                    else:                                     # the RNG state was created by the warm-up: back to its seed
-                        bb._rng.copy_(ops.rng_state(bb.drop_path_seed, dev))
+            if not had_rng and bb._rng is not None:           # the RNG state was created by the warm-up: back to its seed
+                pre["student_droppath_rng"] = ops.rng_state(bb.drop_path_seed, dev)
+            self.load_step_state(pre)                         # undo the warm-up run
         self._graph.replay()
         loss, norms = self._out
         self.optimizer._norms_fresh = norms is not None       # the replay computed them for THESE gradients

@@ -288,7 +288,10 @@ class VisionTransformer(nn.Module):
         xn, qkv, ao, h = e16(M, D), e16(M, 3 * D), e16(M, D), e16(M, HID)
         xn2 = e16(M, D)
         mean1 = rstd1 = None
-        prune = self.prune_last_block and not want_last_attn
+        # the CLS-only tail runs its [frames, 384] GEMMs on the split-K small-M kernel (SAIS_EPI_RAW_SLABS_F32: M < 8192 only), so a
+        # pass with 8192 or more FRAMES computes the last block on every row like the others (pruned=False is
+        # recorded in `saved`, the backward follows it)
+        prune = self.prune_last_block and not want_last_attn and Ftot < ops.ROW_GEMM_MIN_M
         blockcall = self.block_calls and ops.TIMER is None and len(groups) == 1 and fused
         for i in range(self.depth):
             p = f"blocks.{i}."

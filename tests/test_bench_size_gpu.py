@@ -8,7 +8,7 @@ F >= 42 frames, and the hipGraph replay of the training step is what `bench.py` 
   * config-2 step: eager launch vs GraphedStep replay from identical weights -> same loss, same gradients, same
     updated weights.
 
-Tolerances: logits 1e-3 max-abs (north star), features 3e-2 of max|ref|, gradients 4e-2 / 6e-2 relative L2 (bf16 MFMA
+Tolerances: logits 1e-3 max-abs (north star), features 2e-2 of max|ref|, gradients 4e-2 / 6e-2 relative L2 (bf16 MFMA
 operands, fp32 accumulation), graph-vs-eager gradients 1e-5 relative L2 (fp32 atomics reorder the dW sums).
 """
 import numpy as np
@@ -355,10 +355,10 @@ def test_outlier_weights_at_the_eight_wave_dispatch(gpu):
     dfeat = (reps[:B * T].cpu() - ref).abs().max().item() / ref.abs().max().item()
     dlogit = (sim.cpu() - sim_ref).abs().max().item()
     dattn = (attn.cpu() - a_ref).abs().max().item()
-    parity_log(tag + "features max-abs / max|ref|", dfeat, 3e-2)
+    parity_log(tag + "features max-abs / max|ref|", dfeat, 2e-2)
     parity_log(tag + "cosine logits max-abs", dlogit, LOGIT_TOL)
     parity_log(tag + "attention map max-abs", dattn, 2e-3)
-    assert dfeat <= 3e-2 and dlogit <= LOGIT_TOL and dattn <= 2e-3, (dfeat, dlogit, dattn)
+    assert dfeat <= 2e-2 and dlogit <= LOGIT_TOL and dattn <= 2e-3, (dfeat, dlogit, dattn)
 
 
 def test_config2_graph_replay_equals_eager_step(gpu):

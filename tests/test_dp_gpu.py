@@ -203,3 +203,31 @@ def test_bench_two_ranks_complete_and_print_one_line(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["comm"]["allreduce_bytes_per_step"] > 80e6 and d["value"] > 0 and d["roofline"]["all_kernels"]
+
+
+def test_bench_eight_ranks_over_gloo_on_one_gpu(tmp_path):
+    """World 8 without a second GPU: bench.py's distributed branch with eight ranks under torch.distributed.run,
+    exchanging through gloo and sharing cuda:0 (1 clip x 8 frames per rank, bf16 gradient payload).  Every rank must build
+    the SAME bucket list (collectives are matched by issue order: one rank with a different plan would hang or corrupt),
+    the ranks must hold DIFFERENT data (rank-seeded), and rank 0 prints exactly one line with n_gpus 8."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    dump = tmp_path / "ranks"
+    dump.mkdir()
+    env = dict(os.environ, SAIS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SAIS_BENCH_RANK_DUMP=str(dump))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--steps", "2", "--warmup", "1", "--clips", "1", "--frames", "8",
+                        "--sustain-seconds", "0", "--parity-clips", "0", "--grad-payload", "bf16"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["scaling"] == "weak" and d["value"] > 0
+    assert d["comm"]["payload_dtype"] == "bf16" and 40e6 < d["comm"]["allreduce_bytes_per_step"] < 70e6      # half of ~122 MB
+    ranks = [json.load(open(dump / f"rank{i}.json")) for i in range(8)]
+    assert all(x["world"] == 8 for x in ranks)
+    assert all(x["buckets"] == ranks[0]["buckets"] for x in ranks) and len(ranks[0]["buckets"]) >= 3
+    assert len({x["frames_checksum"] for x in ranks}) == 8, "every rank must draw its own clips"

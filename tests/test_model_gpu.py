@@ -4,7 +4,7 @@ reference itself, tests/golden/make_golden.py) and against the pinned CPU oracle
 Tolerances (stated here, used below):
   * class logits (cosine similarities)              <= 1e-3 max-abs   (north-star bar)
   * returned temporal attention maps                <= 2e-3 max-abs
-  * embeddings / ViT features (bf16 MFMA operands)  <= 3e-2 * max|ref|
+  * embeddings / ViT features (bf16 MFMA operands)  <= 2e-2 * max|ref|
   * gradients (bf16 operands, fp32 accumulation)    <= 4e-2 relative L2 per tensor
 """
 import numpy as np
@@ -16,7 +16,7 @@ import synth
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
-LOGIT_TOL, ATTN_TOL, FEAT_REL, GRAD_REL = 1e-3, 2e-3, 3e-2, 4e-2
+LOGIT_TOL, ATTN_TOL, FEAT_REL, GRAD_REL = 1e-3, 2e-3, 2e-2, 4e-2      # FEAT_REL: ONE bar with tests/test_bench_size_gpu.py (worst seen 1.7e-2, outlier fixture)
 
 
 @pytest.fixture(scope="module")

@@ -7,6 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd $R
+# the tree these numbers describe (the box has no .git: the caller passes the commit in SAIS_HEAD)
+echo "${SAIS_HEAD:-unknown}" > $O/HEAD
 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 cp gpurun_out/parity_worst.json $O/parity_worst.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log

@@ -81,6 +81,28 @@ def mean(v):
     return sum(v) / len(v) if v else 0.0
 
 
+def provenance():
+    """Which tree the counters describe: the files outlive kernel changes, so they carry the commit they were collected on
+    (the gpurun box has no .git: tools/gpu_validate.sh writes gpurun_out/<tag>/HEAD before the passes; else `git rev-parse`)."""
+    import datetime
+    import subprocess
+    head = None
+    for d in sys.argv[1:4]:
+        f = os.path.join(os.path.dirname(os.path.abspath(d)), "HEAD")
+        if os.path.exists(f):
+            head = open(f).read().strip()
+            break
+    dirty = None
+    if head is None:
+        try:
+            head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+            dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "sais_amd"], text=True).strip())
+        except Exception:
+            head = "unknown"
+    return {"head": head, "kernel_sources_modified_since_head": dirty,
+            "collected": datetime.date.today().isoformat(), "passes": [os.path.relpath(os.path.abspath(d), ROOT) for d in sys.argv[1:4]]}
+
+
 def main():
     sq, fetch, write = collect(sys.argv[1]), collect(sys.argv[2]), collect(sys.argv[3])
     mf = {}
@@ -99,8 +121,9 @@ def main():
             "lds_bank_conflict_ratio": round(g.get("SQ_LDS_BANK_CONFLICT", 0.0) / g["SQ_LDS_IDX_ACTIVE"], 4)
             if g.get("SQ_LDS_IDX_ACTIVE") else None,
         }
+    prov = provenance()
     json.dump({"collected_with": "rocprofv3 --pmc (one SQ pass) -- python3 bench.py --steps 2 --warmup 1 --no-graph",
-               "kernels": mf}, open(os.path.join(ROOT, "profiles", "pmc_mfma.json"), "w"), indent=1)
+               "_provenance": prov, "kernels": mf}, open(os.path.join(ROOT, "profiles", "pmc_mfma.json"), "w"), indent=1)
     tr = {}
     for n in sorted(set(fetch) & set(write)):
         f, w = mean(fetch[n].get("FETCH_SIZE", [])), mean(write[n].get("WRITE_SIZE", []))
@@ -115,6 +138,7 @@ def main():
     tr["_step"] = {"step_hbm_bytes": int(step_bytes), "steps_profiled": nsteps, "launches_per_step": per_step,
                    "note": "sum over the matched kernel families (all GEMM / attention / LayerNorm / SGD kernels; the "
                            "temporal-encoder kernels and elementwise torch kernels are not matched)"}
+    tr["_provenance"] = prov
     json.dump(tr, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print("step_hbm_bytes %.2f GB over %d steps" % (step_bytes / 1e9, nsteps))
     for n, v in mf.items():
