@@ -214,7 +214,7 @@ def main():
     flow = args.optical_flow_to_reps
     sub = 'flows' if flow else 'images'
     videos = [args.video] if args.video else sorted(os.listdir(os.path.join(args.data_path, sub)))
-    fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 256), use_graph=True)
+    fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 256), use_graph=True, tail_batch=64)
     reps = {}
     for v in videos:
         err = None

@@ -438,6 +438,145 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two eight-wave groups of ONE 1024-thread workgroup in ENFORCED anti-phase (round 5, LABNOTES R5.2).  Measured on the kernel
+// above (SAIS_NT_GRID, SAIS_NT_ABL builds): K loops alone 62.5 us with two workgroups per CU and 81 us with one, epilogues alone
+// 58 us (HBM-bound) either way, the whole kernel 141 us = MORE than their sum — the two workgroups of a CU run the same program
+// from the same start, so both are in their K loops together (each slowed by the other) and in their epilogues together (the
+// store path and HBM saturated, the matrix pipe idle), and a tile's first-touch A rows are fetched while every CU writes.
+// Here the two tile pipelines of a CU are two wave groups of one workgroup that share every s_barrier: group 0 runs the nk
+// K-steps of its tile while group 1 runs the epilogue of ITS previous tile in nk slices (one 16-row sub-tile per interval,
+// then idle intervals), and vice versa.  At any moment eight waves feed the matrix pipe and eight drain to HBM, the next
+// tile's first operands are requested a whole half-period ahead, and HBM sees a steady write stream.
+// Same tile, LDS image (2 x 80 KiB), epilogues and registers as the eight-wave kernel.  Needs nk >= 5.
+template <int EPI>
+__global__ __launch_bounds__(1024) void gemm_nt_w16_kernel(NtParams p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w16 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = w16 >> 3, wid = w16 & 7;
+    char* const smem = smem_all + grp * (5 * TILE_BYTES);            // this group's A ring (3 x 16 KiB) + W ring (2 x 16 KiB)
+    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
+    const int ntn = p.N / BN;
+    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
+    const bf16* asrc[2]; const bf16* bsrc[2];
+    auto set_tile = [&](int v, int& m0, int& n0) {
+        const int tile = xcd_remap(v, ntiles);
+        n0 = (tile % ntn) * BN; m0 = (tile / ntn) * BM;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 8 * (2 * wid + j) + sub;
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
+            bsrc[j] = p.B + (size_t)(n0 + perm_row32(r)) * p.ldb + schunk * 8;
+        }
+    };
+    char* const sW = smem + 3 * TILE_BYTES;
+    auto issue_a = [&](int kt) {
+        char* s = smem + (kt % 3) * TILE_BYTES + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(asrc[j] + kt * BK, s + j * 1024);
+    };
+    auto issue_w = [&](int kt) {
+        char* s = sW + (kt & 1) * TILE_BYTES + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(bsrc[j] + kt * BK, s + j * 1024);
+    };
+    const int nk = p.K / BK;
+    constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2 : (EPI == SAIS_EPI_PATCH_F32) ? 2
+                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
+    const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
+    // virtual workgroup ids: group 0 = blockIdx.x, group 1 = blockIdx.x + gridDim.x (same XCD); both walk with stride 2 G
+    const int G2 = 2 * (int)gridDim.x;
+    auto count = [&](int v0) { return v0 < ntiles ? (ntiles - v0 + G2 - 1) / G2 : 0; };
+    const int nA = count(blockIdx.x), nB = count(blockIdx.x + gridDim.x);
+    const int mine = grp ? nB : nA;
+    const int totA = 2 * nk * nA, totB = nB ? nk + 2 * nk * nB : 0;
+    const int total = totA > totB ? totA : totB;                     // barriers every wave of the workgroup takes
+    int done = 0;
+    auto bar = [&] { __builtin_amdgcn_s_barrier(); ++done; };
+    int v = blockIdx.x + grp * gridDim.x, m0 = 0, n0 = 0;
+    if (mine > 0) {
+        set_tile(v, m0, n0);
+        issue_a(0);
+        issue_w(0);
+        issue_a(1);
+    }
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1 && mine > 0)
+        for (int i = 0; i < nk; ++i) bar();                          // group 1 runs half a period behind
+    for (int t = 0; t < mine; ++t) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        float bias[8];
+        EpiAux8 aux;
+        __builtin_amdgcn_s_setprio(2);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue_w(kt + 1);
+            if (kt + 2 < nk) issue_a(kt + 2);
+            const char* sa = smem + (kt % 3) * TILE_BYTES;
+            const char* sb = sW + (kt & 1) * TILE_BYTES;
+            if (kt == nk - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[2];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) fa[tt] = *(const bf16x8*)(sa + swz(wr * 64 + tt * 16 + li, ks * 4 + g));
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) fb[tt] = *(const bf16x8*)(sb + swz(wc * 32 + tt * 16 + li, ks * 4 + g));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(fb[nt], fa[mt], acc[mt][nt]);
+            }
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // last step: only the epilogue's loads are out
+            bar();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // epilogue phase = nk intervals beside the OTHER group's K loop.  The next tile's first operands go out first: they
+        // have the whole phase to arrive.
+        const int cm0 = m0, cn0 = n0;
+        const bool more = t + 1 < mine;
+        if (more) {
+            v += G2;
+            set_tile(v, m0, n0);
+            issue_a(0);
+            issue_w(0);
+            issue_a(1);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = cm0 + wr * 64 + mt * 16 + li;
+            if (m < p.M) {
+                float vv[8];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vv[4 * nt + r] = acc[mt][nt][r];
+                epilogue8<EPI>(p, m, cn0 + wc * 32 + 8 * g, vv, bias, aux, mt);
+            }
+            bar();
+        }
+        for (int i = 4; i < nk - 1; ++i) bar();
+        // A'(0) and W'(0) must have landed before the phase's last barrier; the two A'(1) pieces and this epilogue's stores may
+        // stay in flight (vmcnt is in-order: they are younger)
+        const int allow = (more && cm0 + BM <= p.M) ? nstores + 2 : 0;
+        if (allow == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (allow == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (allow == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bar();
+    }
+    while (done < total) bar();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Four workgroups per CU (round 5).  LABNOTES R4.4: a workgroup of the eight-wave kernel above is a latency CHAIN (K loop ->
 // epilogue -> K loop; neither phase is slowed by what the CU's other workgroup does), so the launch takes tiles-per-workgroup x
 // chain length and what shortens it is more chains per CU.  Same 128 x 128 tile, same fill bytes per flop, but FOUR waves of
@@ -1218,7 +1357,18 @@ static constexpr bool w4_epi(int e) {
 }
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        if (big && nt_w4 && w4_epi(E) && g->K >= 2 * QK) {                                  \
+        if (big && nt_w16 && g->K / BK >= 5) {                                              \
+            static thread_local bool set16 = false;                                         \
+            if (!set16) {                                                                   \
+                if (hipFuncSetAttribute((const void*)gemm_nt_w16_kernel<E>,                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 10 * TILE_BYTES) != hipSuccess) \
+                    return SAIS_ERR_LAUNCH;                                                 \
+                set16 = true;                                                               \
+            }                                                                               \
+            const int nt_ = (int)grid.x, half_ = (nt_ + 1) / 2;                             \
+            hipLaunchKernelGGL(gemm_nt_w16_kernel<E>, dim3(half_ < 256 ? half_ : 256), dim3(1024), 10 * TILE_BYTES, \
+                               (hipStream_t)stream, p, nt_);                                \
+        } else if (big && nt_w4 && w4_epi(E) && g->K >= 2 * QK) {                           \
             const int nt_ = (int)grid.x;                                                    \
             hipLaunchKernelGGL(gemm_nt_w4q_kernel<E>, dim3(nt_ < 1024 ? nt_ : 1024), dim3(256), 5 * QTILE, \
                                (hipStream_t)stream, p, nt_);                                \
@@ -1260,6 +1410,7 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     const bool big = g->M >= 8192;
     // persistent workgroups of the eight-wave kernel (2 per CU); SAIS_NT_GRID=256 = one per CU (diagnostic: LABNOTES R5.2)
     static const int nt_grid = [] { const char* e = getenv("SAIS_NT_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    static const bool nt_w16 = [] { const char* e = getenv("SAIS_NT_W16"); return e ? atoi(e) != 0 : false; }();
     static const bool nt_w4 = [] { const char* e = getenv("SAIS_NT_W4"); return e ? atoi(e) != 0 : false; }();
     if (g->epilogue == SAIS_EPI_RAW_SLABS_F32) {                // split-K over grp_in slices: small M only, raw fp32 slabs
         if (big || g->grp_in < 1 || g->grp_in > g->K / BK || g->ldo % 4) return SAIS_ERR_ARG;

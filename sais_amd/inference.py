@@ -77,31 +77,72 @@ def pad_collate_tta(items):
     return out
 
 
+def collate_windows_tta(rgb_reps, flow_reps, wins):
+    """sample_window + pad_collate_tta over MANY windows of one video at once: the same dict of tensors as
+    pad_collate_tta([sample_window(rgb_reps, flow_reps, s, e) for s, e in wins]) (held to it in tests/test_host_cpu.py), built
+    with ONE gather per TTA version and stream instead of six small ones per window — the index arithmetic
+    (prepare_dataset.py:2642-2666: wrap-around -1, flow rows unique(idx // 15) < len(flow_reps)) runs on the host in numpy."""
+    dev = rgb_reps.device
+    nflow = flow_reps.shape[0]
+    B = len(wins)
+    out = {"x": [], "xpad": [], "xlens": [], "f": [], "fpad": [], "flens": []}
+    per_win = [tta_indices(s, e) for s, e in wins]
+    for v in range(len(TTA_OFFSETS)):
+        rgb_idx = [per_win[b][v] for b in range(B)]
+        flow_idx = [flow_rows(ix, nflow) for ix in rgb_idx]
+        for key, reps, idx in (("x", rgb_reps, rgb_idx), ("f", flow_reps, flow_idx)):
+            lens = [len(ix) for ix in idx]
+            maxT = max(lens)
+            ix = np.zeros((B, max(maxT, 1)), dtype=np.int64)
+            keep = np.zeros((B, max(maxT, 1)), dtype=bool)
+            for b, row in enumerate(idx):
+                ix[b, :len(row)] = row
+                keep[b, :len(row)] = True
+            g = reps[torch.from_numpy(ix).to(dev)]                        # negative indices wrap, as numpy does in the reference
+            g = (g * torch.from_numpy(keep).to(dev).unsqueeze(-1).to(g.dtype))[:, :maxT]
+            mask = torch.zeros(B, 1, maxT + 1, dtype=torch.bool)
+            for b, n in enumerate(lens):
+                mask[b, :, n + 1:] = True                                  # createPaddingMask :2798-2806
+            out[key].append(g.unsqueeze(1).contiguous())
+            out[key + "pad"].append(mask.to(dev))
+            out[key + "lens"].append(lens)
+    return out
+
+
 # --------------------------------------------------------------------------- ViT feature extraction
 class FeatureExtractor:
     """extractFeatures (:351-378) with the fixed-shape ViT forward captured once into a hipGraph and replayed per
     batch (the launch-bound part of inference: ~90 kernel launches per batch collapse into one graph launch)."""
 
-    def __init__(self, vit, batch_size=32, use_graph=True):
+    def __init__(self, vit, batch_size=32, use_graph=True, tail_batch=None):
+        """batch_size frames per replay; tail_batch (optional, < batch_size): a second, smaller captured shape for what is
+        left at the end of a video (and for short inputs such as the flow maps: 34 of them for a 512-frame video), so that a
+        large main batch — the GEMM kernels are most efficient from ~50 k token rows = 256 frames on — does not turn the
+        remainder into a mostly-padding replay."""
         self.vit = vit.eval()
         self.bs = batch_size
+        self.tail = tail_batch if tail_batch and tail_batch < batch_size else None
         self.use_graph = use_graph
-        self.graph = None
-        self.static_in = None
-        self.static_out = None
+        self._graphs = {}                                             # frames per replay -> (graph, static_in, static_out)
 
-    def _capture(self, device):
-        self.static_in = torch.zeros(self.bs, 3, 224, 224, device=device)
+    def _capture(self, device, bs):
+        static_in = torch.zeros(bs, 3, 224, 224, device=device)
         with torch.no_grad():
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(2):                                    # warm-up: allocator + LDS attributes + shadows
-                    self.vit(self.static_in)
+                    self.vit(static_in)
             torch.cuda.current_stream().wait_stream(s)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.static_out = self.vit(self.static_in)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self.vit(static_in)
+        self._graphs[bs] = (graph, static_in, static_out)
+
+    # the attributes older callers / tests read: the main shape's graph
+    @property
+    def graph(self):
+        return self._graphs.get(self.bs, (None,))[0]
 
     @torch.no_grad()
     def __call__(self, frames):
@@ -110,31 +151,42 @@ class FeatureExtractor:
             raise L.SaisHipError("FeatureExtractor needs device tensors: the HIP path has no CPU fallback")
         N = frames.shape[0]
         out = torch.empty(N, 384, device=frames.device)
-        if self.use_graph and self.graph is None:
-            self._capture(frames.device)
-        for i in range(0, N, self.bs):
-            n = min(self.bs, N - i)
+        i = 0
+        while i < N:
+            left = N - i
+            bs = self.bs if (left >= self.bs or self.tail is None) else self.tail
+            n = min(bs, left)
             if self.use_graph:
-                self.static_in[:n].copy_(frames[i:i + n])
-                if n < self.bs:
-                    self.static_in[n:].zero_()
-                self.graph.replay()
-                out[i:i + n].copy_(self.static_out[:n])
+                if bs not in self._graphs:
+                    self._capture(frames.device, bs)
+                graph, static_in, static_out = self._graphs[bs]
+                static_in[:n].copy_(frames[i:i + n])
+                if n < bs:
+                    static_in[n:].zero_()
+                graph.replay()
+                out[i:i + n].copy_(static_out[:n])
             else:
                 out[i:i + n] = self.vit(frames[i:i + n].float())
+            i += n
         return out
 
 
 # --------------------------------------------------------------------------- windowed temporal inference
 @torch.no_grad()
-def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, total_frames=None, rank=0, world_size=1):
+def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, total_frames=None, rank=0, world_size=1,
+                compute_batch=256):
     """The `Custom_inference` phase of single_epoch (perform_training.py:71-185) over one video.
     Returns the dict train.py:116 saves as reps_and_labels_<phase>, the attention list (:117) and the importance list
     (:118; per-batch [B,1,T+1,1] tensors with `-il`, else empty).  `total_frames` = the video's row count in
     paths/Custom_Paths.csv, which is what sizes the windows in the reference (prepare_dataset.py:1705-1727); default:
     the number of feature rows.
     world_size > 1: the batches of `batch_size` windows are the reference's own (same composition, same
-    padding), rank r runs a contiguous range of them and every rank returns the lists merged in batch order."""
+    padding), rank r runs a contiguous range of them and every rank returns the lists merged in batch order.
+    `batch_size` (main.sh: -bs 2) fixes the SHAPE of the outputs (one attention tensor per batch of that many windows, as
+    train.py:117 saves them); the arithmetic runs over up to `compute_batch` windows per call of the model — a window's
+    outputs do not depend on its batch mates (padding is masked, rows are independent), and 17 x 3 x 2 little forward passes
+    with a host round trip each were 63 % of a 512-frame video's inference time (LABNOTES R5.3).  Embeddings, attention
+    and importances leave the device ONCE at the end."""
     from .parallel import gather_in_rank_order, shard_range
     model.eval()
     wins = gesture_windows(rgb_reps.shape[0] if total_frames is None else total_frames)
@@ -142,23 +194,34 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
     attention, labels, names, importance = [], [], [], []
     starts = list(range(0, len(wins), batch_size))
     lo, hi = shard_range(len(starts), rank, world_size)
-    for i in starts[lo:hi]:
-        items = [sample_window(rgb_reps, flow_reps, s, e) for s, e in wins[i:i + batch_size]]
-        c = pad_collate_tta(items)
-        use_f = model.modalities in ("Flow", "RGB-Flow")
+    mine = wins[starts[lo]:starts[hi - 1] + batch_size] if hi > lo else []
+    use_f = model.modalities in ("Flow", "RGB-Flow")
+    cb = max(batch_size, (int(compute_batch) // batch_size) * batch_size)     # whole batches per call
+    emb_parts, attn_parts, imp_parts = ([], [], []), [], []
+    for i in range(0, len(mine), cb):
+        c = collate_windows_tta(rgb_reps, flow_reps, mine[i:i + cb])
         out = model(c["x"], c["f"] if use_f else None, c["xlens"], c["flens"], 'Prototypes', c["xpad"],
                     c["fpad"] if use_f else None, None)
         if model.importance_loss:                                    # (importances, embs, attn), prepare_model.py:445-446
             imp, embs, attn = out
-            importance.append(imp.detach().cpu())                    # perform_training.py:139-141
+            imp_parts.append(imp.detach())                           # perform_training.py:139-141
         else:
             embs, attn = out
         for v in range(3):
-            for b in range(len(items)):
-                reps[v].append(embs[v][b].detach().cpu())
-        attention.append(attn.detach().cpu())
-        labels += [torch.tensor(0, dtype=torch.long)] * len(items)          # placeholder label (:2637)
-        names += [videoname] * len(items)
+            emb_parts[v].append(embs[v].detach())
+        attn_parts.append(attn.detach())
+    if mine:
+        embs_cpu = [torch.cat(p).cpu() for p in emb_parts]           # ONE device -> host copy per output
+        attn_cpu = torch.cat(attn_parts).cpu()
+        imp_cpu = torch.cat(imp_parts).cpu() if imp_parts else None
+        for v in range(3):
+            reps[v].extend(e.clone() for e in embs_cpu[v].unbind(0))
+        for i in range(0, len(mine), batch_size):                    # the reference's per-batch tensors
+            attention.append(attn_cpu[i:i + batch_size].clone())
+            if imp_cpu is not None:
+                importance.append(imp_cpu[i:i + batch_size].clone())
+        labels += [torch.tensor(0, dtype=torch.long)] * len(mine)            # placeholder label (:2637)
+        names += [videoname] * len(mine)
     if world_size > 1:
         parts = gather_in_rank_order((reps, attention, labels, names, importance), world_size)
         reps = tuple([e for p in parts for e in p[0][v]] for v in range(3))

@@ -390,6 +390,25 @@ def test_window_sampler_and_tta_indices_follow_the_reference_quirks():
     assert c["flens"][0] == [2, 2] and tuple(c["f"][0].shape) == (2, 1, 2, 384)
 
 
+def test_vectorised_window_collate_equals_the_per_window_path():
+    """collate_windows_tta (one gather per TTA version and stream over ALL windows) builds exactly the tensors of
+    pad_collate_tta([sample_window(...)]) — first-window wrap-around, ragged flow rows, rows filtered at the end of the
+    flow features — for several video lengths and window subsets."""
+    from sais_amd.inference import collate_windows_tta, gesture_windows, pad_collate_tta, sample_window
+    g = torch.Generator().manual_seed(11)
+    for n, nflow in ((512, 34), (512, 33), (77, 5), (45, 3), (15, 1), (200, 14)):
+        rgb, flow = torch.randn(n, 384, generator=g), torch.randn(nflow, 384, generator=g)
+        wins = gesture_windows(n)
+        for sub in (wins, wins[:1], wins[1:4], wins[-2:]):
+            if not sub:
+                continue
+            a = collate_windows_tta(rgb, flow, sub)
+            b = pad_collate_tta([sample_window(rgb, flow, s, e) for s, e in sub])
+            for key in ("x", "f", "xpad", "fpad"):
+                assert len(a[key]) == 3 and all(x.shape == y.shape and torch.equal(x, y) for x, y in zip(a[key], b[key])), (n, key)
+            assert a["xlens"] == b["xlens"] and a["flens"] == b["flens"]
+
+
 def test_window_sampler_matches_the_reference_dataset(golden):
     """Frame / flow-row indices of every Custom_inference window and TTA version vs tests/golden/sampler.npz, which
     was produced by the reference's own VideoDataset.__getitem__ (make_golden_sampler.py)."""

@@ -106,7 +106,7 @@ def test_optical_flow_stage_writes_the_flow_images(gpu, tmp_path):
     import json
     mk = json.load(open(root / "flows" / "vid_01" / ".flows_complete.json"))
     assert mk["count"] == 3 and mk["weights"].startswith("random")
-    files = sorted(os.listdir(root / "flows" / "vid_01"))
+    files = sorted(f for f in os.listdir(root / "flows" / "vid_01") if not f.startswith("."))
     assert files == ["flows_00000000.jpg", "flows_00000001.jpg", "flows_00000002.jpg"]       # frames 0, 15, 30 (+15 each)
     first = np.asarray(Image.open(root / "flows" / "vid_01" / files[0]))
     assert first.shape == (h, w, 3) and first.std() > 1.0
