@@ -390,6 +390,13 @@ int sais_vit_attn_cls_bwd(const void* qkv, long ldqkv, const void* dout, long ld
 int sais_raft_corr_pool(const float* corr0, long ld0, int rows, int H, int W, float* l1, float* l2, float* l3, void* stream);
 int sais_raft_lookup(const float* l0, long ld0, const float* l1, const float* l2, const float* l3, const float* coords,
                      int B, int H, int W, int radius, float* out, void* stream);
+/* Convolution as a matrix-core GEMM (ABI 10; the RAFT encoders / update block, extract_representations.py:221-252 via ptlflow's
+ * `raft`): cols f32 [rows, ld] <- im2col of ONE image x f32 [C, H, W]; row = output position oy * Wo + ox, column
+ * (c * kh + ky) * kw + kx = the order of weight.view(Cout, C * kh * kw); column C*kh*kw holds 1.0 (append the bias to the weight
+ * matrix as that column), the remaining columns and the rows >= Ho * Wo are zero (pad ld to a multiple of 64 and rows to a
+ * multiple of 128 for sais_gemm_nt_f32).  y[Cout, Ho * Wo] = sais_gemm_nt_f32(A = weights [Cout, ld], B = cols) is NCHW.    */
+int sais_im2col_f32(const float* x, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                    float* cols, int ld, int rows, void* stream);
 
 /* ---------------------------------------------------------------- ViT embedding glue
  * PatchEmbed + prepare_tokens, vision_transformer.py:116-131,196-207.                            */

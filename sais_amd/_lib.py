@@ -156,6 +156,7 @@ SIGNATURES = {
     "sais_vit_attn_cls_bwd": [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_long, c_void_p],
     "sais_raft_corr_pool": [c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "sais_raft_lookup": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    "sais_im2col_f32": [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "sais_patchify": [c_void_p, c_int, c_int, c_void_p, c_void_p],
     "sais_vit_cls_rows": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "sais_vit_embed_bwd": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -448,6 +448,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 // then idle intervals), and vice versa.  At any moment eight waves feed the matrix pipe and eight drain to HBM, the next
 // tile's first operands are requested a whole half-period ahead, and HBM sees a steady write stream.
 // Same tile, LDS image (2 x 80 KiB), epilogues and registers as the eight-wave kernel.  Needs nk >= 5.
+#ifdef SAIS_NT_STAMP
+__device__ unsigned long long g_nt16_stamps[16][36];
+#endif
 template <int EPI>
 __global__ __launch_bounds__(1024) void gemm_nt_w16_kernel(NtParams p, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
@@ -494,7 +497,19 @@ __global__ __launch_bounds__(1024) void gemm_nt_w16_kernel(NtParams p, int ntile
     const int totA = 2 * nk * nA, totB = nB ? nk + 2 * nk * nB : 0;
     const int total = totA > totB ? totA : totB;                     // barriers every wave of the workgroup takes
     int done = 0;
+#ifdef SAIS_NT_STAMP
+    // lane 0 of every wave of workgroup 0 stamps the shader clock BEFORE and AFTER each of 18 consecutive barriers (from the
+    // 24th on: both groups are in steady state): arrival and release times of every interval (tools/nt16_stamp.py)
+    auto bar = [&] {
+        const int k = done - 24;
+        if (blockIdx.x == 0 && lane == 0 && k >= 0 && k < 18) g_nt16_stamps[w16][2 * k] = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        if (blockIdx.x == 0 && lane == 0 && k >= 0 && k < 18) g_nt16_stamps[w16][2 * k + 1] = __builtin_readcyclecounter();
+        ++done;
+    };
+#else
     auto bar = [&] { __builtin_amdgcn_s_barrier(); ++done; };
+#endif
     int v = blockIdx.x + grp * gridDim.x, m0 = 0, n0 = 0;
     if (mine > 0) {
         set_tile(v, m0, n0);
@@ -719,6 +734,9 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_w4q_kernel(NtParams p, int nti
 }
 
 #ifdef SAIS_NT_STAMP
+extern "C" int sais_debug_nt16_stamps(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt16_stamps), sizeof(unsigned long long) * 16 * 36) == hipSuccess ? 0 : -2;
+}
 extern "C" int sais_debug_nt_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -2;
 }

@@ -96,7 +96,53 @@ __global__ __launch_bounds__(256) void lookup_kernel(LookupParams p) {
     }
 }
 
+// im2col for the convolutions of the encoders and the update block (round 5: they run as bf16x3 matrix-core GEMMs on
+// sais_gemm_nt_f32 instead of MIOpen): cols[pos][k] = x[c][oy * sh - ph + ky][ox * sw - pw + kx], k = (c * kh + ky) * kw + kx
+// (the order of weight.view(Cout, Cin * kh * kw)), zero outside the image; column K = Cin * kh * kw holds 1.0 (the bias rides
+// in the GEMM as one more weight column), columns K + 1 .. ld - 1 and rows pos >= Ho * Wo are zero (the GEMM's padding).
+// One workgroup per 16 positions; consecutive threads write consecutive k of a row (coalesced 1-KiB segments), reads of x are
+// gathers out of L2 (an input element is read kh * kw times).
+struct Im2colParams {
+    const float* x; float* cols;
+    int C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo, K, ld, rows;
+};
+__global__ __launch_bounds__(256) void im2col_kernel(Im2colParams p) {
+    const int npos = p.Ho * p.Wo, khw = p.kh * p.kw;
+    for (int r = 0; r < 16; ++r) {
+        const int pos = blockIdx.x * 16 + r;
+        if (pos >= p.rows) return;
+        float* dst = p.cols + (size_t)pos * p.ld;
+        const int oy = pos / p.Wo, ox = pos - oy * p.Wo;
+        const int y0 = oy * p.sh - p.ph, x0 = ox * p.sw - p.pw;
+        for (int k = threadIdx.x; k < p.ld; k += 256) {
+            float v = 0.f;
+            if (pos < npos) {
+                if (k < p.K) {
+                    const int c = k / khw, rem = k - c * khw, ky = rem / p.kw, kx = rem - ky * p.kw;
+                    const int y = y0 + ky, xx = x0 + kx;
+                    if (y >= 0 && y < p.H && xx >= 0 && xx < p.W) v = p.x[((size_t)c * p.H + y) * p.W + xx];
+                } else if (k == p.K) {
+                    v = 1.0f;
+                }
+            }
+            dst[k] = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int sais_im2col_f32(const float* x, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                               float* cols, int ld, int rows, void* stream) {
+    SAIS_ENTER();
+    if (!x || !cols || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0) return SAIS_ERR_ARG;
+    const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+    const long K = (long)C * kh * kw;
+    if (Ho <= 0 || Wo <= 0 || ld < K + 1 || rows < Ho * Wo) return SAIS_ERR_ARG;
+    Im2colParams p{x, cols, C, H, W, kh, kw, sh, sw, ph, pw, Ho, Wo, (int)K, ld, rows};
+    hipLaunchKernelGGL(im2col_kernel, dim3((rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, p);
+    return sais_check_launch();
+}
 
 extern "C" int sais_raft_corr_pool(const float* corr0, long ld0, int rows, int H, int W, float* l1, float* l2, float* l3,
                                    void* stream) {

@@ -478,6 +478,44 @@ def raft_lookup(pyr, coords, radius=4):
     return out
 
 
+_CONV_W = {}
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
+    """torch.nn.functional.conv2d(x, weight, bias, stride, padding) [-> relu] for f32 NCHW on the matrix cores: per image an
+    im2col gather (sais_im2col_f32) and y[Cout, Ho Wo] = [weight | bias] . cols^T on the fp32-grade bf16x3 GEMM
+    (sais_gemm_nt_f32).  The padded [Cout, K + 1 -> 64 k] weight matrix is cached per parameter (inference weights are frozen:
+    keyed by storage pointer and version)."""
+    _chk(x, F32, "x")
+    B, C, H, W = x.shape
+    Cout, Cin, kh, kw = weight.shape
+    if Cin != C:
+        raise L.SaisHipError(f"conv2d: {C} input channels, weight expects {Cin}")
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    K = C * kh * kw
+    ld = (K + 1 + 63) // 64 * 64
+    rows = (Ho * Wo + 127) // 128 * 128
+    key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), ld)
+    wm = _CONV_W.get(key)
+    if wm is None:
+        wm = torch.zeros(Cout, ld, dtype=F32, device=x.device)
+        wm[:, :K] = weight.detach().reshape(Cout, K).float()
+        if bias is not None:
+            wm[:, K] = bias.detach().float()
+        if len(_CONV_W) > 256:
+            _CONV_W.clear()
+        _CONV_W[key] = wm
+    x = x.contiguous()
+    cols = torch.empty(rows, ld, dtype=F32, device=x.device)
+    y = torch.empty(B, Cout, rows, dtype=F32, device=x.device)
+    for b in range(B):
+        L.call("sais_im2col_f32", _p(x[b]), C, H, W, kh, kw, sh, sw, ph, pw, _p(cols), ld, rows, _stream())
+        gemm_nt_f32(wm, cols, L.EPI_BIAS_RELU_F32 if relu else L.EPI_BIAS_F32, y[b])
+    return y[:, :, :Ho * Wo].reshape(B, Cout, Ho, Wo)
+
+
 def touch(t):
     """Prefetch hint: pull a contiguous tensor towards the GPU's caches (include/sais_hip.h, sais_touch)."""
     if t is not None and t.numel() and t.is_contiguous():

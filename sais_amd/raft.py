@@ -6,10 +6,13 @@ SAIS/scripts/extract_representations.py:30-143,221-288 — `ptlflow.get_model('r
 PARITY UNPINNED: ptlflow 0.2.5 and its 'things' checkpoint are third-party artefacts absent from the reference tree and
 unreachable offline.  The network follows the published RAFT (Teed & Deng, ECCV 2020) with the published parameter names, so a
 `raft-things` state dict loads; without one the weights are seeded random (the stage then exercises the pipeline, not the
-physics).  First slice of the stage: the correlation volume — the all-pairs GEMM, its pyramid and the per-iteration window
-lookup, the parts of RAFT that are NOT convolutions — runs on this library's HIP kernels (include/sais_hip.h:
-sais_gemm_nt_f32, sais_raft_corr_pool, sais_raft_lookup); the encoders' and the update block's convolutions are torch
-modules on the device (MIOpen) for now.  No CPU path: the correlation ops raise on host tensors.
+physics).  The arithmetic of the stage runs on this library's HIP kernels (include/sais_hip.h): the correlation volume — the
+all-pairs GEMM (sais_gemm_nt_f32), its pyramid (sais_raft_corr_pool) and the per-iteration window lookup (sais_raft_lookup) —
+and, since round 5, EVERY convolution of the encoders, the motion encoder, the separable ConvGRU, the flow head and the
+upsampling-mask head: an im2col gather (sais_im2col_f32) + the fp32-grade bf16x3 matrix-core GEMM with the bias as one more
+weight column (`ops.conv2d`; no MIOpen / nn.Conv2d on the path).  What stays in torch is element-wise glue: the instance /
+batch normalisations (no learnable reduction across samples at inference), sigmoid / tanh of the GRU gates, concatenations,
+the softmax of the 9-neighbour upsampling mask.  No CPU path: every op raises on host tensors.
 """
 import math
 
@@ -22,15 +25,38 @@ from . import ops
 HDIM, LEVELS, RADIUS = 128, 4, 4
 
 
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+class _Conv(nn.Module):
+    """A convolution layer with nn.Conv2d's parameters (same names, shapes and default initialisation, so published state
+    dicts load) whose forward is ops.conv2d: im2col + the bf16x3 matrix-core GEMM of this library.  relu=True fuses the
+    activation that directly follows the layer into the GEMM's epilogue."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, relu=False):
+        super().__init__()
+        kh, kw = _pair(kernel_size)
+        self.stride, self.padding, self.relu = _pair(stride), _pair(padding), relu
+        self.weight = nn.Parameter(torch.empty(cout, cin, kh, kw))
+        self.bias = nn.Parameter(torch.empty(cout))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))                  # nn.Conv2d.reset_parameters
+        bound = 1.0 / math.sqrt(cin * kh * kw)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding, relu=self.relu)
+
+
 class _ResBlock(nn.Module):
     def __init__(self, cin, cout, norm, stride):
         super().__init__()
-        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1)
-        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1)
+        self.conv1 = _Conv(cin, cout, 3, stride, 1)
+        self.conv2 = _Conv(cout, cout, 3, 1, 1)
         self.norm1, self.norm2 = norm(cout), norm(cout)
         self.downsample = None
         if stride != 1:
-            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride))
+            self.downsample = nn.Sequential(_Conv(cin, cout, 1, stride))
             self.norm3 = norm(cout)
 
     def forward(self, x):
@@ -44,12 +70,12 @@ class _ResBlock(nn.Module):
 class _Encoder(nn.Module):
     def __init__(self, out_dim, norm):
         super().__init__()
-        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3)
+        self.conv1 = _Conv(3, 64, 7, 2, 3)
         self.norm1 = norm(64)
         self.layer1 = nn.Sequential(_ResBlock(64, 64, norm, 1), _ResBlock(64, 64, norm, 1))
         self.layer2 = nn.Sequential(_ResBlock(64, 96, norm, 2), _ResBlock(96, 96, norm, 1))
         self.layer3 = nn.Sequential(_ResBlock(96, 128, norm, 2), _ResBlock(128, 128, norm, 1))
-        self.conv2 = nn.Conv2d(128, out_dim, 1)
+        self.conv2 = _Conv(128, out_dim, 1)
 
     def forward(self, x):
         x = F.relu(self.norm1(self.conv1(x)))
@@ -59,14 +85,14 @@ class _Encoder(nn.Module):
 class _MotionEncoder(nn.Module):
     def __init__(self, cor_planes):
         super().__init__()
-        self.convc1, self.convc2 = nn.Conv2d(cor_planes, 256, 1), nn.Conv2d(256, 192, 3, padding=1)
-        self.convf1, self.convf2 = nn.Conv2d(2, 128, 7, padding=3), nn.Conv2d(128, 64, 3, padding=1)
-        self.conv = nn.Conv2d(256, 126, 3, padding=1)
+        self.convc1, self.convc2 = _Conv(cor_planes, 256, 1, relu=True), _Conv(256, 192, 3, padding=1, relu=True)
+        self.convf1, self.convf2 = _Conv(2, 128, 7, padding=3, relu=True), _Conv(128, 64, 3, padding=1, relu=True)
+        self.conv = _Conv(256, 126, 3, padding=1, relu=True)
 
-    def forward(self, flow, corr):
-        cor = F.relu(self.convc2(F.relu(self.convc1(corr))))
-        flo = F.relu(self.convf2(F.relu(self.convf1(flow))))
-        return torch.cat([F.relu(self.conv(torch.cat([cor, flo], 1))), flow], 1)
+    def forward(self, flow, corr):                       # every ReLU of the block rides in its convolution's epilogue
+        cor = self.convc2(self.convc1(corr))
+        flo = self.convf2(self.convf1(flow))
+        return torch.cat([self.conv(torch.cat([cor, flo], 1)), flow], 1)
 
 
 class _SepConvGRU(nn.Module):
@@ -74,7 +100,7 @@ class _SepConvGRU(nn.Module):
         super().__init__()
         for k, ks, pad in (("1", (1, 5), (0, 2)), ("2", (5, 1), (2, 0))):
             for n in "zrq":
-                setattr(self, f"conv{n}{k}", nn.Conv2d(hidden + inp, hidden, ks, padding=pad))
+                setattr(self, f"conv{n}{k}", _Conv(hidden + inp, hidden, ks, padding=pad))
 
     def forward(self, h, x):
         for k in "12":
@@ -89,10 +115,10 @@ class _SepConvGRU(nn.Module):
 class _FlowHead(nn.Module):
     def __init__(self):
         super().__init__()
-        self.conv1, self.conv2 = nn.Conv2d(128, 256, 3, padding=1), nn.Conv2d(256, 2, 3, padding=1)
+        self.conv1, self.conv2 = _Conv(128, 256, 3, padding=1, relu=True), _Conv(256, 2, 3, padding=1)
 
     def forward(self, x):
-        return self.conv2(F.relu(self.conv1(x)))
+        return self.conv2(self.conv1(x))
 
 
 class _UpdateBlock(nn.Module):
@@ -101,7 +127,7 @@ class _UpdateBlock(nn.Module):
         self.encoder = _MotionEncoder(LEVELS * (2 * RADIUS + 1) ** 2)
         self.gru = _SepConvGRU()
         self.flow_head = _FlowHead()
-        self.mask = nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, 576, 1))
+        self.mask = nn.Sequential(_Conv(128, 256, 3, padding=1), nn.ReLU(inplace=True), _Conv(256, 576, 1))     # keys mask.0 / mask.2
 
     def forward(self, net, inp, corr, flow):
         net = self.gru(net, torch.cat([inp, self.encoder(flow, corr)], 1))

@@ -71,6 +71,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.sais_gemm_tn_grouped_slab_bytes(items, 4, 300) == 0 and lib.sais_gemm_tn_grouped_slab_bytes(None, 4, M) == 0
     assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_BWD, 256, 197) >= M * (1536 + 3 * 384 + 1152) * 2 + 36 * 7 * 128 * 384 * 4
     assert lib.sais_gemm_tn_grouped_ws(None, 4, M, 7, None, 0, None) == -1
+    assert lib.sais_im2col_f32(None, 3, 8, 8, 3, 3, 1, 1, 1, 1, None, 64, 128, None) == -1
     assert lib.sais_workspace_bytes(_lib.OP_TEMPORAL_LAYER_FWD, 8, 33) >= 8 * 264 * 384 * 4
     assert lib.sais_workspace_bytes(_lib.OP_TEMPORAL_LAYER_BWD, 8, 33) >= 264 * (3 * 384 + 2048 + 1152) * 4
     assert lib.sais_temporal_layer_fwd(None, None, None, 0, None) == -1

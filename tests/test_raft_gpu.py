@@ -52,6 +52,43 @@ def test_correlation_pyramid_and_lookup_vs_oracle(gpu, H, W):
     assert float((got.cpu() - want).abs().max()) <= 1e-4 * scale
 
 
+@pytest.mark.parametrize("B,C,H,W,Cout,k,stride,pad,relu", [
+    (2, 3, 50, 67, 64, 7, 2, 3, False),            # the encoders' stem
+    (1, 64, 25, 34, 96, 3, 2, 1, False),           # a strided residual block
+    (1, 96, 13, 17, 128, 1, 2, 0, False),          # its 1 x 1 downsample
+    (2, 384, 16, 21, 128, (1, 5), 1, (0, 2), False),   # separable ConvGRU
+    (1, 384, 16, 21, 128, (5, 1), 1, (2, 0), False),
+    (1, 256, 16, 21, 126, 3, 1, 1, True),          # motion encoder (Cout not a multiple of anything) + fused ReLU
+    (1, 256, 16, 21, 2, 3, 1, 1, False),           # flow head
+    (1, 324, 16, 21, 256, 1, 1, 0, True)])
+def test_conv2d_on_the_matrix_cores_vs_torch(gpu, B, C, H, W, Cout, k, stride, pad, relu):
+    """ops.conv2d (im2col gather + bf16x3 GEMM, bias as a weight column) against torch.nn.functional.conv2d in fp64 on the
+    host: every convolution shape RAFT uses."""
+    import torch.nn.functional as F
+    from sais_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C + Cout)
+    kh, kw = (k, k) if isinstance(k, int) else k
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(Cout, C, kh, kw, generator=g) / (C * kh * kw) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride, pad)
+    if relu:
+        ref = ref.relu()
+    got = ops.conv2d(x.to(DEV), w.to(DEV), b.to(DEV), stride, pad, relu=relu)
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert float((got.cpu().double() - ref).abs().max()) <= 3e-5 * max(1.0, float(ref.abs().max()))      # fp32-grade
+    got2 = ops.conv2d(x.to(DEV), w.to(DEV), None, stride, pad, relu=relu)                              # no bias
+    ref2 = F.conv2d(x.double(), w.double(), None, stride, pad)
+    assert float((got2.cpu().double() - (ref2.relu() if relu else ref2)).abs().max()) <= 3e-5 * max(1.0, float(ref2.abs().max()))
+
+
+def test_raft_module_has_no_library_convolution(gpu):
+    from sais_amd.raft import RAFT
+    m = RAFT(iters=1)
+    assert not any(isinstance(x, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)) for x in m.modules())
+    assert sum(1 for x in m.modules() if type(x).__name__ == "_Conv") == 2 * 16 + 15     # two encoders + the update block
+
+
 def test_raft_forward_and_colour_coding_vs_oracle(gpu):
     from oracle import raft_oracle as R
     from sais_amd.raft import RAFT, flow_image_uint8, flow_to_rgb
