@@ -1197,7 +1197,12 @@ struct TnWideGroup {
 // atomics that all 252 workgroups issue at the same moment; the chip retires ~1.3 TB/s of them), every workgroup stores its
 // raw 128 x 384 partial tile ONCE, in register order (16 B per lane, 1 KiB per wave-instruction), into the slab of its split;
 // tn_slab_finish_kernel sums the splits in a fixed order and adds the result to dW / db: deterministic gradients.
-template <bool SLAB>
+// NI (round 5, opt-in SAIS_TN_NI=2): barrier intervals per 64-row step.  4 = the schedule above.  2 = one LDS interval (the
+// fragments of BOTH k-halves, the whole next tile's LDS writes, the loads of the tile after it) and one interval of 48 MFMAs per
+// step: half the barriers — the bare MFMA + barrier skeleton of the 4-interval form already takes 130 of the kernel's 198 us —
+// paid for with 80 instead of 40 fragment registers, which leaves room for ONE staging register set (a tile is requested one
+// step before its LDS write instead of two).
+template <bool SLAB, int NI = 4>
 __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp, float* slabs) {
     extern __shared__ __attribute__((aligned(16))) char wsmem[];          // 2 x WSTAGE
     CLK_STAMP(3);
@@ -1300,6 +1305,61 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp, float* 
         fence();
         mma();
     };
+    if constexpr (NI == 2) {
+        bf16x8 fp2[2][4], fq2[2][6];
+        auto frags2 = [&](int cur) {
+            const char* sp = wsmem + cur * WSTAGE;
+            const char* sq = sp + WBLK;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row = ks * 32 + 4 * g + q4;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const int cp = wr * 64 + tt * 16 + 4 * p4;
+                    fp2[ks][tt] = cat4(lds_read_tr16(tr_addr(sp, row, cp)), lds_read_tr16(tr_addr(sp, row + 16, cp)));
+                }
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    const int c = wc * 96 + tt * 16;
+                    const char* qb = sq + (c >> 7) * WBLK;
+                    const int cq = (c & 127) + 4 * p4;
+                    fq2[ks][tt] = cat4(lds_read_tr16(tr_addr(qb, row, cq)), lds_read_tr16(tr_addr(qb, row + 16, cq)));
+                }
+            }
+        };
+        auto mma2 = [&] {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[i][j] = mfma16(fp2[ks][i], fq2[ks][j], acc[i][j]);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accb[i] = mfma16(fp2[ks][i], ones, accb[i]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        gload4(0, stg[0], 0); gload4(0, stg[0], 1);
+        lwrite4(0, stg[0], 0); lwrite4(0, stg[0], 1);
+        gload4(1, stg[0], 0); gload4(1, stg[0], 1);
+        __syncthreads();
+        if (wr == 1) __builtin_amdgcn_s_barrier();                // waves 4-7 run one interval behind
+        for (int st = 0; st < nsteps; ++st) {
+            const int cur = st & 1;
+            frags2(cur);
+            lwrite4(cur ^ 1, stg[0], 0); lwrite4(cur ^ 1, stg[0], 1);     // tile st + 1 (a repeat of the last tile at the end)
+            gload4(st + 2, stg[0], 0); gload4(st + 2, stg[0], 1);
+            fence();
+            mma2();
+        }
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+    } else {
     gload4(0, stg[0], 0); gload4(0, stg[0], 1);
     gload4(1, stg[1], 0); gload4(1, stg[1], 1);
     lwrite4(0, stg[0], 0); lwrite4(0, stg[0], 1);
@@ -1311,6 +1371,7 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp, float* 
         if (st + 1 < nsteps) step(1, st + 1, stg[0]);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    }
     if constexpr (SLAB) {
         const int tg = (wg - split * gp.ntiles), zt = split * gp.ntiles + tg;
         f32x4* o = (f32x4*)slabs + ((size_t)zt * 8 + wid) * (24 * 64) + lane;
@@ -1632,6 +1693,16 @@ extern "C" int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int 
             hipLaunchKernelGGL(gemm_tn_pp_kernel<true>, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)slabs);
             hipLaunchKernelGGL(tn_slab_finish_kernel, dim3(wt, 8), dim3(256), 0, (hipStream_t)stream, wg, (const float*)slabs, wns);
         } else {
+            static const int tn_ni = [] { const char* e = getenv("SAIS_TN_NI"); return e ? atoi(e) : 4; }();
+            if (tn_ni == 2) {
+                static thread_local bool set2 = false;
+                if (!set2) {
+                    if (hipFuncSetAttribute((const void*)gemm_tn_pp_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE) != hipSuccess)
+                        return SAIS_ERR_LAUNCH;
+                    set2 = true;
+                }
+                hipLaunchKernelGGL((gemm_tn_pp_kernel<false, 2>), dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)nullptr);
+            } else
             hipLaunchKernelGGL(gemm_tn_pp_kernel<false>, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)nullptr);
         }
         return sais_check_launch();

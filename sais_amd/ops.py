@@ -2,6 +2,7 @@
 memory, the current HIP stream, and dtype checks; every op below is one hand-written gfx950 kernel.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -497,8 +498,15 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
     K = C * kh * kw
     ld = (K + 1 + 63) // 64 * 64
     rows = (Ho * Wo + 127) // 128 * 128
-    key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), ld)
-    wm = _CONV_W.get(key)
+    # cache entry = (weak references to the very tensor objects, their versions, the matrix): a freed tensor's address can be
+    # handed to another one by the caching allocator, so neither the pointer nor id() alone identifies a weight
+    ent = _CONV_W.get(id(weight))
+    wm = None
+    if ent is not None:
+        wref, wver, bref, bver, mat = ent
+        if wref() is weight and wver == weight._version and mat.shape[1] == ld and mat.device == x.device and \
+                ((bias is None and bref is None) or (bref is not None and bref() is bias and bver == bias._version)):
+            wm = mat
     if wm is None:
         wm = torch.zeros(Cout, ld, dtype=F32, device=x.device)
         wm[:, :K] = weight.detach().reshape(Cout, K).float()
@@ -506,7 +514,8 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, relu=False):
             wm[:, K] = bias.detach().float()
         if len(_CONV_W) > 256:
             _CONV_W.clear()
-        _CONV_W[key] = wm
+        _CONV_W[id(weight)] = (weakref.ref(weight), weight._version, None if bias is None else weakref.ref(bias),
+                               None if bias is None else bias._version, wm)
     x = x.contiguous()
     cols = torch.empty(rows, ld, dtype=F32, device=x.device)
     y = torch.empty(B, Cout, rows, dtype=F32, device=x.device)

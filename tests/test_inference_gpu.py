@@ -82,6 +82,32 @@ def test_long_video_512_frames_graph_extraction_and_windows(gpu):
     assert tuple(probs.shape) == (34, 2) and torch.allclose(probs.sum(1).cpu(), torch.ones(34), atol=1e-5)
 
 
+def test_tail_graph_and_batched_windows_equal_the_small_batch_forms(gpu):
+    """Round 5: (a) a FeatureExtractor with a large main batch and a smaller captured tail shape gives, frame for frame, the
+    features of the single-shape extractor (rows are independent; same kernels per dispatch regime up to the GEMM's tile
+    walk: <= 1e-6 relative); (b) run_windows computing ALL windows per call equals the reference's batches of two run one
+    by one (same outputs, same per-batch attention tensors) to fp32 summation order."""
+    from sais_amd.inference import FeatureExtractor, run_windows
+    vit, m = _models()
+    frames = synth.clips(seed=9, B=1, T=150)[0].to(DEV)
+    a = FeatureExtractor(vit, batch_size=128, use_graph=True, tail_batch=64)(frames)        # 128 + 64 (22 real frames)
+    b = FeatureExtractor(vit, batch_size=64, use_graph=True)(frames)
+    assert a.shape == (150, 384) and float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    e = FeatureExtractor(vit, batch_size=128, use_graph=False, tail_batch=64)(frames)
+    assert torch.equal(a, e), "graph replay of both captured shapes must reproduce the eager kernels bit for bit"
+    reps = synth.reps(seed=3, B=1, T=200)[0, 0].to(DEV)
+    flow = synth.reps(seed=4, B=1, T=13)[0, 0].to(DEV)
+    big, attn_big, _ = run_windows(m, reps, flow, videoname="v", batch_size=2)                 # 13 windows in one call
+    small, attn_small, _ = run_windows(m, reps, flow, videoname="v", batch_size=2, compute_batch=2)
+    assert len(attn_big) == len(attn_small) == 7 and [tuple(x.shape) for x in attn_big] == [tuple(x.shape) for x in attn_small]
+    for x, y in zip(attn_big, attn_small):
+        assert float((x - y).abs().max()) <= 1e-5
+    for v in range(3):
+        assert len(big["reps"][v]) == 13
+        for x, y in zip(big["reps"][v], small["reps"][v]):
+            assert float((x - y).abs().max()) <= 1e-4 * max(1.0, float(y.abs().max()))
+
+
 def test_two_streams_with_different_lengths_and_ragged_batch(gpu):
     """config 4 shapes at inference: RGB T=15/12, flow T=2/1 in one padded batch."""
     from oracle import sais_oracle as O
