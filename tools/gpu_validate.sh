@@ -15,6 +15,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 
 python bench.py > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo
 python bench.py --workload dino > $O/bench_dino.json 2> $O/bench_dino.err; head -c 300 $O/bench_dino.json; echo
 python bench.py --two-stream --no-cpu-baseline --sustain-seconds 0 > $O/bench_two_stream.json 2> $O/bench_two_stream.err; head -c 250 $O/bench_two_stream.json; echo
+# BASELINE config 5: long-video inference (512 frames, hipGraph extraction + 34 windows x 3 TTA + attention export)
+python bench.py --workload extract --steps 20 --warmup 3 > $O/bench_extract.json 2> $O/bench_extract.err; head -c 300 $O/bench_extract.json; echo
 # the distributed branch of bench.py over RCCL with a world of one: the step INCLUDING its all-reduces is one hipGraph
 SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --sustain-seconds 0 > $O/force_dist_world1.log 2>&1; tail -c 2500 $O/force_dist_world1.log | head -c 300; echo
@@ -22,6 +24,7 @@ SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-n
     bench.py --workload dino --gpus 1 --steps 10 --warmup 3 > $O/force_dist_world1_dino.log 2>&1; tail -c 1200 $O/force_dist_world1_dino.log | head -c 400; echo
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --parity-clips 0 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_extract -- python3 $R/bench.py --workload extract --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_extract.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dino -- python3 $R/bench.py --workload dino --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_dino.log 2>&1
 B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --sustain-seconds 0 --parity-clips 0"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
