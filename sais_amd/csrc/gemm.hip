@@ -438,6 +438,146 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
 }
 
 // ---------------------------------------------------------------------------------------------
+// W in registers (round 5, LABNOTES R5.6; K = 384 only, the K loop fully unrolled).  The stamps of R5.2 show a K-step of the
+// kernel above taking 1 200-1 700 cycles of a wave's time for 256 cycles of its MFMAs: W(kt + 1) is requested at the top of step
+// kt and awaited at its end (two-slot W ring: one exposed L2 round trip of LDS-DMA per step), and a third W slot does not fit two
+// workgroups per CU.  Here W does not pass through LDS at all: a wave loads the MFMA fragments of ITS 32 weight columns
+// straight from global memory (L2-resident: 16-B per lane, four loads per step) TWO steps ahead into a rotating triple of register
+// sets (+ 32 VGPRs), and the 80 KiB of LDS become a five-slot A ring with four steps of lead.  Per step and wave: 2 LDS-DMA issues
+// instead of 4, 8 fragment reads instead of 12, no W to publish at the barrier.  vmcnt is one in-order counter, so the issue
+// order inside a step is W first, then A, and the counted wait at the end of step kt leaves exactly A(kt + 3), W(kt + 2), A(kt + 4)
+// in flight.
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_nt_w8r_kernel(NtParams p, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // A ring: 5 x 16 KiB
+    constexpr int NK = 6, NA = 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3, g = lane >> 4, li = lane & 15;
+    const int ntn = p.N / BN;
+    const int sub = lane >> 3, spos = lane & 7, schunk = spos ^ sub;
+    const bf16* asrc[2]; const bf16* wsrc[2];
+    auto set_tile = [&](int v, int& m0, int& n0) {
+        const int tile = xcd_remap(v, ntiles);
+        n0 = (tile % ntn) * BN; m0 = (tile / ntn) * BM;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 8 * (2 * wid + j) + sub;
+            int m = m0 + r;
+            m = m < p.M ? m : p.M - 1;
+            asrc[j] = p.A + (size_t)m * p.lda + schunk * 8;
+            // fragment tile j of this wave's 32 columns: MFMA row li <-> weight row 8 (li >> 2) + 4 j + (li & 3) (perm_row32: a
+            // lane then owns 8 contiguous output columns), k = 8 g .. 8 g + 7 of a 32-deep half-step
+            wsrc[j] = p.B + (size_t)(n0 + wc * 32 + 8 * (li >> 2) + 4 * j + (li & 3)) * p.ldb + 8 * g;
+        }
+    };
+    auto issue_a = [&](int kt) {
+        char* s = smem + (kt % NA) * TILE_BYTES + (2 * wid) * 1024;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(asrc[j] + kt * BK, s + j * 1024);
+    };
+    bf16x8 wf[3][2][2];                                               // [set][k-half][column tile]
+    auto load_w = [&](int kt, bf16x8 (&dst)[2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) dst[ks][nt] = *(const bf16x8*)(wsrc[nt] + kt * BK + ks * 32);
+    };
+    constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2 : (EPI == SAIS_EPI_PATCH_F32) ? 2
+                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
+    const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
+    auto prologue = [&] {                                             // W(0), A(0), W(1), A(1), A(2), A(3): the order the waits count on
+        load_w(0, wf[0]);
+        issue_a(0);
+        load_w(1, wf[1]);
+        issue_a(1);
+        issue_a(2);
+        issue_a(3);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int v = blockIdx.x, m0, n0;
+    if (v >= ntiles) return;
+    set_tile(v, m0, n0);
+    prologue();
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                 // W(0) and A(0) are in; W(1), A(1..3) may be in flight
+    __builtin_amdgcn_s_barrier();
+    int carry = 0;                           // stores of the previous tile's epilogue that may still be in flight at step 0
+    for (;;) {
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+        float bias[8];
+        EpiAux8 aux;
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int kt = 0; kt < NK; ++kt) {
+            if (kt + 2 < NK) load_w(kt + 2, wf[(kt + 2) % 3]);
+            if (kt + 4 < NK) issue_a(kt + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* sa = smem + (kt % NA) * TILE_BYTES;
+            if (kt == NK - 1) epilogue_loads8<EPI>(p, m0 + wr * 64, li, n0 + wc * 32 + 8 * g, bias, aux);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) fa[t] = *(const bf16x8*)(sa + swz(wr * 64 + t * 16 + li, ks * 4 + g));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma16(wf[kt % 3][ks][nt], fa[mt], acc[mt][nt]);
+            }
+            // in flight after this point (oldest first): [kt = 0: A(2), A(3), the previous tile's stores] W(kt+2), A(kt+4) and,
+            // before them, A(kt+3) — everything older, i.e. W(kt+1) and A(kt+1), has to be in
+            if (kt == 0) {
+                const int allow = 10 + carry;
+                if (allow == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                else if (allow == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+                else if (allow == 18) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+                else if (allow == 22) asm volatile("s_waitcnt vmcnt(22) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            } else if (kt == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (kt == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else if (kt == 3) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (kt == 4) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // last step: only the epilogue's loads are out
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_setprio(0);
+        const int cm0 = m0, cn0 = n0;
+        const int nv = v + gridDim.x;
+        const bool more = nv < ntiles;
+        if (more) {
+            set_tile(nv, m0, n0);
+            prologue();
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = cm0 + wr * 64 + mt * 16 + li;
+            if (m >= p.M) continue;
+            float vv[8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vv[4 * nt + r] = acc[mt][nt][r];
+            epilogue8<EPI>(p, m, cn0 + wc * 32 + 8 * g, vv, bias, aux, mt);
+        }
+        if (!more) break;
+        v = nv;
+        // W'(0) and A'(0) must be in; W'(1), A'(1..3) and this epilogue's stores may stay in flight (a ragged tile issues fewer
+        // stores than counted: wait for everything)
+        const int allow = (cm0 + BM <= p.M) ? nstores + 10 : 0;
+        carry = allow ? nstores : 0;
+        if (allow == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        else if (allow == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (allow == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); carry = 0; }
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Two eight-wave groups of ONE 1024-thread workgroup in ENFORCED anti-phase (round 5, LABNOTES R5.2).  Measured on the kernel
 // above (SAIS_NT_GRID, SAIS_NT_ABL builds): K loops alone 62.5 us with two workgroups per CU and 81 us with one, epilogues alone
 // 58 us (HBM-bound) either way, the whole kernel 141 us = MORE than their sum — the two workgroups of a CU run the same program
@@ -1436,7 +1576,18 @@ static constexpr bool w4_epi(int e) {
 }
 #define LAUNCH_NT(E)                                                                        \
     case E:                                                                                 \
-        if (big && nt_w16 && g->K / BK >= 5) {                                              \
+        if (big && nt_w8r && w4_epi(E) && g->K == 6 * BK) {                                 \
+            static thread_local bool set8r = false;                                         \
+            if (!set8r) {                                                                   \
+                if (hipFuncSetAttribute((const void*)gemm_nt_w8r_kernel<E>,                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 5 * TILE_BYTES) != hipSuccess) \
+                    return SAIS_ERR_LAUNCH;                                                 \
+                set8r = true;                                                               \
+            }                                                                               \
+            const int nt_ = (int)grid.x;                                                    \
+            hipLaunchKernelGGL(gemm_nt_w8r_kernel<E>, dim3(nt_ < nt_grid ? nt_ : nt_grid), dim3(512), 5 * TILE_BYTES, \
+                               (hipStream_t)stream, p, nt_);                                \
+        } else if (big && nt_w16 && g->K / BK >= 5) {                                       \
             static thread_local bool set16 = false;                                         \
             if (!set16) {                                                                   \
                 if (hipFuncSetAttribute((const void*)gemm_nt_w16_kernel<E>,                 \
@@ -1489,6 +1640,7 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     const bool big = g->M >= 8192;
     // persistent workgroups of the eight-wave kernel (2 per CU); SAIS_NT_GRID=256 = one per CU (diagnostic: LABNOTES R5.2)
     static const int nt_grid = [] { const char* e = getenv("SAIS_NT_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+    static const bool nt_w8r = [] { const char* e = getenv("SAIS_NT_W8R"); return e ? atoi(e) != 0 : false; }();
     static const bool nt_w16 = [] { const char* e = getenv("SAIS_NT_W16"); return e ? atoi(e) != 0 : false; }();
     static const bool nt_w4 = [] { const char* e = getenv("SAIS_NT_W4"); return e ? atoi(e) != 0 : false; }();
     if (g->epilogue == SAIS_EPI_RAW_SLABS_F32) {                // split-K over grp_in slices: small M only, raw fp32 slabs
