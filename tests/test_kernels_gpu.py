@@ -799,3 +799,22 @@ def test_gemm_tn_grouped_f32_accumulates_owned_or_atomic(ops, nsplit):
     for (p, q, dW, db), (rw, rb) in zip(items, refs):
         assert_close(dW, rw, atol=2e-3 * math.sqrt(M), rtol=1e-4)
         assert_close(db, rb, atol=1e-3 * math.sqrt(M))
+
+
+# ------------------------------------------------------------------ the opt-in kernel forms of round 5 stay CORRECT
+@pytest.mark.parametrize("switch,select", [
+    ("SAIS_NT_W4", "gemm_nt_epilogues or gemm_nt_exact"),        # four workgroups per CU, BK = 32 (LABNOTES R5.1)
+    ("SAIS_NT_W16", "gemm_nt_epilogues or gemm_nt_exact or gemm_patch"),   # two groups in anti-phase (R5.2)
+    ("SAIS_NT_W8R", "gemm_nt_epilogues or gemm_nt_exact"),       # W in registers (R5.6)
+    ("SAIS_TN_NI", "gemm_tn")])                                  # dW with two barrier intervals per step (R5.4; value 2)
+def test_opt_in_kernel_forms_pass_the_same_tests(ops, switch, select):
+    """The alternative organisations measured (and rejected on speed) this round are kept as opt-in switches read once per
+    process: the same parity tests as the shipped kernels, in a child process with the switch on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **{switch: "2" if switch == "SAIS_TN_NI" else "1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k",
+                        f"({select}) and not opt_in and not slab_mode"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
