@@ -82,6 +82,25 @@ def test_conv2d_on_the_matrix_cores_vs_torch(gpu, B, C, H, W, Cout, k, stride, p
     assert float((got2.cpu().double() - (ref2.relu() if relu else ref2)).abs().max()) <= 3e-5 * max(1.0, float(ref2.abs().max()))
 
 
+def test_conv2d_weight_cache_follows_in_place_updates_and_freed_tensors(gpu):
+    """ops.conv2d caches the padded [Cout, K + 1] weight matrix per live parameter tensor: an in-place update (a new
+    checkpoint loaded into the module) and a different tensor at a recycled address must both rebuild it."""
+    import torch.nn.functional as F
+    from sais_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 8, 12, 15, generator=g).to(DEV)
+    w, b = torch.randn(4, 8, 3, 3, generator=g).to(DEV), torch.randn(4, generator=g).to(DEV)
+    y1 = ops.conv2d(x, w, b, 1, 1)
+    w.mul_(2.0); b.add_(1.0)                                            # in place: same storage, new version
+    y2 = ops.conv2d(x, w, b, 1, 1)
+    assert float((y2 - F.conv2d(x, w, b, 1, 1)).abs().max()) <= 1e-4 and float((y2 - y1).abs().max()) > 0.1
+    for seed in range(6):                                               # fresh tensors, old ones freed: addresses get reused
+        w2 = torch.randn(4, 8, 3, 3, generator=torch.Generator().manual_seed(100 + seed)).to(DEV)
+        y = ops.conv2d(x, w2, None, 1, 1)
+        assert float((y - F.conv2d(x, w2, None, 1, 1)).abs().max()) <= 1e-4
+        del w2, y
+
+
 def test_raft_module_has_no_library_convolution(gpu):
     from sais_amd.raft import RAFT
     m = RAFT(iters=1)
