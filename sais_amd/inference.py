@@ -77,7 +77,7 @@ def pad_collate_tta(items):
     return out
 
 
-def collate_windows_tta(rgb_reps, flow_reps, wins):
+def collate_windows_tta(rgb_reps, flow_reps, wins, pad_flow_to=0):
     """sample_window + pad_collate_tta over MANY windows of one video at once: the same dict of tensors as
     pad_collate_tta([sample_window(rgb_reps, flow_reps, s, e) for s, e in wins]) (held to it in tests/test_host_cpu.py), built
     with ONE gather per TTA version and stream instead of six small ones per window — the index arithmetic
@@ -93,6 +93,8 @@ def collate_windows_tta(rgb_reps, flow_reps, wins):
         for key, reps, idx in (("x", rgb_reps, rgb_idx), ("f", flow_reps, flow_idx)):
             lens = [len(ix) for ix in idx]
             maxT = max(lens)
+            if key == "f" and pad_flow_to:                   # static shapes for graph replay: padding is masked, values unchanged
+                maxT = max(maxT, pad_flow_to)
             ix = np.zeros((B, max(maxT, 1)), dtype=np.int64)
             keep = np.zeros((B, max(maxT, 1)), dtype=bool)
             for b, row in enumerate(idx):
@@ -175,9 +177,46 @@ class FeatureExtractor:
 
 
 # --------------------------------------------------------------------------- windowed temporal inference
+class _WindowGraph:
+    """The temporal encoder over ONE fixed-size chunk of windows (all three TTA versions, both streams) captured into a
+    hipGraph: static inputs x_v [chunk,1,T_v,384], f_v [chunk,1,FLOW_PAD,384] and their key-padding masks; static outputs.  A
+    chunk is ~170 launches of 5-15 us kernels issued from Python; replayed it is one graph launch.  Shapes depend only on the chunk
+    size, so ONE capture per model serves every video.  OPT-IN (`run_windows(use_graph=True)`) and not used by the CLI or the
+    benchmark: measured SLOWER on a 512-frame video (5.6 vs 3.4 ms for the windows half, LABNOTES R5.7) — the ~170 tiny kernels
+    are device-bound at ~8 us each, so removing the host's launch work buys nothing, while fixed chunks compute 64 windows for 34."""
+    FLOW_PAD = 2                                             # unique(idx // 15) of <= 15 consecutive frames spans <= 2 flow rows
+
+    def __init__(self, model, c, use_f):
+        self.model, self.use_f = model, use_f
+        self.x = [t.clone() for t in c["x"]]
+        self.f = [t.clone() for t in c["f"]]
+        self.xpad = [t.clone() for t in c["xpad"]]
+        self.fpad = [t.clone() for t in c["fpad"]]
+        self.xlens, self.flens = c["xlens"], c["flens"]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                               # warm-up: workspaces, engines, allocator
+                self._call()
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._call()
+
+    def _call(self):
+        return self.model(self.x, self.f if self.use_f else None, self.xlens, self.flens, 'Prototypes', self.xpad,
+                          self.fpad if self.use_f else None, None)
+
+    def replay(self, c):
+        for dst, src in zip(self.x + self.f + self.xpad + self.fpad, c["x"] + c["f"] + c["xpad"] + c["fpad"]):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.out
+
+
 @torch.no_grad()
 def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, total_frames=None, rank=0, world_size=1,
-                compute_batch=256):
+                compute_batch=256, use_graph=False):
     """The `Custom_inference` phase of single_epoch (perform_training.py:71-185) over one video.
     Returns the dict train.py:116 saves as reps_and_labels_<phase>, the attention list (:117) and the importance list
     (:118; per-batch [B,1,T+1,1] tensors with `-il`, else empty).  `total_frames` = the video's row count in
@@ -189,7 +228,10 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
     train.py:117 saves them); the arithmetic runs over up to `compute_batch` windows per call of the model — a window's
     outputs do not depend on its batch mates (padding is masked, rows are independent), and 17 x 3 x 2 little forward passes
     with a host round trip each were 63 % of a 512-frame video's inference time (LABNOTES R5.3).  Embeddings, attention
-    and importances leave the device ONCE at the end."""
+    and importances leave the device ONCE at the end.
+    use_graph=True: the windows are processed in fixed chunks of min(compute_batch, 32) (the last chunk padded with repeats
+    of its last window, flow rows padded to two under the mask) and each chunk is one replay of a hipGraph captured once per
+    model (`_WindowGraph`); same values up to the masked padding's summation order."""
     from .parallel import gather_in_rank_order, shard_range
     model.eval()
     wins = gesture_windows(rgb_reps.shape[0] if total_frames is None else total_frames)
@@ -200,19 +242,31 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
     mine = wins[starts[lo]:starts[hi - 1] + batch_size] if hi > lo else []
     use_f = model.modalities in ("Flow", "RGB-Flow")
     cb = max(batch_size, (int(compute_batch) // batch_size) * batch_size)     # whole batches per call
+    if use_graph:
+        cb = min(cb, 32)
     emb_parts, attn_parts, imp_parts = ([], [], []), [], []
     for i in range(0, len(mine), cb):
-        c = collate_windows_tta(rgb_reps, flow_reps, mine[i:i + cb])
-        out = model(c["x"], c["f"] if use_f else None, c["xlens"], c["flens"], 'Prototypes', c["xpad"],
-                    c["fpad"] if use_f else None, None)
+        chunk = mine[i:i + cb]
+        n = len(chunk)
+        if use_graph:
+            c = collate_windows_tta(rgb_reps, flow_reps, chunk + [chunk[-1]] * (cb - n), pad_flow_to=_WindowGraph.FLOW_PAD)
+            graphs = model.__dict__.setdefault("_window_graphs", {})
+            key = (cb, str(rgb_reps.device), tuple(tuple(t.shape) for t in c["x"] + c["f"]))
+            if key not in graphs:
+                graphs[key] = _WindowGraph(model, c, use_f)
+            out = graphs[key].replay(c)
+        else:
+            c = collate_windows_tta(rgb_reps, flow_reps, chunk)
+            out = model(c["x"], c["f"] if use_f else None, c["xlens"], c["flens"], 'Prototypes', c["xpad"],
+                        c["fpad"] if use_f else None, None)
         if model.importance_loss:                                    # (importances, embs, attn), prepare_model.py:445-446
             imp, embs, attn = out
-            imp_parts.append(imp.detach())                           # perform_training.py:139-141
+            imp_parts.append(imp.detach()[:n].clone())               # perform_training.py:139-141
         else:
             embs, attn = out
         for v in range(3):
-            emb_parts[v].append(embs[v].detach())
-        attn_parts.append(attn.detach())
+            emb_parts[v].append(embs[v].detach()[:n].clone())        # clone: the graph's static outputs are overwritten by the next replay
+        attn_parts.append(attn.detach()[:n].clone())
     if mine:
         embs_cpu = [torch.cat(p).cpu() for p in emb_parts]           # ONE device -> host copy per output
         attn_cpu = torch.cat(attn_parts).cpu()

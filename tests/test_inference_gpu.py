@@ -106,6 +106,22 @@ def test_tail_graph_and_batched_windows_equal_the_small_batch_forms(gpu):
         assert len(big["reps"][v]) == 13
         for x, y in zip(big["reps"][v], small["reps"][v]):
             assert float((x - y).abs().max()) <= 1e-4 * max(1.0, float(y.abs().max()))
+    # (c) the hipGraph form: fixed chunks of 32 windows (13 real + 19 repeats), flow rows padded to two under the mask; the
+    # second video replays the SAME captured graph with new inputs (40 windows = two chunks)
+    g1, attn_g1, _ = run_windows(m, reps, flow, videoname="v", batch_size=2, use_graph=True)
+    assert len(getattr(m, "_window_graphs")) == 1 and len(attn_g1) == 7
+    reps2 = synth.reps(seed=5, B=1, T=610)[0, 0].to(DEV)
+    flow2 = synth.reps(seed=6, B=1, T=40)[0, 0].to(DEV)
+    g2, attn_g2, _ = run_windows(m, reps2, flow2, videoname="w", batch_size=2, use_graph=True)
+    e2, attn_e2, _ = run_windows(m, reps2, flow2, videoname="w", batch_size=2)
+    assert len(getattr(m, "_window_graphs")) == 1 and len(g2["labels"]) == 40 == len(e2["labels"])
+    for got, want, ag, aw in ((g1, big, attn_g1, attn_big), (g2, e2, attn_g2, attn_e2)):
+        assert [tuple(x.shape) for x in ag] == [tuple(x.shape) for x in aw]
+        for x, y in zip(ag, aw):
+            assert float((x - y).abs().max()) <= 1e-5
+        for v in range(3):
+            for x, y in zip(got["reps"][v], want["reps"][v]):
+                assert float((x - y).abs().max()) <= 1e-4 * max(1.0, float(y.abs().max()))
 
 
 def test_two_streams_with_different_lengths_and_ragged_batch(gpu):
