@@ -86,28 +86,46 @@ def collate_windows_tta(rgb_reps, flow_reps, wins, pad_flow_to=0):
     nflow = flow_reps.shape[0]
     B = len(wins)
     out = {"x": [], "xpad": [], "xlens": [], "f": [], "fpad": [], "flens": []}
-    per_win = [tta_indices(s, e) for s, e in wins]
-    for v in range(len(TTA_OFFSETS)):
-        rgb_idx = [per_win[b][v] for b in range(B)]
-        flow_idx = [flow_rows(ix, nflow) for ix in rgb_idx]
-        for key, reps, idx in (("x", rgb_reps, rgb_idx), ("f", flow_reps, flow_idx)):
-            lens = [len(ix) for ix in idx]
-            maxT = max(lens)
+    starts = np.asarray([s for s, _ in wins], dtype=np.int64)
+    uniform = all(e - s == DURATION_FRAMES for s, e in wins)     # what gesture_windows produces: jump = 15 // 10 = 1
+    per_win = None if uniform else [tta_indices(s, e) for s, e in wins]
+    for v, off in enumerate(TTA_OFFSETS):
+        if uniform:
+            # closed form of tta_indices / flow_rows for 15-frame windows: indices s - 1 + off .. e - 2, their flow rows the one or
+            # two values of idx // 15 (floor division: -1 // 15 = -1 survives the `< nflow` filter, as in the reference)
+            L = DURATION_FRAMES - off
+            first = starts - 1 + off
+            rix = first[:, None] + np.arange(L, dtype=np.int64)[None, :]
+            rkeep = np.ones((B, L), dtype=bool)
+            r0, r1 = first // FLOW_JUMP, (first + L - 1) // FLOW_JUMP
+            fix = np.stack([r0, r1], 1)
+            fkeep = np.stack([r0 < nflow, (r1 != r0) & (r1 < nflow)], 1)
+            fix = np.where(fkeep, fix, 0)
+            both = ((rix, rkeep), (fix, fkeep))
+        else:
+            rgb_idx = [per_win[b][v] for b in range(B)]
+            both = []
+            for idx in (rgb_idx, [flow_rows(ix, nflow) for ix in rgb_idx]):
+                m = max(max(len(r) for r in idx), 1)
+                ix, keep = np.zeros((B, m), dtype=np.int64), np.zeros((B, m), dtype=bool)
+                for b, row in enumerate(idx):
+                    ix[b, :len(row)] = row
+                    keep[b, :len(row)] = True
+                both.append((ix, keep))
+        for key, reps, (ix, keep) in (("x", rgb_reps, both[0]), ("f", flow_reps, both[1])):
+            lens = keep.sum(1)
+            maxT = int(lens.max())
             if key == "f" and pad_flow_to:                   # static shapes for graph replay: padding is masked, values unchanged
                 maxT = max(maxT, pad_flow_to)
-            ix = np.zeros((B, max(maxT, 1)), dtype=np.int64)
-            keep = np.zeros((B, max(maxT, 1)), dtype=bool)
-            for b, row in enumerate(idx):
-                ix[b, :len(row)] = row
-                keep[b, :len(row)] = True
+            if ix.shape[1] < max(maxT, 1):
+                padc = max(maxT, 1) - ix.shape[1]
+                ix, keep = np.pad(ix, ((0, 0), (0, padc))), np.pad(keep, ((0, 0), (0, padc)))
             g = reps[torch.from_numpy(ix).to(dev)]                        # negative indices wrap, as numpy does in the reference
             g = (g * torch.from_numpy(keep).to(dev).unsqueeze(-1).to(g.dtype))[:, :maxT]
-            mask = torch.zeros(B, 1, maxT + 1, dtype=torch.bool)
-            for b, n in enumerate(lens):
-                mask[b, :, n + 1:] = True                                  # createPaddingMask :2798-2806
+            mask = torch.from_numpy(np.arange(maxT + 1)[None, :] > lens[:, None]).unsqueeze(1)      # createPaddingMask :2798-2806
             out[key].append(g.unsqueeze(1).contiguous())
             out[key + "pad"].append(mask.to(dev))
-            out[key + "lens"].append(lens)
+            out[key + "lens"].append([int(n) for n in lens])
     return out
 
 
