@@ -310,3 +310,20 @@ def test_cli_inference_sharded_over_two_ranks_equals_single_process(gpu, tmp_pat
         assert len(r2["reps"][v]) == nwin and all(torch.equal(x, y) for x, y in zip(r1["reps"][v], r2["reps"][v]))
     # the head-averaged map is summed over the 4 heads with fp32 atomics: equal up to the order of those four additions
     assert len(a1) == len(a2) == (nwin + 1) // 2 and all(float((x - y).abs().max()) <= 1e-7 for x, y in zip(a1, a2))
+
+
+def test_bench_extract_workload_prints_one_valid_line(gpu):
+    """`bench.py --workload extract` (BASELINE config 5 as a measured workload): one JSON line with the contract's fields, the in-run
+    parity gate against the CPU oracle green, the two halves timed, a roofline object for the dominant kernel."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "extract", "--steps", "2", "--warmup", "1",
+                        "--video-frames", "128", "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "frames/s" and d["value"] > 0 and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["dtype"] == "bf16"
+    assert d["config"]["video_frames"] == 128 and d["config"]["windows"] == (128 - 15) // 15 + 1 and "workload" in d["config"]
+    assert d["parity"]["pass"] and d["parity"]["max_abs_logit"] <= 1e-3 and "invalid" not in d
+    assert d["split_ms"]["vit_extraction"] > 0 and d["split_ms"]["windows_and_export"] > 0
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["all_kernels"]
