@@ -230,7 +230,7 @@ def cpu_baseline(T, C, threads, weights, Bfull=8):
     # the headline leg IS the benchmarked configuration (B clips of T frames, fwd+bwd+SGD): 3 timed steps after one warm-up
     # (~15 s each on 32 cores: BASELINE.md §3 asks for >= 3); the other legs are a few seconds each
     main, n_main = leg(Bfull, T, 4, True, 1e9, 3)
-    variants = {}
+    variants = {f"config2_B{Bfull}_T{T}_fwd_bwd_sgd": {"frames_per_s": main, "timed_steps": n_main}}     # = `value`
     for name, (B, Tn, nl, train, budget, mx) in {
             "config1_B1_T16_1layer_fwd": (1, 16, 1, False, 1.5, 3),
             "config1_B1_T16_1layer_fwd_bwd": (1, 16, 1, True, 2.5, 3),
