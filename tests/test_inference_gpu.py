@@ -312,6 +312,24 @@ def test_cli_inference_sharded_over_two_ranks_equals_single_process(gpu, tmp_pat
     assert len(a1) == len(a2) == (nwin + 1) // 2 and all(float((x - y).abs().max()) <= 1e-7 for x, y in zip(a1, a2))
 
 
+def test_long_feature_file_runs_in_chunks_of_256_windows(gpu):
+    """A 4 000-frame feature file = 266 windows: two calls of the model (256 + 10 windows, 4 096 token rows in the first) must give
+    what batches of two give, window for window."""
+    from sais_amd.inference import run_windows
+    _, m = _models()
+    reps = synth.reps(seed=31, B=1, T=4000)[0, 0].to(DEV)
+    flow = synth.reps(seed=32, B=1, T=266)[0, 0].to(DEV)
+    big, attn_big, _ = run_windows(m, reps, flow, videoname="long", batch_size=2)
+    ref, attn_ref, _ = run_windows(m, reps, flow, videoname="long", batch_size=2, compute_batch=2)
+    assert len(big["labels"]) == 266 == len(ref["labels"]) and len(attn_big) == 133 == len(attn_ref)
+    for k in (0, 1, 63, 127, 128, 132):
+        assert float((attn_big[k] - attn_ref[k]).abs().max()) <= 1e-5
+    for v in range(3):
+        for k in (0, 1, 2, 100, 255, 256, 265):
+            x, y = big["reps"][v][k], ref["reps"][v][k]
+            assert float((x - y).abs().max()) <= 1e-4 * max(1.0, float(y.abs().max()))
+
+
 def test_bench_extract_workload_prints_one_valid_line(gpu):
     """`bench.py --workload extract` (BASELINE config 5 as a measured workload): one JSON line with the contract's fields, the in-run
     parity gate against the CPU oracle green, the two halves timed, a roofline object for the dominant kernel."""
