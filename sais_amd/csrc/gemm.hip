@@ -1544,33 +1544,54 @@ __global__ __launch_bounds__(512) void gemm_tn_pp_kernel(TnWideGroup gp, float* 
         }
 }
 
-// grid (tiles, 8): block (t, w) sums wave w's part of tile t over the nsplit slabs (fixed order) and adds it to dW; block
-// (t, 0) also finishes the bias gradient of a tile in the first column block
+// One thread per (tile, wave, accumulator tile, lane): the nsplit partial f32x4 of its position are loaded together (up to 16
+// loads in flight per thread; round 5's form walked them one dependent load at a time from 288 workgroups and cost more than the
+// atomics it replaced), summed in a fixed order and added to dW; the bias parts by the last blocks of the grid.
 __global__ __launch_bounds__(256) void tn_slab_finish_kernel(TnWideGroup gp, const float* slabs, int nsplit) {
-    int t = blockIdx.x, it0 = 0;
-    const int tg = t, w = blockIdx.y;
+    constexpr int PER_TILE = 8 * 24 * 64;                                     // f32x4 elements of one workgroup's slab
+    const int nbody = gp.ntiles * PER_TILE / 256;
+    const size_t zstride = (size_t)gp.ntiles * PER_TILE;                      // f32x4 per split
+    if ((int)blockIdx.x < nbody) {
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        int t = e / PER_TILE;
+        const int w8 = e - t * PER_TILE, lane = w8 & 63, ij = (w8 >> 6) % 24, w = (w8 >> 6) / 24;
+        const f32x4* src = (const f32x4*)slabs + (size_t)t * PER_TILE + w8;
+        f32x4 v[16];
+        f32x4 sum = src[0];
+        for (int z0 = 1; z0 < nsplit; z0 += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z0 + u < nsplit) v[u] = src[(size_t)(z0 + u) * zstride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z0 + u < nsplit) sum += v[u];
+        }
+        int it0 = 0;
+        while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;
+        if (it0 > 0) t -= gp.tile_end[it0 - 1];
+        const TnParams& p = gp.item[it0];
+        const int nt2 = p.N2 / WQ;
+        const int n1_0 = (t / nt2) * 128, n2_0 = (t % nt2) * WQ;
+        const int wr = w >> 2, wc = w & 3, i = ij / 6, j = ij - 6 * i, g = lane >> 4, li = lane & 15;
+        float* row = p.dW + (size_t)(n1_0 + wr * 64 + i * 16 + 4 * g) * p.ldw + n2_0 + wc * 96 + j * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[(size_t)r * p.ldw] += sum[r];
+        return;
+    }
+    const int e = (blockIdx.x - nbody) * 256 + threadIdx.x;
+    if (e >= gp.ntiles * 128) return;
+    int t = e >> 7;
+    const int tg = t, c = e & 127;
+    int it0 = 0;
     while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;
     if (it0 > 0) t -= gp.tile_end[it0 - 1];
     const TnParams& p = gp.item[it0];
     const int nt2 = p.N2 / WQ;
-    const int n1_0 = (t / nt2) * 128, n2_0 = (t % nt2) * WQ;
-    const int wr = w >> 2, wc = w & 3;
-    const size_t zstride = (size_t)gp.ntiles * 8 * (24 * 64);                 // f32x4 per split
-    const f32x4* base = (const f32x4*)slabs + ((size_t)tg * 8 + w) * (24 * 64);
-    for (int e = threadIdx.x; e < 24 * 64; e += 256) {
-        f32x4 sum = base[e];
-        for (int z = 1; z < nsplit; ++z) sum += base[z * zstride + e];
-        const int lane = e & 63, ij = e >> 6, i = ij / 6, j = ij - 6 * i, g = lane >> 4, li = lane & 15;
-        float* row = p.dW + (size_t)(n1_0 + wr * 64 + i * 16 + 4 * g) * p.ldw + n2_0 + wc * 96 + j * 16 + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) row[(size_t)r * p.ldw] += sum[r];
-    }
-    if (w == 0 && n2_0 == 0 && p.db && threadIdx.x < 128) {
-        const float* bb = slabs + (size_t)nsplit * zstride * 4 + (size_t)tg * 128 + threadIdx.x;
-        float sum = 0.f;
-        for (int z = 0; z < nsplit; ++z) sum += bb[(size_t)z * gp.ntiles * 128];
-        p.db[n1_0 + threadIdx.x] += sum;
-    }
+    if (p.db == nullptr || t % nt2 != 0) return;
+    const float* bb = slabs + (size_t)nsplit * zstride * 4 + (size_t)tg * 128 + c;
+    float sum = 0.f;
+    for (int z = 0; z < nsplit; ++z) sum += bb[(size_t)z * gp.ntiles * 128];
+    p.db[(t / nt2) * 128 + c] += sum;
 }
 
 }  // namespace
@@ -1624,6 +1645,23 @@ static constexpr bool w4_epi(int e) {
         break;
 
 extern "C" int sais_gemm_nt_row_(const SaisGemm* g, void* stream);      // gemm_row.hip: row-owning tiles, N = 384
+extern "C" int sais_gemm_tn_xl_(const SaisTnItem* items, int nitems, int M, int nwaves, void* slabs, size_t slab_bytes, void* stream);   // gemm_tn_xl.hip: 192 x 384 dW tiles
+extern "C" size_t sais_gemm_tn_xl_slab_bytes_(const SaisTnItem* items, int nitems, int M, int nwaves);
+// SAIS_TN_XL = 4 | 8 waves (default 4), 0 = the 128 x 384 kernel; SAIS_TN_XL_SLABS = 0: fp32 atomics instead of slabs + finish;
+// SAIS_TN_SLABS = 1: the round-5 slab form of the 128 x 384 kernel (implies SAIS_TN_XL = 0)
+static int tn_xl_waves() {
+    static const int v = [] {
+        const char* s = getenv("SAIS_TN_SLABS");
+        if (s && atoi(s) != 0) return 0;
+        const char* e = getenv("SAIS_TN_XL");
+        return e ? atoi(e) : 4;
+    }();
+    return v;
+}
+static bool tn_xl_slabs() {
+    static const bool v = [] { const char* e = getenv("SAIS_TN_XL_SLABS"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
 CLK_EXPORT(gemm)
 
 
@@ -1784,7 +1822,14 @@ static int launch_tn(const void* P, int ldp, const void* Q, int ldq, int M, int 
 }
 
 extern "C" size_t sais_gemm_tn_grouped_slab_bytes(const SaisTnItem* items, int nitems, int M) {
-    if (!items || nitems <= 0 || nitems > SAIS_TN_MAX_ITEMS || M % TK || M < 8192) return 0;
+    if (!items || nitems <= 0 || nitems > SAIS_TN_MAX_ITEMS) return 0;
+    if (tn_xl_waves()) {
+        const size_t need = tn_xl_slabs() ? sais_gemm_tn_xl_slab_bytes_(items, nitems, M, tn_xl_waves()) : 0;
+        if (need) return need;
+    }
+    // the 128 x 384 kernel's slab form is opt-in (SAIS_TN_SLABS = 1): without the switch no workspace is asked for
+    static const bool old_slabs = [] { const char* e = getenv("SAIS_TN_SLABS"); return e ? atoi(e) != 0 : false; }();
+    if (!old_slabs || M % TK || M < 8192) return 0;
     int wt = 0;
     for (int i = 0; i < nitems; ++i) {
         if (items[i].N1 % 128 || items[i].N2 % WQ) return 0;
@@ -1818,6 +1863,12 @@ extern "C" int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int 
         gp.tile_end[i] = total;
     }
     gp.ntiles = total;
+    // large tiles (192 x 384, gemm_tn_xl.hip) when every N1 % 192 == 0, N2 % 384 == 0 and M % 32 == 0
+    if (tn_xl_waves()) {
+        const bool sl = slabs != nullptr && tn_xl_slabs();
+        const int r = sais_gemm_tn_xl_(items, nitems, M, tn_xl_waves(), sl ? slabs : nullptr, sl ? slab_bytes : 0, stream);
+        if (r != 0) return r > 0 ? SAIS_OK : r;
+    }
     // wide tiles (128 x 384) when every item allows them and M is a whole number of 64-row steps
     bool wide = M % TK == 0 && M >= 8192;
     for (int i = 0; i < nitems && wide; ++i) wide = items[i].N2 % WQ == 0;
@@ -1849,7 +1900,7 @@ extern "C" int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int 
         if (slabs && wns > 1 && use_slabs) {
             if (slab_bytes < need || ((uintptr_t)slabs & 15)) return SAIS_ERR_ARG;
             hipLaunchKernelGGL(gemm_tn_pp_kernel<true>, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)slabs);
-            hipLaunchKernelGGL(tn_slab_finish_kernel, dim3(wt, 8), dim3(256), 0, (hipStream_t)stream, wg, (const float*)slabs, wns);
+            hipLaunchKernelGGL(tn_slab_finish_kernel, dim3(wt * (8 * 24 * 64) / 256 + (wt * 128 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wg, (const float*)slabs, wns);
         } else {
             static const int tn_ni = [] { const char* e = getenv("SAIS_TN_NI"); return e ? atoi(e) : 4; }();
             if (tn_ni == 2) {

@@ -286,7 +286,8 @@ def gemm_tn_grouped(items, M, nsplit=None):
     if f32:
         _timed(tag, flops, nbytes, lambda: L.call("sais_gemm_tn_grouped_f32", arr, len(items), M, nsplit, _stream()))
         return
-    # wide-tile regime (the dW of a ViT block at training size): raw split slabs + a fixed-order finish instead of fp32 atomics
+    # large-tile regime (the dW of a ViT block at training size): raw split slabs + a fixed-order finish instead of fp32 atomics
+    # (0 bytes: the regime or the slab form does not apply and no workspace is allocated)
     need = L.load().sais_gemm_tn_grouped_slab_bytes(arr, len(items), M)
     ws = _tn_slabs(need, items[0][0].device) if need else None
     _timed(tag, flops, nbytes,
@@ -297,12 +298,16 @@ _TN_SLABS = {}
 
 
 def _tn_slabs(nbytes, device):
-    """One slab workspace per device, grown on demand (launches on a stream are ordered, so consecutive dW launches share it);
-    allocated outside any hipGraph capture pool by the eager warm-up steps that precede a capture."""
-    buf = _TN_SLABS.get(device)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _TN_SLABS[device] = buf
+    """One slab workspace per device and size class (launches on a stream are ordered, so consecutive dW launches share it);
+    allocated outside any hipGraph capture pool by the eager warm-up steps that precede a capture.  A buffer is never freed or
+    replaced: a captured graph keeps the pointer it was recorded with, so a larger request gets a NEW buffer beside the old."""
+    bufs = _TN_SLABS.setdefault(device, [])
+    for buf in bufs:
+        if buf.numel() >= nbytes:
+            return buf
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    bufs.append(buf)
+    bufs.sort(key=lambda b: b.numel())
     return buf
 
 

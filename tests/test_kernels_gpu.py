@@ -534,6 +534,40 @@ def test_gemm_tn_grouped_matches_individual(ops, M):
             assert_close(db, rb, atol=1e-3 * math.sqrt(M))
 
 
+def test_gemm_tn_grouped_large_tile_exact_integers_and_bitwise_repeatable(ops):
+    """The 192 x 384 dW kernel (gemm_tn_xl.hip: one wave per SIMD, hand-counted vmcnt / lgkmcnt, LDS-DMA ring): small-integer
+    operands make every product and sum exact, so dW and db must EQUAL the fp64 result (a swapped fragment, a stale LDS stage
+    or a missed wait shows as a wrong integer), asymmetric P / Q catch a transposed store, and the slab + finish form has no
+    atomics, so forty launches on the same inputs must be bit-identical (a race screen: LDS-DMA data that arrives late is rare
+    and load-dependent).  M = 197 x 96 = 18 912 rows = 591 steps of 32: splits of 59 and 60 steps (both loop parities)."""
+    M = 197 * 96
+    g = torch.Generator().manual_seed(11)
+    shapes = [(384, 1536), (1536, 384), (384, 384), (1152, 384)]
+    ps = [torch.randint(-2, 3, (M, n1), generator=g).float() for n1, _ in shapes]
+    qs = [torch.randint(-3, 4, (M, n2), generator=g).float() for _, n2 in shapes]
+    def run():
+        items = [(p.to(torch.bfloat16).to(DEV), q.to(torch.bfloat16).to(DEV), torch.zeros(p.shape[1], q.shape[1], device=DEV),
+                  torch.zeros(p.shape[1], device=DEV) if i != 2 else None) for i, (p, q) in enumerate(zip(ps, qs))]
+        ops.gemm_tn_grouped(items, M)
+        return items
+    first = run()
+    for (p, q), (_, _, dW, db) in zip(zip(ps, qs), first):
+        assert torch.equal(dW.cpu().double(), p.double().t() @ q.double())
+        if db is not None:
+            assert torch.equal(db.cpu().double(), p.double().sum(0))
+    # busy neighbours: a second stream streams through HBM while the launches repeat
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, device=DEV)
+    for rep in range(40):
+        with torch.cuda.stream(side):
+            junk.add_(1.0)
+        again = run()
+        for (_, _, dW, db), (_, _, dW2, db2) in zip(first, again):
+            assert torch.equal(dW, dW2), f"repetition {rep}: dW differs"
+            assert db is None or torch.equal(db, db2), f"repetition {rep}: db differs"
+    torch.cuda.synchronize()
+
+
 _SLAB_SCRIPT = r"""
 import math, sys, torch
 sys.path.insert(0, sys.argv[1])
@@ -801,20 +835,27 @@ def test_gemm_tn_grouped_f32_accumulates_owned_or_atomic(ops, nsplit):
         assert_close(db, rb, atol=1e-3 * math.sqrt(M))
 
 
-# ------------------------------------------------------------------ the opt-in kernel forms of round 5 stay CORRECT
-@pytest.mark.parametrize("switch,select", [
-    ("SAIS_NT_W4", "gemm_nt_epilogues or gemm_nt_exact"),        # four workgroups per CU, BK = 32 (LABNOTES R5.1)
-    ("SAIS_NT_W16", "gemm_nt_epilogues or gemm_nt_exact or gemm_patch"),   # two groups in anti-phase (R5.2)
-    ("SAIS_NT_W8R", "gemm_nt_epilogues or gemm_nt_exact"),       # W in registers (R5.6)
-    ("SAIS_TN_NI", "gemm_tn")])                                  # dW with two barrier intervals per step (R5.4; value 2)
-def test_opt_in_kernel_forms_pass_the_same_tests(ops, switch, select):
-    """The alternative organisations measured (and rejected on speed) this round are kept as opt-in switches read once per
-    process: the same parity tests as the shipped kernels, in a child process with the switch on."""
+# ------------------------------------------------------------------ the opt-in kernel forms stay CORRECT
+@pytest.mark.parametrize("switch,value,select", [
+    ("SAIS_NT_W4", "1", "gemm_nt_epilogues or gemm_nt_exact"),        # four workgroups per CU, BK = 32 (LABNOTES R5.1)
+    ("SAIS_NT_W16", "1", "gemm_nt_epilogues or gemm_nt_exact or gemm_patch"),   # two groups in anti-phase (R5.2)
+    ("SAIS_NT_W8R", "1", "gemm_nt_epilogues or gemm_nt_exact"),       # W in registers (R5.6)
+    ("SAIS_TN_XL", "0", "gemm_tn"),                                   # dW on the 128 x 384 ping-pong kernel + atomics (rounds 2-5)
+    ("SAIS_TN_XL_SLABS", "0", "gemm_tn"),                             # dW on the 192 x 384 kernel with fp32 atomics (R6.1)
+    ("SAIS_TN_XL", "8", "gemm_tn"),                                   # ... with eight waves, two per SIMD (R6.1)
+    ("SAIS_TN_NI", "2", "gemm_tn")])                                  # 128 x 384 with two barrier intervals per step (R5.4)
+def test_opt_in_kernel_forms_pass_the_same_tests(ops, switch, value, select):
+    """The alternative organisations measured (and rejected on speed) are kept as opt-in switches read once per process: the
+    same parity tests as the shipped kernels, in a child process with the switch set."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, **{switch: "2" if switch == "SAIS_TN_NI" else "1"})
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k",
-                        f"({select}) and not opt_in and not slab_mode"], env=env, cwd=root, capture_output=True, text=True,
-                       timeout=1200)
+    env = dict(os.environ, **{switch: value})
+    if switch == "SAIS_TN_NI":
+        env["SAIS_TN_XL"] = "0"
+    sel = f"({select}) and not opt_in and not slab_mode"
+    if (switch, value) != ("SAIS_TN_XL", "8"):
+        sel += " and not bitwise_repeatable"                    # the race screen needs the atomics-free large-tile form
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k", sel],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]

@@ -12,6 +12,7 @@ for s in $srcs; do
   f=${s%.hip}
   extra="-mllvm -amdgpu-mfma-vgpr-form=1"
   [ "$f" = mlp_fused ] && extra=""
+  [ "$f" = gemm_tn_xl ] && extra=""
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-result \
       $extra "$@" -c $root/sais_amd/csrc/$f.hip -o $out/$f.o &
 done
