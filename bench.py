@@ -86,7 +86,10 @@ def parse_args():
     ap.add_argument("--parity-clips", type=int, default=1,
                     help="clips of the timed batch that also go through the CPU oracle (with the draws the GPU forward "
                          "used) for the in-line parity gate; 0 = skip")
-    ap.add_argument("--sustain-seconds", type=float, default=20.0,
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the short BASELINE config 4 (two-stream) and config 5 (long-video extraction) legs that the "
+                         "default one-GPU run reports under `variants`")
+    ap.add_argument("--sustain-seconds", type=float, default=10.0,
                     help="after the timed region, keep replaying the step for this long and report the settled rate "
                          "(clock under sustained MFMA load); 0 = skip")
     return ap.parse_args()
@@ -633,14 +636,61 @@ def parity_gate(vit, model, protos, frames, pad, labels, B, T, C, two, nclips):
     return out
 
 
-def load_pmc(name):
-    path = os.path.join(ROOT, "profiles", name)
+def kernel_source_hash(root=ROOT):
+    """sha256 over the kernel sources (sais_amd/csrc/*.hip, *.hpp, Makefile, include/*.h), in name order.  Counter files under
+    profiles/ carry the hash of the tree they were collected on (tools/pmc_report.py), so a later kernel edit cannot leave a stale
+    `traffic` in the benchmark line: load_pmc() returns the file only while the hashes agree."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "sais_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "sais_amd", "csrc", "*.hpp"))
+                   + glob.glob(os.path.join(root, "include", "*.h")) + [os.path.join(root, "sais_amd", "csrc", "Makefile")])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(name, root=ROOT):
+    """(counters, stale): the parsed profiles/<name>, and whether it describes OTHER kernel sources than this tree's (no hash in
+    its _provenance counts as stale)."""
+    path = os.path.join(root, "profiles", name)
     if os.path.exists(path):
         try:
-            return json.load(open(path))
+            d = json.load(open(path))
         except Exception:
-            return None
-    return None
+            return None, False
+        return d, (d.get("_provenance") or {}).get("kernel_source_hash") != kernel_source_hash(root)
+    return None, False
+
+
+def run_variants(args):
+    """BASELINE configs 4 and 5 beside the headline: two short child runs of this file (`--two-stream`, `--workload extract`; 5
+    timed steps each, their own parity gates on), condensed.  Children, not in-process: each leg builds its own models and graphs
+    and leaves nothing behind in this process; they start after the headline's timed and sustained regions."""
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-variants"]
+    legs = {"config4_two_stream": base + ["--two-stream", "--sustain-seconds", "0"],
+            "config5_long_video": base + ["--workload", "extract"]}
+    out = {}
+    for name, cmd in legs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = json.loads(r.stdout.strip().splitlines()[-1])
+            par = line.get("parity") or {}
+            v = {"value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line["steps"],
+                 "workload": line["config"]["workload"], "frac_of_mfma_roofline": line.get("frac_of_mfma_roofline"),
+                 "roofline": {k: line["roofline"].get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us")},
+                 "parity": {k: par.get(k) for k in ("max_abs_logit", "max_abs_attn", "max_abs_feature_rel", "tolerance_logit", "pass")},
+                 "exit_code": r.returncode, "wall_s": round(time.perf_counter() - t0, 1)}
+            if "split_ms" in line:
+                v["split_ms"] = line["split_ms"]
+            if line.get("invalid"):
+                v["invalid"] = True
+        except Exception as e:                                   # a failed leg is reported, it does not void the headline
+            v = {"error": repr(e)[:300], "wall_s": round(time.perf_counter() - t0, 1)}
+        out[name] = v
+    return out
 
 
 # ------------------------------------------------------------------------------------------ main
@@ -832,13 +882,16 @@ def main():
         # key of the same kernel in profiles/pmc_traffic.json ("gemm_ln_bwd[N384,K1536]" -> "gemm_ln_bwd[K1536]")
         base = kern.split("[")[0]
         pmc_key = base + "[" + kern.split(",")[-1] if base in ("gemm_ln_fwd", "gemm_ln_bwd") else base
-        pmc = (load_pmc("pmc_traffic.json") or {}).get(pmc_key)
+        pmc_all, pmc_stale = load_pmc("pmc_traffic.json")
+        pmc = None if pmc_stale else (pmc_all or {}).get(pmc_key)
         roof = dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                     frac=round(ach / MFMA_PEAK_TFLOPS, 4),
                     traffic=(pmc or {}).get("hbm_bytes_per_launch"),
+                    traffic_stale=bool(pmc_stale),
                     traffic_source="profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command, collected "
-                                   "offline; NOT a live counter)",
-                    traffic_collected=(load_pmc("pmc_traffic.json") or {}).get("_provenance"),
+                                   "offline; NOT a live counter; null + traffic_stale when the kernel sources have "
+                                   "changed since: the file carries their hash)",
+                    traffic_collected=(pmc_all or {}).get("_provenance"),
                     algorithmic_bytes=int(nbytes),
                     hbm_gbps_algorithmic=round(nbytes / (avg_ms * 1e-3) / 1e9, 1),
                     avg_launch_us=round(avg_ms * 1e3, 1), launches_per_step=k["launches"] // NPASS,
@@ -893,7 +946,7 @@ def main():
         if roof is not None:
             roof["hbm_frac"] = round(nstream * B * T * HBM_BYTES_PER_FRAME * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)
             roof["hbm_frac_note"] = "MODEL-based: 133 MB/frame fused-plan algorithmic bytes / step time / 8 TB/s"
-            step_pmc = (load_pmc("pmc_traffic.json") or {}).get("_step", {}).get("step_hbm_bytes")
+            step_pmc = None if pmc_stale else (pmc_all or {}).get("_step", {}).get("step_hbm_bytes")
             if step_pmc and not two and (B, T) == (8, 32):
                 roof["hbm_frac_counters"] = round(step_pmc * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 4)
                 roof["hbm_frac_counters_note"] = ("COUNTER-based: sum over kernel families of launches x PMC bytes per "
@@ -941,6 +994,8 @@ def main():
                         if not k.startswith(("clip_", "transEncoderClip", "attention", "finalModules", "linear2"))},
                        {k: v.detach().float().cpu() for k, v in protos.items()})
             out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)), weights, Bfull=B)
+        if world == 1 and not two and not args.no_variants and os.environ.get("SAIS_BENCH_BACKEND", "nccl") == "nccl":
+            out["variants"] = run_variants(args)
         # a number from a numerically wrong step is not a result: the line says so and the exit code is non-zero
         bad = (parity is not None and not parity["pass"]) or bool(graph_check and graph_check.get("mismatch"))
         if bad:

@@ -427,3 +427,32 @@ def test_window_sampler_matches_the_reference_dataset(golden):
                 assert np.array_equal(xs[v][0, :, 0].numpy().astype(np.int64), g[f"{name}/w{w}/rgb{v}"]), (name, w, v)
                 assert np.array_equal(fs[v][0, :, 0].numpy().astype(np.int64), g[f"{name}/w{w}/flow{v}"]), (name, w, v)
             assert xs[0].shape[1] == int(g[f"{name}/w{w}/imp_len"])
+
+
+def test_counter_files_go_stale_when_a_kernel_source_changes(tmp_path):
+    """bench.py's `roofline.traffic` comes from profiles/pmc_traffic.json, collected offline.  The file carries the hash of the kernel
+    sources it was collected on; a one-comment edit of a copy of gemm.hip must turn the field off (`traffic_stale`)."""
+    import json
+    import shutil
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sub in (("sais_amd", "csrc"), ("include",)):
+        os.makedirs(tmp_path.joinpath(*sub))
+    for f in os.listdir(os.path.join(root, "sais_amd", "csrc")):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":
+            shutil.copy(os.path.join(root, "sais_amd", "csrc", f), tmp_path / "sais_amd" / "csrc" / f)
+    shutil.copy(os.path.join(root, "include", "sais_hip.h"), tmp_path / "include" / "sais_hip.h")
+    os.makedirs(tmp_path / "profiles")
+    h = bench.kernel_source_hash(str(tmp_path))
+    assert h == bench.kernel_source_hash(root)                       # same bytes, same hash
+    json.dump({"gemm_tn_grouped": {"hbm_bytes_per_launch": 1}, "_provenance": {"kernel_source_hash": h}},
+              open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
+    d, stale = bench.load_pmc("pmc_traffic.json", str(tmp_path))
+    assert d["gemm_tn_grouped"]["hbm_bytes_per_launch"] == 1 and stale is False
+    with open(tmp_path / "sais_amd" / "csrc" / "gemm.hip", "a") as fh:
+        fh.write("// a comment\n")
+    d, stale = bench.load_pmc("pmc_traffic.json", str(tmp_path))
+    assert stale is True
+    json.dump({"gemm_tn_grouped": {"hbm_bytes_per_launch": 1}, "_provenance": {"head": "205f2ce"}},       # pre-round-6 file: no hash
+              open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
+    assert bench.load_pmc("pmc_traffic.json", str(tmp_path))[1] is True

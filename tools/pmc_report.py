@@ -99,7 +99,9 @@ def provenance():
             dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "sais_amd"], text=True).strip())
         except Exception:
             head = "unknown"
-    return {"head": head, "kernel_sources_modified_since_head": dirty,
+    sys.path.insert(0, ROOT)
+    import bench
+    return {"head": head, "kernel_sources_modified_since_head": dirty, "kernel_source_hash": bench.kernel_source_hash(ROOT),
             "collected": datetime.date.today().isoformat(), "passes": [os.path.relpath(os.path.abspath(d), ROOT) for d in sys.argv[1:4]]}
 
 
