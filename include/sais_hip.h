@@ -145,12 +145,14 @@ typedef struct SaisTnItem {
     float* db;                     /* f32 [N1] or NULL         */
 } SaisTnItem;
 int sais_gemm_tn_grouped(const SaisTnItem* items, int nitems, int M, int nsplit, void* stream);
-/* ABI 10: the same launch with a caller-provided slab workspace.  For the wide-tile regime (every N2 % 384 == 0, M % 64 == 0,
- * M >= 8192) the M-splits then store their raw partial tiles into `slabs` and a second launch sums them in a FIXED order into
- * dW / db: no fp32 atomics (7 splits x 7.1 MB of them per ViT block before), bit-reproducible weight gradients.
- * sais_gemm_tn_grouped_slab_bytes returns the bytes that launch needs (0: the regime does not apply, slabs is ignored);
- * slabs 16-B aligned; NULL = the atomic form.  The slab form is OPT-IN: it runs only with SAIS_TN_SLABS=1 in the environment
- * (deterministic gradients; measured ~5 % slower than the atomics on MI355X, LABNOTES R5.1), otherwise `slabs` is ignored.  */
+/* ABI 10: the same launch with a caller-provided slab workspace.  In the large-tile regime (round 6, csrc/gemm_tn_xl.hip: every
+ * N1 % 192 == 0 and N2 % 384 == 0, M % 32 == 0, M >= 8192, >= 48 32-row steps per M-split — the four nn.Linear of a ViT block at
+ * training size) the M-splits store their raw 192 x 384 partial tiles into `slabs` (plain 16-B stores) and a second launch sums
+ * them in a FIXED order into dW / db: no fp32 atomics (10 splits x 7.1 MB of them per ViT block otherwise, ~50 us of the launch),
+ * bit-reproducible weight gradients.  sais_gemm_tn_grouped_slab_bytes returns the bytes that launch uses (0: no slab form applies
+ * and `slabs` is ignored); slabs 16-B aligned; NULL = fp32 atomics.  Environment, read once per process: SAIS_TN_XL = 0 selects
+ * the 128 x 384 kernel of rounds 2-5 (whose own slab form stays opt-in: SAIS_TN_SLABS = 1), SAIS_TN_XL = 8 the eight-wave form
+ * of the large tile, SAIS_TN_XL_SLABS = 0 its atomics (LABNOTES R6.1).                                                      */
 size_t sais_gemm_tn_grouped_slab_bytes(const SaisTnItem* items, int nitems, int M);
 int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int M, int nsplit, void* slabs, size_t slab_bytes, void* stream);
 /* the same with FP32 P and Q (rounded to bf16 while staging, like sais_gemm_tn_f32): one launch for the four weight

@@ -33,6 +33,7 @@ import os as _os
 
 _LAYER_CALLS = _os.environ.get('SAIS_TEMPORAL_LAYER_CALLS', '1') != '0'      # one C call per encoder layer and direction
 _PREFETCH = _os.environ.get('SAIS_TEMPORAL_PREFETCH', '0') == '1'        # measured: no net gain (LABNOTES R4.3): off
+_TTA_MERGE = _os.environ.get('SAIS_TTA_MERGE', '1') != '0'            # inference: all TTA versions and both streams in ONE encoder pass
 _DW_DEFER = _os.environ.get('SAIS_TEMPORAL_DW_DEFER', '1') != '0'       # all layers' weight gradients in ONE launch after the dX chain
 D, TH, FF, EMB, NPOS = 384, 4, 2048, 256, 2000
 
@@ -224,6 +225,8 @@ class fullModel(nn.Module):
             second = torch.tensor([0 if d == 'NH_02' else 1 for d in domains], dtype=torch.uint8, device=dev)
         if isinstance(x, (list, tuple)) or isinstance(f, (list, tuple)):          # TTA versions, :331-346
             n = len(x) if x is not None else len(f)
+            if _TTA_MERGE and not self.importance_loss and not (torch.is_grad_enabled() and self.linear.weight.requires_grad):
+                return self._forward_tta_merged(x, f, xpad, fpad, second, n)
             embs, attn0, imp0 = [], None, None
             for v in range(n):
                 e, a, im = self._forward_one(None if x is None else x[v], None if f is None else f[v],
@@ -234,6 +237,56 @@ class fullModel(nn.Module):
             return (imp0, embs, attn0) if self.importance_loss else (embs, attn0)
         emb, attn, imp = self._forward_one(x, f, xpad, fpad, second)
         return (imp, emb, attn) if self.importance_loss else (emb, attn)          # :444-448
+
+    def _forward_tta_merged(self, xs, fs, xpads, fpads, second, n):
+        """Inference over the TTA versions (prepare_model.py:331-346) as ONE encoder pass: every version of both streams goes
+        through the SAME `transEncoderFrame` (:381-399), a sequence's output does not depend on its batch mates, and padded
+        positions are masked keys — so the n x (RGB, flow) little passes (6 x 4 layers x 7 launches of 5-15 us for a window
+        batch; 20 % of a long video's inference time, LABNOTES R5.3) are stacked along the sequence axis, padded to the longest
+        version under the key-padding mask, and run once.  Same values as the per-version passes up to the summation order of
+        the masked softmax (tests: test_temporal_tta_list_path, test_tta_merged_pass_equals_per_version_passes)."""
+        use_x = self.modalities in ('RGB', 'RGB-Flow')
+        use_f = self.modalities in ('Flow', 'RGB-Flow')
+        parts = []                                               # (stream, version, [B, ns, T, 384], mask [B * ns, T + 1])
+        for name, on, ts, pads in (("x", use_x, xs, xpads), ("f", use_f, fs, fpads)):
+            if not on:
+                continue
+            for v in range(n):
+                t = self._check(None if ts is None else ts[v], name)
+                parts.append((name, v, t, self._mask(None if pads is None else pads[v], t, t.device)))
+        dev = parts[0][2].device
+        fl = self._engine(dev)
+        Tm = max(t.shape[2] for _, _, t, _ in parts)
+        S = Tm + 1
+        tot = sum(t.shape[0] * t.shape[1] for _, _, t, _ in parts)
+        X = torch.zeros(tot, 1, Tm, D, dtype=torch.float32, device=dev)
+        P = torch.ones(tot, S, dtype=torch.uint8, device=dev)
+        where, off = {}, 0
+        for name, v, t, m in parts:
+            k, T = t.shape[0] * t.shape[1], t.shape[2]
+            X[off:off + k, 0, :T] = t.reshape(k, T, D)
+            P[off:off + k, :T + 1] = m
+            where[(name, v)] = (off, k, T)
+            off += k
+        z, attn, _ = self._stream_fwd(X, P, save=False, want_attn=True)
+        z = z.view(tot, S * D)
+        ref = parts[0][2]
+        B, ns = ref.shape[0], ref.shape[1]
+        embs = []
+        for v in range(n):
+            zr = z[where[("x", v)][0]:where[("x", v)][0] + B * ns] if use_x else None
+            zf = z[where[("f", v)][0]:where[("f", v)][0] + B * ns] if use_f else None
+            if use_x and use_f and where[("x", v)][1] != where[("f", v)][1]:
+                raise ValueError("RGB and flow streams must have the same batch size and number of snippets")
+            rep = torch.empty(B, D, dtype=torch.float32, device=dev)
+            emb = torch.empty(B, EMB, dtype=torch.float32, device=dev)
+            ops.head_fwd(zr, zf, S * D, B, fl.w32("linear.weight"), fl.w32("linear.bias"), rep, emb, clip_stride_flow=S * D,
+                         nsnippets=ns, second=None if second is None else (second, fl.w32("linearB.weight"), fl.w32("linearB.bias")))
+            embs.append(emb)
+        # the returned map is version 0's, of the RGB stream when there is one (:436-443): its own [T0 + 1, T0 + 1] corner
+        o0, k0, T0 = where[("x", 0) if use_x else ("f", 0)]
+        attn0 = attn[o0:o0 + k0, :T0 + 1, :T0 + 1].contiguous()
+        return embs, attn0
 
     def _forward_one(self, x, f, xpad, fpad, second=None):
         use_x = self.modalities in ('RGB', 'RGB-Flow')

@@ -67,9 +67,10 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     for it, (n1, n2) in zip(items, ((384, 1536), (1536, 384), (384, 384), (1152, 384))):
         it.N1, it.N2 = n1, n2
     lib.sais_gemm_tn_grouped_slab_bytes.restype = ctypes.c_size_t
-    assert lib.sais_gemm_tn_grouped_slab_bytes(items, 4, M) == 36 * 7 * (128 * 384 * 4 + 512)      # 36 wide tiles x 7 M-splits
+    # round 6: the ViT block's launch runs on 192 x 384 tiles: 24 tiles x 10 M-splits, raw partial tile + bias tile per wave
+    assert lib.sais_gemm_tn_grouped_slab_bytes(items, 4, M) == 24 * 10 * (192 * 384 * 4 + 4 * 32 * 32 * 4)
     assert lib.sais_gemm_tn_grouped_slab_bytes(items, 4, 300) == 0 and lib.sais_gemm_tn_grouped_slab_bytes(None, 4, M) == 0
-    assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_BWD, 256, 197) >= M * (1536 + 3 * 384 + 1152) * 2 + 36 * 7 * 128 * 384 * 4
+    assert lib.sais_workspace_bytes(_lib.OP_VIT_BLOCK_BWD, 256, 197) >= M * (1536 + 3 * 384 + 1152) * 2 + 24 * 10 * 192 * 384 * 4
     assert lib.sais_gemm_tn_grouped_ws(None, 4, M, 7, None, 0, None) == -1
     assert lib.sais_im2col_f32(None, 3, 8, 8, 3, 3, 1, 1, 1, 1, None, 64, 128, None) == -1
     assert lib.sais_workspace_bytes(_lib.OP_TEMPORAL_LAYER_FWD, 8, 33) >= 8 * 264 * 384 * 4

@@ -267,7 +267,8 @@ def test_main_sh_on_jpeg_frames_end_to_end(gpu, tmp_path):
 def test_cli_inference_sharded_over_two_ranks_equals_single_process(gpu, tmp_path):
     """SURVEY 8e, inference: frames (extract_representations.py) and window batches (run_experiments.py --inference) are
     sharded over the ranks of `torch.distributed.run`, results gathered in rank order, rank 0 writes.  Two ranks sharing
-    this box's GPU (gloo) must write the same files, bit for bit, as one process."""
+    this box's GPU (gloo) must write the same feature files, bit for bit, as one process, and the same window outputs up to fp32
+    summation order."""
     from sais_amd import model_io
     from sais_amd.hdf5_min import read_h5
     from sais_amd.temporal import fullModel
@@ -307,9 +308,11 @@ def test_cli_inference_sharded_over_two_ranks_equals_single_process(gpu, tmp_pat
     nwin = (100 - 15) // 15 + 1
     assert r2["videonames"] == r1["videonames"] == ["vid_01"] * nwin
     for v in range(3):
-        assert len(r2["reps"][v]) == nwin and all(torch.equal(x, y) for x, y in zip(r1["reps"][v], r2["reps"][v]))
+        # all TTA versions of a rank's windows run as ONE encoder pass (round 6): its row count, and with it the split-K summation
+        # order of the N = 384 GEMMs, depends on how many windows the rank holds -> equal to fp32 rounding, no longer bit for bit
+        assert len(r2["reps"][v]) == nwin and all(float((x - y).abs().max()) <= 5e-5 for x, y in zip(r1["reps"][v], r2["reps"][v]))
     # the head-averaged map is summed over the 4 heads with fp32 atomics: equal up to the order of those four additions
-    assert len(a1) == len(a2) == (nwin + 1) // 2 and all(float((x - y).abs().max()) <= 1e-7 for x, y in zip(a1, a2))
+    assert len(a1) == len(a2) == (nwin + 1) // 2 and all(float((x - y).abs().max()) <= 1e-6 for x, y in zip(a1, a2))
 
 
 def test_long_feature_file_runs_in_chunks_of_256_windows(gpu):

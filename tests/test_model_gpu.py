@@ -164,6 +164,41 @@ def test_temporal_tta_list_path(gpu, golden):
     assert maxabs(attn, g["TTA/attn"]) <= ATTN_TOL
 
 
+@pytest.mark.parametrize("mod", ["RGB-Flow", "RGB", "Flow"])
+def test_tta_merged_pass_equals_per_version_passes(gpu, mod):
+    """Inference runs the three TTA versions of both streams as ONE encoder pass (stacked sequences, padded under the key mask):
+    embeddings and the returned attention map must equal the per-version passes (ragged lengths inside a version included)."""
+    from sais_amd import temporal as tmod
+    m = make_full(2, mod).eval()
+    xs, fs, xp, fp, xl, fl = [], [], [], [], [], []
+    for v, T in enumerate((15, 12, 9)):
+        lens = [T, T - 2, T]
+        x = synth.reps(seed=900 + v, B=3, T=T)
+        for b, n in enumerate(lens):
+            x[b, :, n:] = 0
+        flen = [2, 1, 2]
+        f = synth.reps(seed=950 + v, B=3, T=2)
+        f[1, :, 1:] = 0
+        xs.append(x.to(DEV)); fs.append(f.to(DEV))
+        xp.append(synth.padding_mask(lens).to(DEV)); fp.append(synth.padding_mask(flen).to(DEV))
+        xl.append(lens); fl.append(flen)
+    args = (xs if mod != "Flow" else None, fs if mod != "RGB" else None, xl, fl, 'Prototypes',
+            xp if mod != "Flow" else None, fp if mod != "RGB" else None, None)
+    old = tmod._TTA_MERGE
+    try:
+        with torch.no_grad():
+            tmod._TTA_MERGE = True
+            e1, a1 = m(*args)
+            tmod._TTA_MERGE = False
+            e0, a0 = m(*args)
+    finally:
+        tmod._TTA_MERGE = old
+    assert a1.shape == a0.shape
+    for v in range(3):
+        assert maxabs(e1[v], e0[v].cpu().numpy()) <= 1e-4          # embeddings of magnitude ~3: split-K order differs with M
+    assert maxabs(a1, a0.cpu().numpy()) <= 1e-5
+
+
 @pytest.mark.parametrize("C", [2, 3])
 def test_loss_logits_and_grads_vs_golden(gpu, golden, C):
     from sais_amd.loss import calcNCELoss, cosine_logits_and_probs
