@@ -194,6 +194,47 @@ class FeatureExtractor:
         return out
 
 
+def collate_windows_merged(rgb_reps, flow_reps, wins):
+    """The 15-frame windows of gesture_windows (hop 15, jump 1) of ONE video as a single stacked batch for fullModel._tta_core:
+    X f32 [6 B, 1, 15, 384] (RGB versions 0-2, then flow versions 0-2; zero padded), P u8 [6 B, 16] (1 = masked key) and the
+    layout dict.  Same rows, zeros and masks as collate_windows_tta / pad_collate_tta give version by version
+    (tests/test_host_cpu.py), built from ONE index array, one host-to-device copy and one gather over [rgb_reps; flow_reps]."""
+    dev = rgb_reps.device
+    N, nflow = rgb_reps.shape[0], flow_reps.shape[0]
+    B = len(wins)
+    starts = np.asarray([s for s, _ in wins], dtype=np.int64)
+    assert all(e - s == DURATION_FRAMES for s, e in wins)
+    Tm = DURATION_FRAMES
+    idx = np.zeros((6 * B, Tm), dtype=np.int64)
+    lens = np.zeros(6 * B, dtype=np.int64)
+    where = {}
+    for v, off in enumerate(TTA_OFFSETS):
+        Lv = DURATION_FRAMES - off
+        first = starts - 1 + off                                     # may be -1: wraps to the last frame, as in the reference
+        rix = first[:, None] + np.arange(Lv, dtype=np.int64)[None, :]
+        idx[v * B:(v + 1) * B, :Lv] = np.where(rix < 0, rix + N, rix)
+        lens[v * B:(v + 1) * B] = Lv
+        where[("x", v)] = (v * B, B, Lv)
+        r0, r1 = first // FLOW_JUMP, (first + Lv - 1) // FLOW_JUMP    # floor division: -1 // 15 = -1 survives `< nflow` and wraps
+        k0, k1 = r0 < nflow, (r1 != r0) & (r1 < nflow)
+        # kept rows first (unique() order), as flow_reps[rows] gives them
+        a = np.where(k0, r0, r1)
+        b = np.where(k0 & k1, r1, 0)
+        n_f = k0.astype(np.int64) + k1.astype(np.int64)
+        fo = (3 + v) * B
+        idx[fo:fo + B, 0] = N + np.where(a < 0, a + nflow, a) * (n_f > 0)
+        idx[fo:fo + B, 1] = N + np.where(b < 0, b + nflow, b) * (n_f > 1)
+        lens[fo:fo + B] = n_f
+        where[("f", v)] = (fo, B, 2)
+    keep = np.arange(Tm)[None, :] < lens[:, None]
+    idx = np.where(keep, idx, 0)
+    packed = torch.from_numpy(np.concatenate([idx, keep.astype(np.int64)], 1)).to(dev, non_blocking=True)
+    table = torch.cat([rgb_reps, flow_reps], 0)
+    X = (table[packed[:, :Tm]] * packed[:, Tm:].unsqueeze(-1).to(table.dtype)).unsqueeze(1)
+    P = torch.cat([torch.zeros(6 * B, 1, dtype=torch.uint8, device=dev), (1 - packed[:, Tm:]).to(torch.uint8)], 1)
+    return X, P, where
+
+
 # --------------------------------------------------------------------------- windowed temporal inference
 class _WindowGraph:
     """The temporal encoder over ONE fixed-size chunk of windows (all three TTA versions, both streams) captured into a
@@ -263,6 +304,9 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
     if use_graph:
         cb = min(cb, 32)
     emb_parts, attn_parts, imp_parts = ([], [], []), [], []
+    from . import temporal as _tmod
+    fast = (not use_graph and _tmod._TTA_MERGE and model.modalities == "RGB-Flow" and not model.importance_loss
+            and '+' not in model.domain and all(e - s == DURATION_FRAMES for s, e in mine))
     for i in range(0, len(mine), cb):
         chunk = mine[i:i + cb]
         n = len(chunk)
@@ -273,6 +317,10 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
             if key not in graphs:
                 graphs[key] = _WindowGraph(model, c, use_f)
             out = graphs[key].replay(c)
+        elif fast:
+            # one stacked batch, one encoder pass (fullModel._tta_core): no per-version tensors on the way in
+            X, P, where = collate_windows_merged(rgb_reps, flow_reps, chunk)
+            out = model._tta_core(X, P, where, n, 1, 3)
         else:
             c = collate_windows_tta(rgb_reps, flow_reps, chunk)
             out = model(c["x"], c["f"] if use_f else None, c["xlens"], c["flens"], 'Prototypes', c["xpad"],
@@ -283,16 +331,23 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
         else:
             embs, attn = out
         for v in range(3):
-            emb_parts[v].append(embs[v].detach()[:n].clone())        # clone: the graph's static outputs are overwritten by the next replay
-        attn_parts.append(attn.detach()[:n].clone())
+            e = embs[v].detach()[:n]
+            emb_parts[v].append(e.clone() if use_graph else e)        # clone: the graph's static outputs are overwritten by the next replay
+        attn_parts.append(attn.detach()[:n].clone() if use_graph else attn.detach()[:n])
     if mine:
-        embs_cpu = [torch.cat(p).cpu() for p in emb_parts]           # ONE device -> host copy per output
-        attn_cpu = torch.cat(attn_parts).cpu()
+        # ONE device -> host copy: [embeddings of the three versions | attention maps] packed row-wise per window; the per-sample /
+        # per-batch tensors the reference saves are views of that one host tensor (torch.save stores the shared storage once)
+        embs_d = [torch.cat(p) if len(p) > 1 else p[0] for p in emb_parts]
+        attn_d = torch.cat(attn_parts) if len(attn_parts) > 1 else attn_parts[0]
+        nw, E = attn_d.shape[0], embs_d[0].shape[1]
+        ashape = attn_d.shape[1:]
+        packed = torch.cat(embs_d + [attn_d.reshape(nw, -1)], 1).cpu()
         imp_cpu = torch.cat(imp_parts).cpu() if imp_parts else None
         for v in range(3):
-            reps[v].extend(e.clone() for e in embs_cpu[v].unbind(0))
+            reps[v].extend(packed[:, v * E:(v + 1) * E].unbind(0))
+        attn_cpu = packed[:, 3 * E:].reshape(nw, *ashape)
         for i in range(0, len(mine), batch_size):                    # the reference's per-batch tensors
-            attention.append(attn_cpu[i:i + batch_size].clone())
+            attention.append(attn_cpu[i:i + batch_size])
             if imp_cpu is not None:
                 importance.append(imp_cpu[i:i + batch_size].clone())
         labels += [torch.tensor(0, dtype=torch.long)] * len(mine)            # placeholder label (:2637)

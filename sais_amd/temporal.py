@@ -255,7 +255,7 @@ class fullModel(nn.Module):
                 t = self._check(None if ts is None else ts[v], name)
                 parts.append((name, v, t, self._mask(None if pads is None else pads[v], t, t.device)))
         dev = parts[0][2].device
-        fl = self._engine(dev)
+        self._engine(dev)
         Tm = max(t.shape[2] for _, _, t, _ in parts)
         S = Tm + 1
         tot = sum(t.shape[0] * t.shape[1] for _, _, t, _ in parts)
@@ -268,10 +268,19 @@ class fullModel(nn.Module):
             P[off:off + k, :T + 1] = m
             where[(name, v)] = (off, k, T)
             off += k
+        ref = parts[0][2]
+        return self._tta_core(X, P, where, ref.shape[0], ref.shape[1], n, second)
+
+    def _tta_core(self, X, P, where, B, ns, n, second=None):
+        """X f32 [tot, 1, Tm, 384] stacked sequences (zero padded), P u8 [tot, Tm + 1] key-padding masks, where[(stream, version)] =
+        (first sequence, count, T): one encoder pass, then the head per version.  Returns (embs, version 0's attention map)."""
+        use_x = self.modalities in ('RGB', 'RGB-Flow')
+        use_f = self.modalities in ('Flow', 'RGB-Flow')
+        dev = X.device
+        fl = self._engine(dev)
+        tot, S = X.shape[0], X.shape[2] + 1
         z, attn, _ = self._stream_fwd(X, P, save=False, want_attn=True)
         z = z.view(tot, S * D)
-        ref = parts[0][2]
-        B, ns = ref.shape[0], ref.shape[1]
         embs = []
         for v in range(n):
             zr = z[where[("x", v)][0]:where[("x", v)][0] + B * ns] if use_x else None

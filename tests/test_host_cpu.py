@@ -409,6 +409,33 @@ def test_vectorised_window_collate_equals_the_per_window_path():
             assert a["xlens"] == b["xlens"] and a["flens"] == b["flens"]
 
 
+def test_stacked_window_collate_equals_the_per_version_tensors():
+    """collate_windows_merged (ONE stacked batch for the single encoder pass of the inference path) holds, sequence by sequence, the
+    rows, zero padding and key masks of pad_collate_tta([sample_window(...)]) — wrap-around of the first window, one or two flow
+    rows, flow rows filtered at the end of the flow features."""
+    from sais_amd.inference import collate_windows_merged, gesture_windows, pad_collate_tta, sample_window
+    g = torch.Generator().manual_seed(12)
+    for n, nflow in ((512, 34), (512, 33), (77, 5), (45, 3), (15, 1), (200, 14), (200, 12)):
+        rgb, flow = torch.randn(n, 384, generator=g), torch.randn(nflow, 384, generator=g)
+        wins = gesture_windows(n)
+        for sub in (wins, wins[:1], wins[1:4], wins[-2:]):
+            if not sub:
+                continue
+            X, P, where = collate_windows_merged(rgb, flow, sub)
+            b = pad_collate_tta([sample_window(rgb, flow, s, e) for s, e in sub])
+            B = len(sub)
+            assert X.shape == (6 * B, 1, 15, 384) and P.shape == (6 * B, 16) and P.dtype == torch.uint8
+            for key in ("x", "f"):
+                for v in range(3):
+                    o, k, T = where[(key, v)]
+                    ref, mask, lens = b[key][v], b[key + "pad"][v], b[key + "lens"][v]
+                    Tv = ref.shape[2]
+                    assert k == B and T >= Tv
+                    assert torch.equal(X[o:o + B, 0, :Tv], ref[:, 0]) and not X[o:o + B, 0, Tv:].any(), (n, nflow, key, v)
+                    assert torch.equal(P[o:o + B, :Tv + 1].bool(), mask[:, 0]) and P[o:o + B, Tv + 1:].all()
+                    assert [int(t) for t in (1 - P[o:o + B, 1:].long()).sum(1)] == lens
+
+
 def test_window_sampler_matches_the_reference_dataset(golden):
     """Frame / flow-row indices of every Custom_inference window and TTA version vs tests/golden/sampler.npz, which
     was produced by the reference's own VideoDataset.__getitem__ (make_golden_sampler.py)."""
