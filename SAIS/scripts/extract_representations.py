@@ -111,9 +111,15 @@ def extract_flows(args, t0):
             rows = list(csv.DictReader(fh))
         if args.video:
             rows = [r for r in rows if r['label'] == args.video]
-        want = {}
+        # files per video = DISTINCT flow numbers (two CSV rows that map to the same frame // jump overwrite one file: counting rows
+        # would make such a folder look incomplete on every later run)
+        def nflow_of(r):
+            p1 = r['path1'].replace('\\', '/')
+            return int(p1.split('frames_' if 'frames' in p1 else 'frame_')[-1].strip('.jpg')) // jump
+        distinct = {}
         for r in rows:
-            want[r['label']] = want.get(r['label'], 0) + 1
+            distinct.setdefault(r['label'], set()).add(nflow_of(r))
+        want = {lab: len(v) for lab, v in distinct.items()}
         done = {lab for lab, n in want.items() if complete(lab, n)}
         rows = [r for r in rows if r['label'] not in done]
         if rows and not args.raft_checkpoint and not args.raft_random_weights:
@@ -125,10 +131,17 @@ def extract_flows(args, t0):
             model = get_model()
         for lab in set(want) - done:                 # a stale marker / partial folder must not survive a failed run
             mk = os.path.join(args.data_path, 'flows', lab, FLOW_MARKER)
-            if os.path.exists(mk):
+            had_marker = os.path.exists(mk)
+            if had_marker:
                 os.remove(mk)
+            mine = glob.glob(os.path.join(args.data_path, 'flows', lab, 'flows_*.jpg'))
+            if mine and not had_marker and args.raft_random_weights and not args.raft_checkpoint:
+                raise SystemExit('[flow] flows/%s holds %d flows_*.jpg that this script did not write (no %s) and fewer than the %d '
+                                 'the video needs: refusing to overwrite them with maps from seeded RANDOM weights.  Move them away, '
+                                 'complete them, or pass --raft_checkpoint.' % (lab, len(mine), FLOW_MARKER, want[lab]))
         bs = max(1, args.batch_size_per_gpu)
         nsaved = 0
+        saved = {}                                   # label -> flow numbers written in this run
         for i in range(0, len(rows), bs):
             chunk = rows[i:i + bs]
             pairs, nflows = [], []
@@ -158,8 +171,12 @@ def extract_flows(args, t0):
                     out = os.path.join(args.data_path, 'flows', chunk[k]['label'])
                     os.makedirs(out, exist_ok=True)
                     img.save(os.path.join(out, 'flows_%08d.jpg' % nflows[k]))         # :254-262
+                    saved.setdefault(chunk[k]['label'], set()).add(nflows[k])
                     nsaved += 1
-        for lab in set(want) - done:                 # every row of the video is on disk: the folder now counts as complete
+        for lab in set(want) - done:                 # complete only when every distinct flow number of the video was written
+            if len(saved.get(lab, ())) != want[lab]:
+                print(f'[flow] {lab}: {len(saved.get(lab, ()))} of {want[lab]} flow maps written: folder left unmarked (incomplete)')
+                continue
             with open(os.path.join(args.data_path, 'flows', lab, FLOW_MARKER), 'w') as fh:
                 json.dump({'count': want[lab], 'weights': weights, 'iters': args.raft_iters}, fh)
         print(f'[flow] {dataset}: {nsaved} flow maps saved' + (f' ({len(done)} videos already had flows)' if done else ''))

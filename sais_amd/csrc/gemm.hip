@@ -437,6 +437,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
     }
 }
 
+// ---- EXPERIMENT RECORDS (built only with -DSAIS_EXPERIMENTAL=1: tools/build_variant.sh exp -DSAIS_EXPERIMENTAL=1) ----------------
+// Three other organisations of the persistent K = 384 GEMM, each correct, each measured slower than gemm_nt_w8p_kernel
+// (LABNOTES R5.1, R5.2, R5.6).  The default library does not contain them; the switches SAIS_NT_W8R / _W16 / _W4 are then ignored.
+#ifndef SAIS_EXPERIMENTAL
+#define SAIS_EXPERIMENTAL 0
+#endif
+#if SAIS_EXPERIMENTAL
 // ---------------------------------------------------------------------------------------------
 // W in registers (round 5, LABNOTES R5.6; K = 384 only, the K loop fully unrolled).  The stamps of R5.2 show a K-step of the
 // kernel above taking 1 200-1 700 cycles of a wave's time for 256 cycles of its MFMAs: W(kt + 1) is requested at the top of step
@@ -879,10 +886,14 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_w4q_kernel(NtParams p, int nti
     }
 }
 
+#endif  // SAIS_EXPERIMENTAL
+
 #ifdef SAIS_NT_STAMP
+#if SAIS_EXPERIMENTAL
 extern "C" int sais_debug_nt16_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt16_stamps), sizeof(unsigned long long) * 16 * 36) == hipSuccess ? 0 : -2;
 }
+#endif
 extern "C" int sais_debug_nt_stamps(unsigned long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 8 * 16) == hipSuccess ? 0 : -2;
 }
@@ -1601,8 +1612,8 @@ static constexpr bool w4_epi(int e) {
     return e == SAIS_EPI_BIAS_BF16 || e == SAIS_EPI_BIAS_GELU_GRAD_BF16 || e == SAIS_EPI_MUL_BF16 || e == SAIS_EPI_BIAS_GELU_BF16 ||
            e == SAIS_EPI_BIAS_RELU_BF16;
 }
-#define LAUNCH_NT(E)                                                                        \
-    case E:                                                                                 \
+#if SAIS_EXPERIMENTAL
+#define LAUNCH_NT_EXP(E)                                                                    \
         if (big && nt_w8r && w4_epi(E) && g->K == 6 * BK) {                                 \
             static thread_local bool set8r = false;                                         \
             if (!set8r) {                                                                   \
@@ -1629,7 +1640,14 @@ static constexpr bool w4_epi(int e) {
             const int nt_ = (int)grid.x;                                                    \
             hipLaunchKernelGGL(gemm_nt_w4q_kernel<E>, dim3(nt_ < 1024 ? nt_ : 1024), dim3(256), 5 * QTILE, \
                                (hipStream_t)stream, p, nt_);                                \
-        } else if (big) {                                                                   \
+        } else
+#else
+#define LAUNCH_NT_EXP(E)
+#endif
+#define LAUNCH_NT(E)                                                                        \
+    case E:                                                                                 \
+        LAUNCH_NT_EXP(E)                                                                    \
+        if (big) {                                                                          \
             static thread_local bool set8p = false;                                         \
             if (!set8p) {                                                                   \
                 if (hipFuncSetAttribute((const void*)gemm_nt_w8p_kernel<E>,                 \
@@ -1902,6 +1920,7 @@ extern "C" int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int 
             hipLaunchKernelGGL(gemm_tn_pp_kernel<true>, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)slabs);
             hipLaunchKernelGGL(tn_slab_finish_kernel, dim3(wt * (8 * 24 * 64) / 256 + (wt * 128 + 255) / 256), dim3(256), 0, (hipStream_t)stream, wg, (const float*)slabs, wns);
         } else {
+#if SAIS_EXPERIMENTAL
             static const int tn_ni = [] { const char* e = getenv("SAIS_TN_NI"); return e ? atoi(e) : 4; }();
             if (tn_ni == 2) {
                 static thread_local bool set2 = false;
@@ -1912,6 +1931,7 @@ extern "C" int sais_gemm_tn_grouped_ws(const SaisTnItem* items, int nitems, int 
                 }
                 hipLaunchKernelGGL((gemm_tn_pp_kernel<false, 2>), dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)nullptr);
             } else
+#endif
             hipLaunchKernelGGL(gemm_tn_pp_kernel<false>, dim3(wt * wns), dim3(512), 2 * WSTAGE, (hipStream_t)stream, wg, (float*)nullptr);
         }
         return sais_check_launch();

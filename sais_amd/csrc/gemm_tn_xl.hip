@@ -62,6 +62,9 @@ template <int N> DEVINL void xl_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 #ifndef SAIS_XL_ABL
 #define SAIS_XL_ABL 0
 #endif
+#ifndef SAIS_EXPERIMENTAL
+#define SAIS_EXPERIMENTAL 0
+#endif
 
 // SLAB: instead of fp32 atomics (75 MB per ViT block at 10 splits: ~50 us of the launch, LABNOTES R6.1: the chip retires ~1.5 TB/s
 // of them and every workgroup flushes at the same moment) each workgroup stores its raw partial tile ONCE, in register order
@@ -437,6 +440,7 @@ static bool xl_plan(const SaisTnItem* items, int nitems, int M, XlGroup& gp) {
 }
 
 static size_t xl_slab_need(const XlGroup& gp, int nwaves) {
+    if (!SAIS_EXPERIMENTAL) nwaves = 4;
     const int nt_wave = nwaves == 8 ? 9 : 18;
     const size_t nwg = (size_t)gp.ntiles * gp.nsplit;
     return nwg * nwaves * nt_wave * 4 * 64 * 16 + nwg * nwaves * 4 * 64 * 16;
@@ -474,6 +478,8 @@ extern "C" int sais_gemm_tn_xl_(const SaisTnItem* items, int nitems, int M, int 
     if (!xl_plan(items, nitems, M, gp)) return 0;
     const bool slab = slabs != nullptr && gp.nsplit >= 2;
     if (slab && (slab_bytes < xl_slab_need(gp, nwaves) || ((uintptr_t)slabs & 15))) return SAIS_ERR_ARG;
+#if SAIS_EXPERIMENTAL      // the eight-wave form of the same tile (two waves per SIMD, compiler-scheduled): slower, LABNOTES R6.1
     if (nwaves == 8) return slab ? xl_launch<8, true>(gp, (float*)slabs, (hipStream_t)stream) : xl_launch<8, false>(gp, nullptr, (hipStream_t)stream);
+#endif
     return slab ? xl_launch<4, true>(gp, (float*)slabs, (hipStream_t)stream) : xl_launch<4, false>(gp, nullptr, (hipStream_t)stream);
 }

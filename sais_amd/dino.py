@@ -588,8 +588,12 @@ class GraphedTrainStep:
         self._graph = torch.cuda.CUDAGraph()
         # RCCL collectives inside (a gradient exchange is active): ProcessGroupNCCL's watchdog thread makes HIP calls of its own
         # while this thread captures.  A process group that merely exists (world 1, no exchange) keeps the strict mode.
+        # An RCCL process group that exists is enough: DINOLoss.update_center all-reduces the column sums inside the
+        # captured region whenever torch.distributed is initialised, world 1 included (main_dino.py always initialises one).
+        import torch.distributed as dist
         sync = getattr(self.optimizer, "_sync", None)
-        mode = "thread_local" if (sync is not None and getattr(sync, "active", False)) else "global"
+        nccl = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+        mode = "thread_local" if (nccl or (sync is not None and getattr(sync, "active", False))) else "global"
         with torch.cuda.graph(self._graph, capture_error_mode=mode):
             self._out = fn()
         self._temp = float(self.dino_loss.teacher_temp_schedule[epoch])

@@ -144,6 +144,7 @@ class FeatureExtractor:
         self.tail = tail_batch if tail_batch and tail_batch < batch_size else None
         self.use_graph = use_graph
         self._graphs = {}                                             # frames per replay -> (graph, static_in, static_out)
+        self._sig = None
 
     def _capture(self, device, bs):
         static_in = torch.zeros(bs, 3, 224, 224, device=device)
@@ -158,6 +159,13 @@ class FeatureExtractor:
             with torch.cuda.graph(graph):
                 static_out = self.vit(static_in)
         self._graphs[bs] = (graph, static_in, static_out)
+        self._sig = self._weights_sig(device)
+
+    def _weights_sig(self, device):
+        """The captured launches hold pointers into the ViT's weight shadows and were recorded against one set of weights: a later
+        load_state_dict / optimizer step (FlatParams.signature) or a reallocated flat buffer makes every captured graph stale."""
+        fl = self.vit._engine(device)
+        return (fl.signature(self.vit._sentinels), fl.flat.data_ptr())
 
     # the attributes older callers / tests read: the main shape's graph
     @property
@@ -177,6 +185,8 @@ class FeatureExtractor:
             bs = self.bs if (left >= self.bs or self.tail is None) else self.tail
             n = min(bs, left)
             if self.use_graph:
+                if self._graphs and self._weights_sig(frames.device) != self._sig:
+                    self._graphs.clear()                              # the weights changed since the capture: never replay those
                 if bs not in self._graphs:
                     self._capture(frames.device, bs)
                 graph, static_in, static_out = self._graphs[bs]
@@ -303,17 +313,27 @@ def run_windows(model, rgb_reps, flow_reps, videoname="video", batch_size=2, tot
     cb = max(batch_size, (int(compute_batch) // batch_size) * batch_size)     # whole batches per call
     if use_graph:
         cb = min(cb, 32)
+    if model.modalities == "Flow":
+        # the returned map is the FLOW stream's [B, Tf + 1, Tf + 1] with Tf the longest flow sequence of the BATCH (one or two rows):
+        # a wider compute chunk would change the shape the reference saves for a batch whose windows all have one flow row
+        cb, use_graph = batch_size, False
     emb_parts, attn_parts, imp_parts = ([], [], []), [], []
     from . import temporal as _tmod
-    fast = (not use_graph and _tmod._TTA_MERGE and model.modalities == "RGB-Flow" and not model.importance_loss
-            and '+' not in model.domain and all(e - s == DURATION_FRAMES for s, e in mine))
+    fast = (not use_graph and _tmod._TTA_MERGE and hasattr(model, "_tta_core") and model.modalities == "RGB-Flow"
+            and not model.importance_loss and '+' not in getattr(model, "domain", "")
+            and all(e - s == DURATION_FRAMES for s, e in mine))
     for i in range(0, len(mine), cb):
         chunk = mine[i:i + cb]
         n = len(chunk)
         if use_graph:
             c = collate_windows_tta(rgb_reps, flow_reps, chunk + [chunk[-1]] * (cb - n), pad_flow_to=_WindowGraph.FLOW_PAD)
             graphs = model.__dict__.setdefault("_window_graphs", {})
-            key = (cb, str(rgb_reps.device), tuple(tuple(t.shape) for t in c["x"] + c["f"]))
+            # the captured launches hold pointers into the model's weight shadows: a graph is valid only for the weights it was captured
+            # with (FlatParams.signature changes on load_state_dict / an optimizer step, and shadows may then be reallocated)
+            sig = model._engine(rgb_reps.device).signature(model._sentinels())
+            key = (cb, str(rgb_reps.device), tuple(tuple(t.shape) for t in c["x"] + c["f"]), sig, model.flat.flat.data_ptr())
+            for k in [k for k in graphs if k[:3] == key[:3] and k != key]:
+                del graphs[k]                                    # stale weights: drop, never replay
             if key not in graphs:
                 graphs[key] = _WindowGraph(model, c, use_f)
             out = graphs[key].replay(c)

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experimental: rejected kernel forms, built only with -DSAIS_EXPERIMENTAL=1 (not part of -m gpu)")
 
 
 @pytest.fixture(scope="session")
