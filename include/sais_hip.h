@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 10
+#define SAIS_ABI_VERSION 11
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -192,6 +192,13 @@ typedef struct SaisGemmLn {
                                       residual-stream gradient is dres[m / period] when m % period == 0 and ZERO otherwise — the
                                       gradient entering the last ViT block exists on the CLS rows only (period = tokens per frame;
                                       VisionTransformer.forward returns x[:, 0], vision_transformer.py:212-214)            */
+    const void* xn16; int ldxn16;  /* bwd, optional (ABI 11): the bf16 LayerNorm OUTPUT y = xhat * gamma + beta the forward saved for the
+                                      next GEMM and for dW.  With it (and `beta`) the epilogue rebuilds xhat = (y - beta) / gamma from
+                                      768 B per row instead of reading the 1536-B fp32 `resid` row (-38.7 MB per launch at config 2);
+                                      `resid` must still be valid: a workgroup falls back to it when some |gamma_c| < 1e-3 or
+                                      |beta_c| > 64 |gamma_c| (the division would amplify y's bf16 rounding).  xhat enters dx only
+                                      through xhat * mean(dy g xhat), a term ~1/sqrt(384) of dy: measured effect on the ViT parameter
+                                      gradients <= 1e-3 relative (tests).  SAIS_LN_BWD_X16=0 in the environment ignores the field. */
 } SaisGemmLn;
 int sais_gemm_ln_fwd(const SaisGemmLn* g, void* stream);
 int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream);
@@ -244,7 +251,7 @@ typedef struct SaisVitBlockParams {
     const void* proj_w; const float* proj_b;      /* [384,384]  */
     const void* fc1_w;  const float* fc1_b;       /* [1536,384] */
     const void* fc2_w;  const float* fc2_b;       /* [384,1536] */
-    const float* norm1_g;                         /* backward only */
+    const float* norm1_g; const float* norm1_b;   /* backward only (norm1_b: ABI 11, may be NULL = fp32 LayerNorm input path) */
     const float* norm2_g; const float* norm2_b;
     const float* next_norm_g; const float* next_norm_b;   /* forward: norm1 of the NEXT block, or NULL */
     /* backward only: transposed bf16 shadows [in,out] (dX = dY . W runs on the same NT kernels) and f32 gradient accumulators */

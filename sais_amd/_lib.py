@@ -45,7 +45,7 @@ class SaisGemmLn(ctypes.Structure):
                 ("out16", c_void_p), ("ldo16", c_int), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
                 ("mean", c_void_p), ("rstd", c_void_p), ("dres", c_void_p), ("lddres", c_int),
                 ("dgamma", c_void_p), ("dbeta", c_void_p), ("rowscale", c_void_p), ("rowscale16", c_void_p),
-                ("dres_period", c_int)]
+                ("dres_period", c_int), ("xn16", c_void_p), ("ldxn16", c_int)]
 
 
 class SaisMlp(ctypes.Structure):
@@ -56,7 +56,7 @@ class SaisMlp(ctypes.Structure):
 
 class SaisVitBlockParams(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in (
-        "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "norm1_g", "norm2_g", "norm2_b",
+        "qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "norm1_g", "norm1_b", "norm2_g", "norm2_b",
         "next_norm_g", "next_norm_b", "qkv_wt", "proj_wt", "fc1_wt", "fc2_wt", "d_qkv_w", "d_qkv_b", "d_proj_w", "d_proj_b",
         "d_fc1_w", "d_fc1_b", "d_fc2_w", "d_fc2_b", "d_norm1_g", "d_norm1_b", "d_norm2_g", "d_norm2_b")]
 

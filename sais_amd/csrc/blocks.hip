@@ -144,6 +144,7 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
         g.resid = a->x_mid; g.ldr = D; g.out32 = a->dx; g.ldo32 = D; g.out16 = dxb; g.ldo16 = D;
         g.gamma = w->norm2_g; g.mean = (float*)a->mean2; g.rstd = (float*)a->rstd2; g.dres = a->dx; g.lddres = D;
         g.dgamma = w->d_norm2_g; g.dbeta = w->d_norm2_b; g.rowscale16 = a->rowscale_attn;
+        g.xn16 = a->xn2; g.ldxn16 = D; g.beta = w->norm2_b;       // xhat from the saved bf16 norm2 output (ABI 11)
         TRY(sais_gemm_ln_bwd(&g, stream));
     } else {
         TRY(gemm(du, HID, w->fc1_wt, HID, M, D, HID, SAIS_EPI_BIAS_BF16, nullptr, dxn, D, nullptr, 0, nullptr, 0, nullptr, stream));
@@ -175,6 +176,7 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
         g.resid = a->x_in; g.ldr = D; g.out32 = a->dx; g.ldo32 = D; g.out16 = a->dx16_out; g.ldo16 = D;
         g.gamma = w->norm1_g; g.mean = (float*)a->mean1; g.rstd = (float*)a->rstd1; g.dres = a->dx; g.lddres = D;
         g.dgamma = w->d_norm1_g; g.dbeta = w->d_norm1_b; g.rowscale16 = a->rowscale_prev;
+        if (w->norm1_b) { g.xn16 = a->xn1; g.ldxn16 = D; g.beta = w->norm1_b; }
         TRY(sais_gemm_ln_bwd(&g, stream));
     } else {
         TRY(gemm(dqkv, QKV, w->qkv_wt, QKV, M, D, QKV, SAIS_EPI_BIAS_BF16, nullptr, dxn, D, nullptr, 0, nullptr, 0, nullptr, stream));

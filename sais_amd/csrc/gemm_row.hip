@@ -373,6 +373,11 @@ extern "C" int sais_gemm_ln_bwd(const SaisGemmLn* g, void* stream) {
     p.gamma = g->gamma; p.mean = g->mean; p.rstd = g->rstd;
     p.dres = g->dres; p.lddres = g->lddres; p.dres_period = g->dres_period; p.dgamma = g->dgamma; p.dbeta = g->dbeta;
     p.rowscale = g->rowscale16;
+    static const bool x16 = [] { const char* e = getenv("SAIS_LN_BWD_X16"); return e ? atoi(e) != 0 : true; }();
+    if (x16 && g->xn16 && g->beta) {
+        if ((g->ldxn16 & 3) || ((uintptr_t)g->xn16 & 7)) return SAIS_ERR_ARG;
+        p.xn16 = (const bf16*)g->xn16; p.ldxn16 = g->ldxn16; p.beta = g->beta;
+    }
     return launch_row<ROW_LN_BWD>(p, stream);
 }
 

@@ -30,6 +30,7 @@ struct RowParams {
     // the sample the row belongs to.  RESID / LN_FWD: x_out = residual + s (acc + bias).  LN_BWD: the bf16 copy of dx that
     // feeds the NEXT branch's backward GEMMs is s dx (the fp32 residual-stream gradient is not scaled).
     const float* rowscale;
+    const bf16* xn16; int ldxn16;   // LN_BWD, optional: the saved bf16 LayerNorm output; xhat = (xn16 - beta) / gamma instead of (aux - mean) rstd
 };
 
 // acc: this wave's 7 x 6 accumulator tiles; smem: the workgroup's dynamic LDS (>= 32 (NW/4) x 1552 B + 6 KiB; the operand
@@ -304,7 +305,41 @@ DEVINL void row_epilogue(const RowParams& p, f32x4 (&acc)[RMT][6], char* smem, i
             for (int i = tid; i < RBN; i += 64 * NW) gls[i] = p.gamma[i];
 #pragma unroll
             for (int i = 0; i < 12; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
-            float xnext[12], dnext[12], munext, rsnext;
+            float dnext[12], munext, rsnext;
+            unsigned xnext[12];                                      // the prefetched LayerNorm-input row: 12 fp32 or (first six dwords) 12 bf16, as raw bits
+            // bf16 form of the LayerNorm input: the forward's saved OUTPUT y = xhat gamma + beta (half the bytes of the fp32 row).
+            // Used by the whole workgroup or not at all: every column needs a gamma the division does not blow up on.
+            float* const igls = gls + RBN;                           // 1 / gamma
+            float* const bls = igls + RBN;                           // - beta / gamma
+            bool use16 = false;
+            if constexpr (PF == 1) {
+                if (p.xn16 != nullptr) {
+                    int ok = 1;
+                    for (int i = tid; i < RBN; i += 64 * NW) {
+                        const float gv = p.gamma[i], bv = p.beta[i];
+                        igls[i] = 1.0f / gv;
+                        bls[i] = -bv / gv;
+                        ok &= (fabsf(gv) >= 1e-3f && fabsf(bv) <= 64.f * fabsf(gv)) ? 1 : 0;
+                    }
+                    use16 = __syncthreads_and(ok) != 0;
+                }
+            }
+            // the bf16 row travels in the first six dwords of the fp32 row's registers (no second prefetch set)
+            auto ld12h = [&](const bf16* q, unsigned (&v)[12]) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x2 t = *(const u32x2*)(q + 128 * i + 4 * l32);
+                    v[2 * i] = t[0];
+                    v[2 * i + 1] = t[1];
+                }
+            };
+            auto ld12u = [&](const float* q, unsigned (&v)[12]) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x4 t = *(const u32x4*)(q + 128 * i + 4 * l32);
+                    v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+                }
+            };
             auto ld_dres = [&](int m, float (&v)[12]) {
                 if (!p.dres) return;
                 if (p.dres_period > 0) {                             // compact: only every period-th row carries a gradient
@@ -375,7 +410,8 @@ DEVINL void row_epilogue(const RowParams& p, f32x4 (&acc)[RMT][6], char* smem, i
                 dump(s);
                 if (s == 0) {
                     const int m = clampm(m0 + trow(0));
-                    ld12((const float*)p.aux + (size_t)m * p.ldaux, xnext);
+                    if (use16) ld12h(p.xn16 + (size_t)m * p.ldxn16, xnext);
+                    else ld12u((const float*)p.aux + (size_t)m * p.ldaux, xnext);
                     ld_dres(m, dnext);
                     munext = p.mean[m];
                     rsnext = p.rstd[m];
@@ -389,11 +425,30 @@ DEVINL void row_epilogue(const RowParams& p, f32x4 (&acc)[RMT][6], char* smem, i
                     ld12(slab + srow(it) * SLD, dy);
                     ld12(gls, gm);
                     const float mu = munext, rs = rsnext;
+                    if (use16) {                                     // xhat = (y - beta) / gamma from the bf16 row
+                        float hv[12];
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) { xv[i] = xnext[i]; dr[i] = p.dres ? dnext[i] : 0.f; }
+                        for (int i = 0; i < 6; ++i) {                // bf16 -> f32: the 16 bits moved up
+                            const unsigned u = xnext[i];
+                            hv[2 * i] = __builtin_bit_cast(float, u << 16);
+                            hv[2 * i + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
+                        }
+                        ld12(igls, xv);                              // 1 / gamma, then - beta / gamma: xhat = y / gamma - beta / gamma
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) hv[i] *= xv[i];
+                        ld12(bls, xv);
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) xv[i] = hv[i] + xv[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 12; ++i) xv[i] = (__builtin_bit_cast(float, xnext[i]) - mu) * rs;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) dr[i] = p.dres ? dnext[i] : 0.f;
                     if (it + 1 < NIT) {
                         const int mn = clampm(m0 + trow(it + 1));
-                        ld12((const float*)p.aux + (size_t)mn * p.ldaux, xnext);
+                        if (use16) ld12h(p.xn16 + (size_t)mn * p.ldxn16, xnext);
+                        else ld12u((const float*)p.aux + (size_t)mn * p.ldaux, xnext);
                         ld_dres(mn, dnext);
                         munext = p.mean[mn];
                         rsnext = p.rstd[mn];
@@ -402,7 +457,6 @@ DEVINL void row_epilogue(const RowParams& p, f32x4 (&acc)[RMT][6], char* smem, i
                     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
                     for (int i = 0; i < 12; ++i) {
-                        xv[i] = (xv[i] - mu) * rs;                   // xhat
                         if (live) { ag[i] += dy[i] * xv[i]; ab[i] += dy[i]; }
                         dy[i] *= gm[i];
                         c1 += dy[i];

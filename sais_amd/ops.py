@@ -127,10 +127,13 @@ def gemm_ln_fwd(a, w, bias, resid, x_out, xn_out, gamma, beta, eps, mean=None, r
 
 
 def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dgamma=None, dbeta=None, rowscale16=None,
-                dres_period=0):
+                dres_period=0, xn16=None, beta=None):
     """dy = a[M,K] . w[384,K]^T, then LayerNorm backward at the saved input x / mean / rstd:
     dx = dres + dLN(dy) -> dx32 (f32) and/or dx16 (bf16); dgamma / dbeta accumulated.  dres may alias dx32.
-    dres_period > 0: dres is compact [M / period, 384] — row m gets dres[m / period] when m % period == 0, else nothing."""
+    dres_period > 0: dres is compact [M / period, 384] — row m gets dres[m / period] when m % period == 0, else nothing.
+    xn16 (+ beta): the forward's saved bf16 LayerNorm output; the kernel then rebuilds xhat = (xn16 - beta) / gamma from half the
+    bytes of x (x stays the fallback for degenerate gamma: include/sais_hip.h, SaisGemmLn.xn16)."""
+    _chk(xn16, BF16, "xn16"); _chk(beta, F32, "beta")
     _chk(a, BF16, "A"); _chk(w, BF16, "W"); _chk(x, F32, "x"); _chk(dres, F32, "dres"); _chk(dx32, F32, "dx32")
     _chk(dx16, BF16, "dx16"); _chk(gamma, F32, "gamma")
     M, K = a.shape
@@ -138,8 +141,10 @@ def gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=None, dx32=None, dx16=None, dga
         raise L.SaisHipError(f"gemm_ln_bwd: W must be [384,{K}], got {tuple(w.shape)}")
     g = L.SaisGemmLn(_p(a), a.stride(0), _p(w), w.stride(0), M, K, None, _p(x), _ld(x), _p(dx32), _ld(dx32),
                      _p(dx16), _ld(dx16), _p(gamma), None, 0.0, _p(mean), _p(rstd), _p(dres), _ld(dres),
-                     _p(dgamma), _p(dbeta), None, _p(rowscale16), int(dres_period))
-    nbytes = 2 * (M * K + 384 * K) + M * 384 * (4 + 4 + 4 + 2)
+                     _p(dgamma), _p(dbeta), None, _p(rowscale16), int(dres_period),
+                     _p(xn16) if (xn16 is not None and beta is not None) else None, 0 if xn16 is None else _ld(xn16))
+    g.beta = _p(beta) if beta is not None else None
+    nbytes = 2 * (M * K + 384 * K) + M * 384 * ((2 if (xn16 is not None and beta is not None) else 4) + 4 + 4 + 2)
     _timed(f"gemm_ln_bwd[N384,K{K}]", 2.0 * M * 384 * K, nbytes,
            lambda: L.call("sais_gemm_ln_bwd", ctypes.byref(g), _stream()))
 
@@ -357,6 +362,7 @@ def vit_block_params(f, i, depth):
         setattr(P, "d_" + k + "_w", _p(f.g(p + name + ".weight")))
         setattr(P, "d_" + k + "_b", _p(f.g(p + name + ".bias")))
     P.norm1_g, P.norm2_g, P.norm2_b = _p(f.w32(p + "norm1.weight")), _p(f.w32(p + "norm2.weight")), _p(f.w32(p + "norm2.bias"))
+    P.norm1_b = _p(f.w32(p + "norm1.bias"))
     P.d_norm1_g, P.d_norm1_b = _p(f.g(p + "norm1.weight")), _p(f.g(p + "norm1.bias"))
     P.d_norm2_g, P.d_norm2_b = _p(f.g(p + "norm2.weight")), _p(f.g(p + "norm2.bias"))
     if nxt is not None:

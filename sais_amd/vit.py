@@ -516,7 +516,8 @@ class VisionTransformer(nn.Module):
                 ops.gemm_ln_bwd(dqkv[lo:hi], f.wt16[p + "attn.qkv.weight"], s["x_in"][lo:hi], s["mean1"][lo:hi], s["rstd1"][lo:hi],
                                 f.w32(p + "norm1.weight"), dres=dx_c[fo:fo + Fr], dres_period=ntok, dx32=dx[lo:hi],
                                 dx16=dxa[lo:hi], dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"),
-                                rowscale16=None if rs_prev is None else rs_prev[lo:hi])
+                                rowscale16=None if rs_prev is None else rs_prev[lo:hi],
+                                xn16=s["xn1"][lo:hi], beta=f.w32(p + "norm1.bias"))
         else:                                         # small M: scatter the CLS gradient into a zeroed residual-stream gradient
             dx.zero_()
             for g in groups:
@@ -588,7 +589,7 @@ class VisionTransformer(nn.Module):
                 ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
                 ops.gemm_ln_bwd(du, f.wt16[p + "mlp.fc1.weight"], s["x_mid"], s["mean2"], s["rstd2"],
                                 f.w32(p + "norm2.weight"), dres=dx, dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"),
-                                dbeta=f.g(p + "norm2.bias"), rowscale16=rs_attn)
+                                dbeta=f.g(p + "norm2.bias"), rowscale16=rs_attn, xn16=s["xn2"], beta=f.w32(p + "norm2.bias"))
             else:
                 ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
                 ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
@@ -611,7 +612,7 @@ class VisionTransformer(nn.Module):
             if fused:         # dX of qkv with norm1's backward in its epilogue
                 ops.gemm_ln_bwd(dqkv, f.wt16[p + "attn.qkv.weight"], s["x_in"], s["mean1"], s["rstd1"],
                                 f.w32(p + "norm1.weight"), dres=dx, dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"),
-                                dbeta=f.g(p + "norm1.bias"), rowscale16=rs_prev)
+                                dbeta=f.g(p + "norm1.bias"), rowscale16=rs_prev, xn16=s["xn1"], beta=f.w32(p + "norm1.bias"))
             else:
                 ops.gemm_nt(dqkv, f.wt16[p + "attn.qkv.weight"], L.EPI_BIAS_BF16, dxn)
                 ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,

@@ -667,6 +667,48 @@ def test_gemm_ln_bwd(ops, M, K):
     assert_close(dx_only, xr.grad, atol=2e-4 * scale, rtol=1e-4, name="dx (no dres)")
 
 
+@pytest.mark.parametrize("M,K,case", [(197 * 64, 1536, "plain"), (197 * 146 + 5, 1152, "plain"), (197 * 64, 1536, "outlier"),
+                                      (197 * 64, 1536, "tiny_gamma")])
+def test_gemm_ln_bwd_from_the_saved_bf16_layernorm_output(ops, M, K, case):
+    """ABI 11: with the forward's saved bf16 LayerNorm output y the epilogue rebuilds xhat = (y - beta) / gamma instead of reading the
+    fp32 LayerNorm input (half the bytes).  vs torch autograd on the fp32 input: dx within 1e-3 of max|dy| (xhat enters dx only
+    through xhat * mean(dy g xhat)), dgamma within 2e-3 relative L2 (y's bf16 rounding averages out over the rows; 5e-3 for 'outlier').  'outlier':
+    gamma in [0.2, 3], beta up to +-2 (|beta / gamma| up to 10: the rounding of y is amplified).  'tiny_gamma': one gamma = 1e-5 ->
+    every workgroup must fall back to the fp32 input (exact result, as without y)."""
+    a = rnd(M, K, seed=220, scale=0.5, dtype=torch.bfloat16)
+    w = rnd(384, K, seed=221, scale=0.05, dtype=torch.bfloat16)
+    x = rnd(M, 384, seed=222, scale=1.5)
+    x[:, 11] -= 20.0
+    gamma, beta = 1 + 0.1 * rnd(384, seed=223), 0.05 * rnd(384, seed=224)
+    if case == "outlier":
+        gamma = (0.2 + 2.8 * torch.rand(384, generator=torch.Generator().manual_seed(5))).to(DEV)
+        beta = 2.0 * rnd(384, seed=225).clamp(-1, 1)
+    if case == "tiny_gamma":
+        gamma[77] = 1e-5
+    dres = rnd(M, 384, seed=226)
+    mean = x.mean(1)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+    y16 = F.layer_norm(x, (384,), gamma, beta, 1e-6).to(torch.bfloat16)
+    dgamma, dbeta = torch.zeros(384, device=DEV), torch.zeros(384, device=DEV)
+    dx32 = dres.clone()
+    dx16 = torch.empty(M, 384, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_ln_bwd(a, w, x, mean, rstd, gamma, dres=dx32, dx32=dx32, dx16=dx16, dgamma=dgamma, dbeta=dbeta, xn16=y16, beta=beta)
+    dy = a.float() @ w.float().t()
+    xr, gr = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    F.layer_norm(xr, (384,), gr, br, 1e-6).backward(dy)
+    scale = dy.abs().max().item()
+    exact = case == "tiny_gamma"
+    assert_close(dx32, xr.grad + dres, atol=(2e-4 if exact else 1e-3) * scale * max(1.0, gamma.abs().max().item()), rtol=1e-4, name="dx32")
+    rel = lambda got, ref: float((got - ref).norm() / ref.norm())
+    gbar = 1e-4 if exact else (5e-3 if case == "outlier" else 2e-3)         # |beta / gamma| up to 10 amplifies y's bf16 rounding
+    assert rel(dgamma, gr.grad) <= gbar, rel(dgamma, gr.grad)
+    assert_close(dbeta, br.grad, atol=2e-4 * scale * math.sqrt(M), rtol=1e-4, name="dbeta")
+    from parity import parity_log
+    parity_log(f"ln_bwd from bf16 y[{case}]/dgamma rel-L2", rel(dgamma, gr.grad), gbar)
+    parity_log(f"ln_bwd from bf16 y[{case}]/dx max-abs / max|dy|", float((dx32 - xr.grad - dres).abs().max()) / scale, 1e-3 * max(1.0, gamma.abs().max().item()))
+
+
 def _gelu_parts(u):
     cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
     return u * cdf, cdf + u * torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
