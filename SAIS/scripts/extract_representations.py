@@ -136,9 +136,11 @@ def extract_flows(args, t0):
                 os.remove(mk)
             mine = glob.glob(os.path.join(args.data_path, 'flows', lab, 'flows_*.jpg'))
             if mine and not had_marker and args.raft_random_weights and not args.raft_checkpoint:
-                raise SystemExit('[flow] flows/%s holds %d flows_*.jpg that this script did not write (no %s) and fewer than the %d '
-                                 'the video needs: refusing to overwrite them with maps from seeded RANDOM weights.  Move them away, '
-                                 'complete them, or pass --raft_checkpoint.' % (lab, len(mine), FLOW_MARKER, want[lab]))
+                # a marker-less partial folder: the leftovers of an interrupted run, or files the user put there.  They are
+                # regenerated (an interrupted run must not count as done) — but say so loudly when the replacement is noise
+                print('[flow] WARNING: flows/%s holds %d flows_*.jpg without %s and fewer than the %d the video needs: they are '
+                      'OVERWRITTEN with maps from seeded RANDOM weights (smoke runs only; pass --raft_checkpoint for real flow)'
+                      % (lab, len(mine), FLOW_MARKER, want[lab]), file=sys.stderr)
         bs = max(1, args.batch_size_per_gpu)
         nsaved = 0
         saved = {}                                   # label -> flow numbers written in this run

@@ -375,6 +375,13 @@ int set_lds(K kernel, int bytes) {
     granted[dev] = bytes;
     return SAIS_OK;
 }
+
+// zero-fill as a KERNEL node: the head-averaged map is accumulated with atomics over the four heads.  (Round 6: as a
+// hipMemsetAsync node inside a captured graph the fill was right on the first replay and left garbage in the map on later ones —
+// tools/scratch/win_dbg3.py, the opt-in hipGraph form of run_windows; a kernel node replays like every other launch.)
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* p, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) p[i] = 0.f;
+}
 }  // namespace
 
 extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key_pad, int B, int S, float* ctx,
@@ -387,7 +394,10 @@ extern "C" int sais_temporal_attn_fwd(const float* qkv, const unsigned char* key
     const int lds = 3 * Spad * TLD * 4 + Spad;
     if (set_lds(tattn_fwd_kernel, lds)) return SAIS_ERR_LAUNCH;
     hipStream_t s = (hipStream_t)stream;
-    if (attn_avg && hipMemsetAsync(attn_avg, 0, (size_t)B * S * S * 4, s) != hipSuccess) return SAIS_ERR_LAUNCH;
+    if (attn_avg) {
+        const long n = (long)B * S * S;
+        hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s, attn_avg, n);
+    }
     hipLaunchKernelGGL(tattn_fwd_kernel, dim3(TH, B), dim3(256), lds, s, qkv, key_pad, S, ctx, attn_avg, p_drop, rng_state,
                        site);
     return sais_check_launch();
