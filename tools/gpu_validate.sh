@@ -9,7 +9,7 @@ mkdir -p $O
 cd $R
 # the tree these numbers describe (the box has no .git: the caller passes the commit in SAIS_HEAD)
 echo "${SAIS_HEAD:-unknown}" > $O/HEAD
-python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+if [ -z "$SAIS_VALIDATE_SKIP_TESTS" ]; then python -m pytest tests -m gpu -q --durations=25 > $O/pytest.log 2>&1; tail -3 $O/pytest.log; fi
 cp gpurun_out/parity_worst.json $O/parity_worst.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo
@@ -31,6 +31,12 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAI
           SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
-# keep the merge small: the per-dispatch traces are large, the stats and counter CSVs are what the reports read
-find $O -name "*kernel_trace.csv" -size +20M -delete
+# the counter reports are made HERE (the raw per-dispatch CSVs are too large to travel: gpurun merges <= 64 MiB) and copied next to
+# the stats; profiles/ of the build container receives them from gpurun_out/<tag>/
+cd $R
+python tools/pmc_report.py $O/pmc_sq $O/pmc_fetch $O/pmc_write > $O/pmc_report.log 2>&1; tail -30 $O/pmc_report.log
+cp profiles/pmc_mfma.json profiles/pmc_traffic.json $O/ 2>/dev/null
+find $O -name "*kernel_trace.csv" -delete
+find $O -name "*counter_collection.csv" -delete
+find $O -name "*agent_info.csv" -delete
 du -sh $O
