@@ -9,6 +9,7 @@ mkdir -p $O
 cd $R
 # the tree these numbers describe (the box has no .git: the caller passes the commit in SAIS_HEAD)
 echo "${SAIS_HEAD:-unknown}" > $O/HEAD
+if [ -z "$SAIS_VALIDATE_ONLY_PROFILES" ]; then
 if [ -z "$SAIS_VALIDATE_SKIP_TESTS" ]; then python -m pytest tests -m gpu -q --durations=25 > $O/pytest.log 2>&1; tail -3 $O/pytest.log; fi
 cp gpurun_out/parity_worst.json $O/parity_worst.json 2>/dev/null
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
@@ -22,11 +23,13 @@ SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-n
     bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --sustain-seconds 0 > $O/force_dist_world1.log 2>&1; tail -c 2500 $O/force_dist_world1.log | head -c 300; echo
 SAIS_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 \
     bench.py --workload dino --gpus 1 --steps 10 --warmup 3 > $O/force_dist_world1_dino.log 2>&1; tail -c 1200 $O/force_dist_world1_dino.log | head -c 400; echo
+fi   # SAIS_VALIDATE_ONLY_PROFILES
+# --no-variants below: the config 4 / 5 legs of the default run are child processes and would be profiled into the same files
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --parity-clips 0 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --sustain-seconds 0 --parity-clips 0 --no-variants > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_extract -- python3 $R/bench.py --workload extract --steps 10 --warmup 2 --no-cpu-baseline > $O/stats_extract.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dino -- python3 $R/bench.py --workload dino --steps 10 --warmup 3 --no-cpu-baseline > $O/stats_dino.log 2>&1
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --sustain-seconds 0 --parity-clips 0"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --sustain-seconds 0 --parity-clips 0 --no-variants"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
           SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
