@@ -996,7 +996,7 @@ def main():
                         if not k.startswith(("clip_", "transEncoderClip", "attention", "finalModules", "linear2"))},
                        {k: v.detach().float().cpu() for k, v in protos.items()})
             out["cpu_baseline"] = cpu_baseline(T, C, max(1, min(avail, 32)), weights, Bfull=B)
-        if world == 1 and not two and not args.no_variants and os.environ.get("SAIS_BENCH_BACKEND", "nccl") == "nccl":
+        if world == 1 and not dist_on and not two and not args.no_variants and os.environ.get("SAIS_BENCH_BACKEND", "nccl") == "nccl":
             out["variants"] = run_variants(args)
         # a number from a numerically wrong step is not a result: the line says so and the exit code is non-zero
         bad = (parity is not None and not parity["pass"]) or bool(graph_check and graph_check.get("mismatch"))
