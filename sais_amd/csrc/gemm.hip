@@ -1568,14 +1568,15 @@ __global__ __launch_bounds__(256) void tn_slab_finish_kernel(TnWideGroup gp, con
         const int w8 = e - t * PER_TILE, lane = w8 & 63, ij = (w8 >> 6) % 24, w = (w8 >> 6) / 24;
         const f32x4* src = (const f32x4*)slabs + (size_t)t * PER_TILE + w8;
         f32x4 v[16];
-        f32x4 sum = src[0];
-        for (int z0 = 1; z0 < nsplit; z0 += 16) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int z0 = 0; z0 < nsplit; z0 += 16) {              // unconditional loads (clamped index), values selected afterwards
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (z0 + u < nsplit) v[u] = src[(size_t)(z0 + u) * zstride];
+            for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(z0 + u, nsplit - 1) * zstride];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (z0 + u < nsplit) sum += v[u];
+            for (int u = 0; u < 16; ++u) {
+                const float keep = z0 + u < nsplit ? 1.f : 0.f;
+                sum += v[u] * keep;
+            }
         }
         int it0 = 0;
         while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;

@@ -372,16 +372,18 @@ __global__ __launch_bounds__(256) void xl_finish_kernel(XlGroup gp, const float*
         const int w = e - t * PER_TILE, lane = w & 63, r4 = (w >> 6) & 3, k = (w >> 8) % NT, wid = (w >> 8) / NT;
         const f32x4* src = (const f32x4*)slabs + (size_t)t * PER_TILE + w;
         const size_t zs = (size_t)gp.ntiles * PER_TILE;
-        f32x4 v[16];
-        f32x4 sum = src[0];
-        // splits in a fixed order, up to 16 loads in flight
-        for (int z0 = 1; z0 < ns; z0 += 16) {
+        f32x4 v[12];
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        // splits in a fixed order, 12 loads in flight (10 splits at training size): the loads are UNCONDITIONAL (index clamped, value selected afterwards) — a load
+        // under a run-time condition makes hipcc branch around it and wait for each one (cdna_hip_programming.md, "three .s-level traps" (c))
+        for (int z0 = 0; z0 < ns; z0 += 12) {
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (z0 + u < ns) v[u] = src[(size_t)(z0 + u) * zs];
+            for (int u = 0; u < 12; ++u) v[u] = src[(size_t)min(z0 + u, ns - 1) * zs];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (z0 + u < ns) sum += v[u];
+            for (int u = 0; u < 12; ++u) {
+                const float keep = z0 + u < ns ? 1.f : 0.f;
+                sum += v[u] * keep;
+            }
         }
         int it0 = 0;
         while (it0 + 1 < gp.nitems && t >= gp.tile_end[it0]) ++it0;

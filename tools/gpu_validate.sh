@@ -34,11 +34,16 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAI
           SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
+# vector-L1 / L2 request counters (three more passes): how many bytes a kernel moves through its CUs' L1s (LABNOTES R5.5, R6.1)
+rocprofv3 --pmc TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN1_sum --kernel-trace --output-format csv -d $O/tcp1 -- $B > $O/tcp1.log 2>&1
+rocprofv3 --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum --kernel-trace --output-format csv -d $O/tcp2 -- $B > $O/tcp2.log 2>&1
+rocprofv3 --pmc TCC_EA0_WRREQ_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_BUSY_sum --kernel-trace --output-format csv -d $O/tcp3 -- $B > $O/tcp3.log 2>&1
 # the counter reports are made HERE (the raw per-dispatch CSVs are too large to travel: gpurun merges <= 64 MiB) and copied next to
 # the stats; profiles/ of the build container receives them from gpurun_out/<tag>/
 cd $R
 python tools/pmc_report.py $O/pmc_sq $O/pmc_fetch $O/pmc_write > $O/pmc_report.log 2>&1; tail -30 $O/pmc_report.log
-cp profiles/pmc_mfma.json profiles/pmc_traffic.json $O/ 2>/dev/null
+python tools/pmc_tcp_report.py $O/tcp1 $O/tcp2 $O/tcp3 > $O/pmc_tcp_report.log 2>&1; grep -E "gemm_tn_grouped|gelu_grad|attn_bwd" $O/pmc_tcp_report.log
+cp profiles/pmc_mfma.json profiles/pmc_traffic.json profiles/r06_pmc_tcp.json $O/ 2>/dev/null
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -delete
 find $O -name "*agent_info.csv" -delete

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_pmc_tcp.json: vector-L1 (TCP) and L2 request counters per kernel family of the training step, from rocprofv3 --pmc
+"""profiles/<round>_pmc_tcp.json (name from SAIS_TCP_OUT, default r06_pmc_tcp.json): vector-L1 (TCP) and L2 request counters per kernel family of the training step, from rocprofv3 --pmc
 passes over `bench.py --steps 2 --warmup 1 --no-graph` (tools/scratch/gpu_r5m.sh).  usage: pmc_tcp_report.py <dir> [<dir> ...]"""
 import collections
 import csv
@@ -31,10 +31,10 @@ for n, c in sorted(agg.items()):
               "l2_write_requests": int(wr), "l2_write_latency_cycles": round(g.get("TCP_TCC_WRITE_REQ_LATENCY_sum", 0.0) / wr, 1) if wr else None,
               "tcc_ea_wrreq_stall": int(g.get("TCC_EA0_WRREQ_STALL_sum", 0.0)), "tcc_busy_sum": int(g.get("TCC_BUSY_sum", 0.0))}
 json.dump({"collected_with": "rocprofv3 --pmc (three passes: TCP stalls, TCP<->TCC requests and latencies, TCC) -- python3 bench.py --steps 2 "
-                             "--warmup 1 --no-graph --no-cpu-baseline --sustain-seconds 0 --parity-clips 0",
+                             "--warmup 1 --no-graph --no-cpu-baseline --sustain-seconds 0 --parity-clips 0 --no-variants",
            "head": open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "HEAD")).read().strip()
            if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), "HEAD")) else "unknown",
-           "kernels": out}, open(os.path.join(ROOT, "profiles", "r05_pmc_tcp.json"), "w"), indent=1)
+           "kernels": out}, open(os.path.join(ROOT, "profiles", os.environ.get("SAIS_TCP_OUT", "r06_pmc_tcp.json")), "w"), indent=1)
 for n, v in out.items():
     print(f"{n:28s} pend {v['tcp_pending_stall_frac_of_gated']}  ta_stall {v['tcp_ta_data_stall_frac_of_gated']}  rd {v['l2_read_requests']:>9d} @ {v['l2_read_latency_cycles']}  "
           f"wr {v['l2_write_requests']:>9d} @ {v['l2_write_latency_cycles']}  ea_wr_stall {v['tcc_ea_wrreq_stall']}")
