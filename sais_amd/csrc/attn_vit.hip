@@ -215,6 +215,12 @@ __device__ unsigned long long g_attn_stamps[16][40];
 #ifndef SAIS_ATTN_ABL
 #define SAIS_ATTN_ABL 0
 #endif
+#ifndef SAIS_ATTN_NB_ABL
+#define SAIS_ATTN_NB_ABL 0          // timing ablations of the barrier-free backward (WRONG results): 1 no job K, 2 no job Q
+#endif
+#ifndef SAIS_ATTN_BWD_NB_DEFAULT
+#define SAIS_ATTN_BWD_NB_DEFAULT false
+#endif
 template <class G>
 __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
                                                         const bf16* out, long ldout, const float* lse, int nprob,
@@ -375,6 +381,184 @@ __global__ __launch_bounds__(G::BWD_THREADS) void attn_bwd_kernel(const bf16* qk
     }
 }
 
+#ifndef SAIS_EXPERIMENTAL
+#define SAIS_EXPERIMENTAL 0
+#endif
+#if SAIS_EXPERIMENTAL
+// ------------------------------------------------------------------------------------------ backward without the barrier chain (round 6)
+// EXPERIMENT RECORD (built only with -DSAIS_EXPERIMENTAL=1; SAIS_ATTN_BWD_NB=1 selects it): correct at the first run and 5-7 % SLOWER than
+// the single-pass kernel (138-140 vs 131-132 us stand-alone; ablations: staging 30 us, job K 59 us, job Q 52 us — LABNOTES R6.5).
+// The single-pass kernel above pays one workgroup barrier per 32-query step: the key-tile waves hand dS to the dQ waves through
+// LDS, every phase of a step waits for the slowest wave, and MFMA busy is 0.17 (LABNOTES 4.3, R5.7).  Here NO value crosses waves:
+// one wave per 16-row tile does two independent jobs with every operand image (Q, dO, K, V: 4 x 35 KB) staged once —
+//   job K (its KEY tile):   S = Q K^T and dP = dO V^T with the key on the lane (K / V fragments in registers), P from the saved
+//                           log-sum-exp, dV^T += dO^T P, dK^T += Q^T dS over the seven 32-query steps: the loop above minus the dS
+//                           store;
+//   job Q (its QUERY tile): S^T = K Q^T and dP^T = V dO^T with the query on the lane (Q / dO fragments in registers: the forward
+//                           kernel's orientation), P^T and dS^T in registers = the B operand of dQ^T += K^T dS^T over the seven
+//                           32-key steps.
+// S, dP and the exponential are computed twice (7 product groups instead of 5, 2 x the VALU work) — on pipes that idled — and
+// the only barriers are the two around the staging of a problem.  13 waves (832 threads) for 197 tokens, one workgroup per CU.
+template <class G> struct NbTag {};
+template <class G> constexpr int bwd_nb_lds() { return 4 * G::MAT_BYTES + 2 * G::TILE_ROWS * 4; }
+
+template <class G>
+__global__ __launch_bounds__(G::NKT * 64) void attn_bwd_nb_kernel(const bf16* qkv, long ldq, const bf16* dout, long ldo,
+                                                                  const bf16* out, long ldout, const float* lse, int nprob,
+                                                                  bf16* dqkv, long lddq, float scale) {
+    constexpr int NTOK = G::NTOK, NKT = G::NKT, NKS = G::NKS, TILE_ROWS = G::TILE_ROWS, MAT_BYTES = G::MAT_BYTES;
+    constexpr int NTHREADS = NKT * 64, RPP = NTHREADS / 8, NPASS = (TILE_ROWS + RPP - 1) / RPP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CLK_STAMP(11);
+    char* const sQ = smem;
+    char* const sO = smem + MAT_BYTES;                     // dO
+    char* const sK = smem + 2 * MAT_BYTES;
+    char* const sV = smem + 3 * MAT_BYTES;
+    float* const sL = (float*)(smem + 4 * MAT_BYTES);      // lse * log2e   [TILE_ROWS]
+    float* const sD = sL + TILE_ROWS;                      // delta         [TILE_ROWS]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, li = lane & 15;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float c = scale * LOG2E;
+    const int row16 = wid * 16 + li;                       // this lane's key (job K) and query (job Q)
+    for (int prob = blockIdx.x; prob < nprob; prob += gridDim.x) {
+        const int f = prob / NH, h = prob - f * NH;
+        const bf16* base = qkv + (size_t)f * NTOK * ldq + h * HD;
+        const bf16* dob = dout + (size_t)f * NTOK * ldo + h * HD;
+        const bf16* ob = out + (size_t)f * NTOK * ldout + h * HD;
+        {
+            // every global load of the problem is issued before the first use (clamped addresses, no branches)
+            const int cch = tid & 7, r0 = tid >> 3;
+            u32x4 vq[NPASS], vk[NPASS], vv[NPASS], vd[NPASS], vo[NPASS];
+            float lv[NPASS];
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int r = r0 + RPP * i, rc = r < NTOK ? r : NTOK - 1;
+                vq[i] = *(const u32x4*)(base + (size_t)rc * ldq + cch * 8);
+                vk[i] = *(const u32x4*)(base + DM + (size_t)rc * ldq + cch * 8);
+                vv[i] = *(const u32x4*)(base + 2 * DM + (size_t)rc * ldq + cch * 8);
+                vd[i] = *(const u32x4*)(dob + (size_t)rc * ldo + cch * 8);
+                vo[i] = *(const u32x4*)(ob + (size_t)rc * ldout + cch * 8);
+                lv[i] = lse[((size_t)f * NH + h) * NTOK + rc];
+            }
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int r = r0 + RPP * i;
+                if (r < TILE_ROWS) {
+                    const bool ok = r < NTOK;
+                    const u32x4 z = {0, 0, 0, 0};
+                    *(u32x4*)(sQ + r * ROWB + cch * 16) = ok ? vq[i] : z;
+                    *(u32x4*)(sK + r * ROWB + cch * 16) = ok ? vk[i] : z;
+                    *(u32x4*)(sV + r * ROWB + cch * 16) = ok ? vv[i] : z;
+                    *(u32x4*)(sO + r * ROWB + cch * 16) = ok ? vd[i] : z;
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, vd[i]), b = __builtin_bit_cast(bf16x8, vo[i]);
+                    float dl = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dl = __builtin_fmaf((float)a[e], (float)b[e], dl);
+                    dl += __shfl_xor(dl, 1); dl += __shfl_xor(dl, 2); dl += __shfl_xor(dl, 4);
+                    if (cch == 0) {
+                        sD[r] = ok ? dl : 0.f;
+                        sL[r] = ok ? lv[i] * LOG2E : INFINITY;               // exp2(-inf) = 0: pad queries
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- job K: this wave's key tile over the query steps (its K / V row fragments come from the staged images)
+        if (!(SAIS_ATTN_NB_ABL & 1)) {
+            bf16x8 fk[2], fv[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { fk[ks] = row_frag(sK, row16, 4 * ks + g); fv[ks] = row_frag(sV, row16, 4 * ks + g); }
+            f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0, 0, 0, 0}; dv[dt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll 1
+            for (int qs = 0; qs < NKS; ++qs) {
+                f32x4 p[2], ds[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qrow = 32 * qs + 16 * u;      // lane holds q = qrow + 4 g + r, key = row16
+                    f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        a = mfma16(row_frag(sQ, qrow + li, 4 * ks + g), fk[ks], a);     // S[q][key]
+                        b = mfma16(row_frag(sO, qrow + li, 4 * ks + g), fv[ks], b);     // dP[q][key]
+                    }
+                    const f32x4 l4 = *(const f32x4*)(sL + qrow + 4 * g);
+                    const f32x4 d4 = *(const f32x4*)(sD + qrow + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = fast_exp2(__builtin_fmaf(a[r], c, -l4[r]));
+                        p[u][r] = pv;
+                        ds[u][r] = pv * (b[r] - d4[r]);                 // x scale at the dK store
+                    }
+                }
+                const bf16x8 pf = pack_p(p[0], p[1]), dsf = pack_p(ds[0], ds[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    dv[dt] = mfma16(tr_frag(sO, qs, dt, g, li), pf, dv[dt]);            // dV^T[d][key]
+                    dk[dt] = mfma16(tr_frag(sQ, qs, dt, g, li), dsf, dk[dt]);           // dK^T[d][key]
+                }
+            }
+            if (row16 < NTOK) {
+                bf16* krow = dqkv + ((size_t)f * NTOK + row16) * lddq + DM + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    bf16x4 a, b;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = (bf16)(dk[dt][r] * scale); b[r] = (bf16)dv[dt][r]; }
+                    *(bf16x4*)(krow + 16 * dt) = a;
+                    *(bf16x4*)(krow + DM + 16 * dt) = b;
+                }
+            }
+        }
+        // ---- job Q: this wave's query tile over the key steps (query on the lane: lse / delta are per-lane scalars)
+        if (!(SAIS_ATTN_NB_ABL & 2)) {
+            bf16x8 fq[2], fdo[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { fq[ks] = row_frag(sQ, row16, 4 * ks + g); fdo[ks] = row_frag(sO, row16, 4 * ks + g); }
+            f32x4 dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0, 0, 0, 0};
+            const float lq = sL[row16], dlt = sD[row16];
+#pragma unroll 1
+            for (int ks2 = 0; ks2 < NKS; ++ks2) {
+                f32x4 dst[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int krow = 32 * ks2 + 16 * t;     // lane holds key = krow + 4 g + r, q = row16; rows past NKT * 16 are zero
+                    f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        a = mfma16(row_frag(sK, krow + li, 4 * ks + g), fq[ks], a);     // S^T[key][q]
+                        b = mfma16(row_frag(sV, krow + li, 4 * ks + g), fdo[ks], b);    // dP^T[key][q]
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = fast_exp2(__builtin_fmaf(a[r], c, -lq));
+                        dst[t][r] = (krow + 4 * g + r < NTOK) ? pv * (b[r] - dlt) : 0.f;        // pad keys must not reach dQ
+                    }
+                }
+                const bf16x8 dsf = pack_p(dst[0], dst[1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tr_frag(sK, ks2, dt, g, li), dsf, dq[dt]);   // dQ^T[d][q]
+            }
+            if (row16 < NTOK) {                             // lane: query row16, d = 16 dt + 4 g + r
+                bf16* qrow = dqkv + ((size_t)f * NTOK + row16) * lddq + h * HD + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (bf16)(dq[dt][r] * scale);
+                    *(bf16x4*)(qrow + 16 * dt) = v;
+                }
+            }
+        }
+        __syncthreads();                                    // every read of this problem's images is done
+    }
+}
+
+#endif  // SAIS_EXPERIMENTAL
+
 template <class G> constexpr int fwd_lds() { return 2 * G::MAT_BYTES; }
 
 // raise the dynamic-LDS limit of a kernel once per process and device (not per call: keeps the launch
@@ -403,6 +587,19 @@ template <class G>
 int launch_bwd(const void* qkv, long ldqkv, const void* dout, long lddo, const void* out, long ldout, const float* lse,
                int frames, void* dqkv, long lddqkv, void* stream) {
     const int nprob = frames * NH;
+#if SAIS_EXPERIMENTAL
+    // SAIS_ATTN_BWD_NB (read once): 1 = the barrier-free form (197 tokens only), 0 = the single-pass kernel with the dS hand-off
+    static const bool nb = [] { const char* e = getenv("SAIS_ATTN_BWD_NB"); return e ? atoi(e) != 0 : SAIS_ATTN_BWD_NB_DEFAULT; }();
+    if constexpr (G::NKT > 4) {
+        if (nb) {
+            if (set_lds<NbTag<G>>(attn_bwd_nb_kernel<G>, bwd_nb_lds<G>())) return SAIS_ERR_LAUNCH;
+            hipLaunchKernelGGL(attn_bwd_nb_kernel<G>, dim3(nprob < 256 ? nprob : 256), dim3(G::NKT * 64), bwd_nb_lds<G>(),
+                               (hipStream_t)stream, (const bf16*)qkv, ldqkv, (const bf16*)dout, lddo, (const bf16*)out, ldout, lse,
+                               nprob, (bf16*)dqkv, lddqkv, 0.125f);
+            return sais_check_launch();
+        }
+    }
+#endif
     if (set_lds<G>(attn_bwd_kernel<G>, bwd_lds<G>())) return SAIS_ERR_LAUNCH;
     // short sequences leave most of the LDS free: several workgroups per CU
     int per_cu = 160 * 1024 / bwd_lds<G>();                       // resident workgroups per CU (LDS-limited)

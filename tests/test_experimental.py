@@ -18,6 +18,7 @@ EXP_LIB = os.path.join(ROOT, "tools", "bin", "exp", "libsais_hip.so")
     ("SAIS_NT_W4", "1", "gemm_nt_epilogues or gemm_nt_exact"),                  # four workgroups per CU, BK = 32 (R5.1)
     ("SAIS_NT_W16", "1", "gemm_nt_epilogues or gemm_nt_exact or gemm_patch"),   # two groups in anti-phase (R5.2)
     ("SAIS_NT_W8R", "1", "gemm_nt_epilogues or gemm_nt_exact"),                 # W in registers (R5.6)
+    ("SAIS_ATTN_BWD_NB", "1", "vit_attention"),                                 # attention backward without the barrier chain (R6.5)
     ("SAIS_TN_XL", "8", "gemm_tn"),                                             # 192 x 384 dW tile with eight waves (R6.1)
     ("SAIS_TN_NI", "2", "gemm_tn")])                                            # 128 x 384 dW, two barrier intervals per step (R5.4)
 def test_rejected_kernel_forms_pass_the_same_tests(switch, value, select):
