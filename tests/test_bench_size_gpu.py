@@ -375,10 +375,13 @@ def test_config2_graph_replay_equals_eager_step(gpu):
     opt = SGD(list(vit.parameters()) + list(m.parameters()) + list(protos.values()), lr=0.1, engines=[vit, m])
     names, lens = [f"v{b}" for b in range(B)], [T] * B
 
+    maps = []
+
     def step():
         opt.zero_grad()
         reps = vit(frames).view(B, 1, T, 384)
-        emb, _ = m(reps, None, lens, None, 'Prototypes', pad, None, None)
+        emb, attn = m(reps, None, lens, None, 'Prototypes', pad, None, None)
+        maps[:] = [attn]                                      # under capture: the graph's static output
         loss = calcNCELoss(0, emb, cols, names, protos, None)
         loss.backward()
         opt.step()
@@ -398,6 +401,15 @@ def test_config2_graph_replay_equals_eager_step(gpu):
         m.flat.refresh_shadows(m._t_names())
 
     graphed = GraphedStep(step, warmup=2)                     # warm-up + capture run steps: weights move
+    attn_static = maps[0]
+    # the returned attention map must survive REPLAYS: its zero-fill was a captured hipMemsetAsync until round 6, right on the first
+    # replay and garbage from the second on (LABNOTES R6.4); rows sum to one (dropout is off in this test's model)
+    for _ in range(3):
+        restore()
+        graphed()
+    torch.cuda.synchronize()
+    rows = attn_static.detach().float().sum(-1)
+    assert torch.isfinite(attn_static).all() and float((rows - 1).abs().max()) <= 1e-4, float((rows - 1).abs().max())
     restore()
     lg = float(graphed())
     torch.cuda.synchronize()
