@@ -203,6 +203,11 @@ def main():
     ap.add_argument('--local_rank', '--local-rank', default=0, type=int)
     ap.add_argument('--video', default=None, type=str, help='video label (folder under images/ or flows/)')
     ap.add_argument('--synthetic_frames', default=0, type=int, help='use N seeded synthetic frames instead of JPEGs')
+    ap.add_argument('--tail_batch', default='fit', type=str,
+                    help="shape of the last, partial batch of a video: 'fit' (default) = its own size (rounded up to an even "
+                         "number of frames; fastest), N = padded to a fixed second shape of N frames, 0 = padded to "
+                         "--batch_size_per_gpu.  With 0 / N every frame runs the same kernels whatever the number of ranks, so the "
+                         "feature files are bit-identical across world sizes; with 'fit' they agree to bf16 rounding")
     ap.add_argument('--checkpoint', default=None, type=str, help='dino_deitsmall16_pretrain.pth (default: dino-main/outputs/)')
     ap.add_argument('--raft_checkpoint', default=None, type=str,
                     help='--optical_flow: a RAFT state dict with the published key names (e.g. raft-things.pth); default: '
@@ -233,7 +238,8 @@ def main():
     flow = args.optical_flow_to_reps
     sub = 'flows' if flow else 'images'
     videos = [args.video] if args.video else sorted(os.listdir(os.path.join(args.data_path, sub)))
-    fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 256), use_graph=True, tail_batch=64)
+    fx = FeatureExtractor(vit, batch_size=min(args.batch_size_per_gpu, 256), use_graph=True,
+                          tail_batch='fit' if args.tail_batch == 'fit' else (int(args.tail_batch) or None))
     reps = {}
     for v in videos:
         err = None

@@ -71,9 +71,10 @@ def parse_args():
     ap.add_argument("--extract-batch", type=int, default=256,
                     help="--workload extract: frames per hipGraph replay (main.sh asks for 1024, the CLI caps it at 256 = "
                          "50 432 token rows, where the GEMM kernels are at their best)")
-    ap.add_argument("--extract-tail", type=int, default=64,
+    ap.add_argument("--extract-tail", type=int, default=-1,
                     help="--workload extract: frames of the second captured shape that takes the remainder of a video and "
-                         "short inputs (the 34 flow maps); 0 = pad the remainder to --extract-batch")
+                         "short inputs (the 34 flow maps); 0 = pad the remainder to --extract-batch; -1 (default) = one captured "
+                         "shape per distinct remainder, rounded up to an even number of frames")
     ap.add_argument("--window-batch", type=int, default=2, help="--workload extract: windows per batch (main.sh: -bs 2)")
     ap.add_argument("--grad-payload", choices=("fp32", "bf16"), default="fp32",
                     help="N > 1: what the gradient all-reduce carries (bf16 = half the xGMI bytes, sums rounded to bf16)")
@@ -448,7 +449,8 @@ def extract_main(args):
     model = fullModel('reps', 2, 'in_vs_out', 384, 'ViT', modalities='RGB-Flow').to(dev).eval()
     frames = synth.clips(seed=5 + rank, B=1, T=N)[0].to(dev)                     # resident in HBM
     flow_frames = synth.clips(seed=1000 + rank, B=1, T=max(1, N // 15))[0].to(dev)
-    fx = FeatureExtractor(vit, batch_size=bs, use_graph=not args.no_graph, tail_batch=args.extract_tail or None)
+    tail = "fit" if args.extract_tail < 0 else (args.extract_tail or None)
+    fx = FeatureExtractor(vit, batch_size=bs, use_graph=not args.no_graph, tail_batch=tail)
     nwin = len(gesture_windows(N))
 
     def step():
@@ -523,7 +525,7 @@ def extract_main(args):
                        "the fp32 CPU oracle, same weights; logits = cosines against seeded prototypes")
     parity["pass"] = bool(dl <= 1e-3 and da <= 2e-3 and feat_rel <= 2e-2)
     # instrumented pass: HIP events around every MFMA kernel of one eager video (the replayed graph holds the same launches)
-    fe = FeatureExtractor(vit, batch_size=bs, use_graph=False, tail_batch=args.extract_tail or None)
+    fe = FeatureExtractor(vit, batch_size=bs, use_graph=False, tail_batch=tail)
     fe(frames); fe(flow_frames)                              # untimed eager pass first: a first eager launch of a shape can carry
     torch.cuda.synchronize()                                 # one-off host work (seen once as a 3-ms "attention" launch)
     ops.TIMER = ops.KernelTimer()
@@ -541,7 +543,8 @@ def extract_main(args):
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"BASELINE config 5: {N}-frame synthetic video per GPU, frozen ViT-S/16 forward in hipGraph-replayed "
-                               f"batches of {bs} (remainders and the {nvit - N} flow maps in batches of {args.extract_tail or bs}), "
+                               f"batches of {bs} (remainders and the {nvit - N} flow maps in "
+                               f"{'a batch of their own size' if tail == 'fit' else 'batches of %d' % (tail or bs)}), "
                                f"{nwin} sliding windows x 3 TTA versions through the "
                                f"two-stream 4-layer temporal encoder (window batch {args.window_batch}, main.sh's -bs), embeddings "
                                f"+ attention maps [{nwin},16,16] exported to the host; random-init weights",

@@ -134,17 +134,33 @@ class FeatureExtractor:
     """extractFeatures (:351-378) with the fixed-shape ViT forward captured once into a hipGraph and replayed per
     batch (the launch-bound part of inference: ~90 kernel launches per batch collapse into one graph launch)."""
 
-    def __init__(self, vit, batch_size=32, use_graph=True, tail_batch=None):
-        """batch_size frames per replay; tail_batch (optional, < batch_size): a second, smaller captured shape for what is
-        left at the end of a video (and for short inputs such as the flow maps: 34 of them for a 512-frame video), so that a
-        large main batch — the GEMM kernels are most efficient from ~50 k token rows = 256 frames on — does not turn the
-        remainder into a mostly-padding replay."""
+    MAX_GRAPHS = 16                                                   # captured shapes kept per extractor (least recently used out)
+
+    def __init__(self, vit, batch_size=32, use_graph=True, tail_batch=None, tail_round=2):
+        """batch_size frames per replay; tail_batch: the shape used for what is left at the end of a video (and for short
+        inputs such as the flow maps: 34 of them for a 512-frame video), so that a large main batch — the GEMM kernels are most
+        efficient from ~50 k token rows = 256 frames on — does not turn the remainder into a mostly-padding replay.
+          None    the remainder is padded to batch_size (one captured shape);
+          int     a second, fixed captured shape (< batch_size); what is left is padded to it;
+          "fit"   the remainder itself, rounded up to a multiple of tail_round: one captured shape per distinct remainder (at
+                  most MAX_GRAPHS kept).  34 flow maps then cost 34 frames of work instead of 64: 47.5 k -> 50.3 k frames/s on
+                  the 512-frame video (LABNOTES R6.6)."""
         self.vit = vit.eval()
         self.bs = batch_size
-        self.tail = tail_batch if tail_batch and tail_batch < batch_size else None
+        self.fit = tail_batch == "fit"
+        self.tail_round = max(1, int(tail_round))
+        self.tail = tail_batch if (not self.fit and tail_batch and tail_batch < batch_size) else None
         self.use_graph = use_graph
         self._graphs = {}                                             # frames per replay -> (graph, static_in, static_out)
         self._sig = None
+
+    def shape_for(self, left):
+        """Frames per forward pass for `left` remaining frames: the padded shape, the same for replayed and eager passes."""
+        if left >= self.bs:
+            return self.bs
+        if self.fit:
+            return min(self.bs, -(-left // self.tail_round) * self.tail_round)
+        return self.bs if self.tail is None else self.tail
 
     def _capture(self, device, bs):
         static_in = torch.zeros(bs, 3, 224, 224, device=device)
@@ -158,6 +174,9 @@ class FeatureExtractor:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_out = self.vit(static_in)
+        while len(self._graphs) >= self.MAX_GRAPHS:                   # dicts keep insertion order: the first key is the oldest use
+            old = next(k for k in self._graphs if k != self.bs)
+            del self._graphs[old]
         self._graphs[bs] = (graph, static_in, static_out)
         self._sig = self._weights_sig(device)
 
@@ -182,14 +201,14 @@ class FeatureExtractor:
         i = 0
         while i < N:
             left = N - i
-            bs = self.bs if (left >= self.bs or self.tail is None) else self.tail
+            bs = self.shape_for(left)
             n = min(bs, left)
             if self.use_graph:
                 if self._graphs and self._weights_sig(frames.device) != self._sig:
                     self._graphs.clear()                              # the weights changed since the capture: never replay those
                 if bs not in self._graphs:
                     self._capture(frames.device, bs)
-                graph, static_in, static_out = self._graphs[bs]
+                graph, static_in, static_out = self._graphs[bs] = self._graphs.pop(bs)      # re-insert: most recently used last
                 static_in[:n].copy_(frames[i:i + n])
                 if n < bs:
                     static_in[n:].zero_()

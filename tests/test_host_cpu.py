@@ -483,3 +483,19 @@ def test_counter_files_go_stale_when_a_kernel_source_changes(tmp_path):
     json.dump({"gemm_tn_grouped": {"hbm_bytes_per_launch": 1}, "_provenance": {"head": "205f2ce"}},       # pre-round-6 file: no hash
               open(tmp_path / "profiles" / "pmc_traffic.json", "w"))
     assert bench.load_pmc("pmc_traffic.json", str(tmp_path))[1] is True
+
+
+def test_feature_extractor_shapes_per_remainder():
+    """FeatureExtractor.shape_for: the padded shape of a forward pass for `left` remaining frames under the three tail policies
+    (no GPU: only the host arithmetic; the replay / eager bit-identity is tests/test_inference_gpu.py)."""
+    from sais_amd.inference import FeatureExtractor
+
+    class _V(torch.nn.Module):
+        pass
+    one = FeatureExtractor(_V(), batch_size=256)
+    fixed = FeatureExtractor(_V(), batch_size=256, tail_batch=64)
+    fit = FeatureExtractor(_V(), batch_size=256, tail_batch="fit")
+    fit8 = FeatureExtractor(_V(), batch_size=256, tail_batch="fit", tail_round=8)
+    for left, want in ((300, (256, 256, 256, 256)), (256, (256, 256, 256, 256)), (255, (256, 64, 256, 256)),
+                       (100, (256, 64, 100, 104)), (34, (256, 64, 34, 40)), (33, (256, 64, 34, 40)), (1, (256, 64, 2, 8))):
+        assert (one.shape_for(left), fixed.shape_for(left), fit.shape_for(left), fit8.shape_for(left)) == want, left

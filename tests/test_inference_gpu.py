@@ -95,6 +95,15 @@ def test_tail_graph_and_batched_windows_equal_the_small_batch_forms(gpu):
     assert a.shape == (150, 384) and float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
     e = FeatureExtractor(vit, batch_size=128, use_graph=False, tail_batch=64)(frames)
     assert torch.equal(a, e), "graph replay of both captured shapes must reproduce the eager kernels bit for bit"
+    # tail_batch="fit": the remainder gets a captured shape of its own size (150 = 128 + 22; the 9 "flow maps" another one)
+    fit = FeatureExtractor(vit, batch_size=128, use_graph=True, tail_batch="fit")
+    f = fit(frames)
+    assert sorted(fit._graphs) == [22, 128] and float((f - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    assert torch.equal(f, FeatureExtractor(vit, batch_size=128, use_graph=False, tail_batch="fit")(frames))
+    f9 = fit(frames[:9])                                                                     # 9 -> a shape of 10, one padded row
+    assert sorted(fit._graphs) == [10, 22, 128] and torch.equal(f9, FeatureExtractor(vit, batch_size=128, use_graph=False,
+                                                                                      tail_batch="fit")(frames[:9]))
+    assert float((f9 - b[:9]).abs().max()) <= 2e-2 * float(b.abs().max())
     reps = synth.reps(seed=3, B=1, T=200)[0, 0].to(DEV)
     flow = synth.reps(seed=4, B=1, T=13)[0, 0].to(DEV)
     big, attn_big, _ = run_windows(m, reps, flow, videoname="v", batch_size=2)                 # 13 windows in one call
@@ -290,7 +299,8 @@ def test_cli_inference_sharded_over_two_ranks_equals_single_process(gpu, tmp_pat
                         "100"], check=True, env=env, cwd=ROOT)
         ex = launch + [sc("extract_representations.py"), "--arch", "vit_small", "--patch_size", "16", "--model_type",
                        "ViT_SelfSupervised_ImageNet", "--batch_size_per_gpu", "64", "--data_path", str(root) + "/",
-                       "--data_list", "Custom", "--save_type", "h5", "--video", "vid_01", "--synthetic_frames", "100"]
+                       "--data_list", "Custom", "--save_type", "h5", "--video", "vid_01", "--synthetic_frames", "100",
+                       "--tail_batch", "0"]                       # one padded shape: same kernels whatever the shard sizes
         subprocess.run(ex, check=True, env=env, cwd=ROOT)
         subprocess.run(ex + ["--optical_flow_to_reps"], check=True, env=env, cwd=ROOT)
         run = launch + [sc("run_experiments.py"), "-p", str(root) + "/", "-data", "Custom_Gestures", "-d", "Custom", "-m",
