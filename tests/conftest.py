@@ -10,6 +10,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 
 def pytest_configure(config):
+    # The CPU oracle (fp32 torch) is the slow half of the parity tests at benchmark sizes.  Its GEMMs stop scaling past a few dozen
+    # threads and get much slower when torch takes every core of a large host (bench.py's cpu_baseline leg caps them the same way).
+    import torch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(32, avail)))
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(32, avail))))     # the CLI tests' child processes inherit it
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "experimental: rejected kernel forms, built only with -DSAIS_EXPERIMENTAL=1 (not part of -m gpu)")
 
