@@ -568,6 +568,38 @@ def test_gemm_tn_grouped_large_tile_exact_integers_and_bitwise_repeatable(ops):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,shapes", [
+    (8192, [(384, 1536), (1536, 384), (384, 384), (1152, 384)]),            # smallest M of the regime: 256 steps, 10 splits of 25-26: falls back
+    (197 * 128, [(384, 1536), (1536, 384), (384, 384), (1152, 384)]),       # 788 steps: 10 splits of 78-79
+    (197 * 512, [(384, 1536), (1536, 384)]),                                # config 4's M = 100 864: 16 tiles x 16 splits of 197
+    (197 * 256, [(768, 384)]),                                              # the pruned block's k/v-only launch: 4 tiles, 64 splits < 48 steps: falls back
+    (197 * 256, [(384, 384), (384, 768), (768, 1152)]),                     # uneven tile counts per item: 2 + 4 + 12 = 18 tiles x 14 splits
+])
+def test_gemm_tn_grouped_large_tile_strided_views_and_accumulation(ops, M, shapes):
+    """The large-tile dW kernel over what its callers hand it: P / Q as column slices of wider buffers (leading dimension > N, base
+    pointer 16-B but not 128-B aligned), dW as a slice of a wider gradient buffer, a SECOND call that must add to the first (+=), db
+    present or not per item — and the launches at the edges of its regime, which must fall back to the 128 x 384 kernel and give the
+    same numbers.  Small-integer operands: every sum is exact in fp32 in any order, so the results must EQUAL the reference."""
+    g = torch.Generator().manual_seed(M % 1000 + len(shapes))
+    items, refs = [], []
+    for i, (n1, n2) in enumerate(shapes):
+        pw = torch.randint(-2, 3, (M, n1 + 24), generator=g).to(torch.bfloat16).to(DEV)
+        qw = torch.randint(-3, 4, (M, n2 + 40), generator=g).to(torch.bfloat16).to(DEV)
+        p, q = pw[:, 8:8 + n1], qw[:, 16:16 + n2]
+        wide = torch.randint(-5, 6, (n1, n2 + 8), generator=g).float().to(DEV)
+        dW = wide[:, 4:4 + n2]
+        db = torch.randint(-5, 6, (n1,), generator=g).float().to(DEV) if i % 2 == 0 else None
+        refs.append((dW.clone() + 2 * (p.float().t() @ q.float()), None if db is None else db + 2 * p.float().sum(0), wide.clone()))
+        items.append((p, q, dW, db))
+    ops.gemm_tn_grouped(items, M)
+    ops.gemm_tn_grouped(items, M)
+    for (p, q, dW, db), (rw, rb, wide0) in zip(items, refs):
+        assert torch.equal(dW, rw)
+        assert db is None or torch.equal(db, rb)
+        wide = dW._base if dW._base is not None else dW
+        assert torch.equal(wide[:, :4], wide0[:, :4]) and torch.equal(wide[:, -4:], wide0[:, -4:]), "columns beside the dW slice were written"
+
+
 _SLAB_SCRIPT = r"""
 import math, sys, torch
 sys.path.insert(0, sys.argv[1])
