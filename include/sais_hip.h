@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 11
+#define SAIS_ABI_VERSION 12
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -46,6 +46,11 @@ enum {
     SAIS_EPI_MUL_BF16 = 11,       /* ... the backward is out bf16 = acc * aux(bf16), with no erf/exp in its epilogue */
     SAIS_EPI_PATCH_F32 = 7,       /* patch-embed: row f*grp_in+q -> token row f*grp_out+q+grp_off,
                                      out f32 = acc + bias + aux(f32 pos)[q+grp_off]                  */
+    SAIS_EPI_BIAS_GELU_GRADQ_BF16 = 13, /* (ABI 12) as 10, but out2 holds gelu'(acc + bias) as ONE BYTE per element: code q =
+                                     clamp(rint(26 + 203 d), 0, 255), i.e. d = (q - 26) / 203 — 0 and 1 are exact, the range
+                                     [-0.128, 1.128] covers gelu' (min -0.129, max 1.129), step 0.0049 (rms error 0.0014; a bf16
+                                     near 0.5 has 0.0011): half the bytes of the tensor the backward reads again; ldo2 in bytes */
+    SAIS_EPI_MULQ_BF16 = 14,      /* (ABI 12) out bf16 = acc * (aux(u8) - 26) / 203: the backward of 13; ldaux in bytes        */
     SAIS_EPI_RAW_SLABS_F32 = 12   /* (ABI 8, M < 8192 only) split-K: K is cut into grp_in slices, slice z writes its raw partial
                                      sums to out f32 [grp_in][M][ldo]; sais_splitk_finish sums them in a fixed order      */
 };
@@ -244,6 +249,9 @@ int sais_mlp_bwd(const SaisMlp* a, void* stream);
  * block's norm1(x_out) (xn_next; next_norm_g == NULL for the last block).                                               */
 enum SaisOp { SAIS_OP_VIT_BLOCK_FWD = 0, SAIS_OP_VIT_BLOCK_BWD = 1, SAIS_OP_TEMPORAL_LAYER_FWD = 2, SAIS_OP_TEMPORAL_LAYER_BWD = 3 };
 size_t sais_workspace_bytes(int op, int frames, int ntok);   /* temporal ops: (op, sequences B, tokens S) */
+/* (ABI 12) bytes per element of the GELU' tensor sais_vit_block_fwd writes and sais_vit_block_bwd reads: 1 = one-byte codes
+ * (default; epilogues 13 / 14), 2 = bf16 (environment SAIS_GELU_GRAD_Q8=0, read once per process; epilogues 10 / 11). */
+int sais_gelu_grad_bytes(void);
 
 typedef struct SaisVitBlockParams {
     /* bf16 weight shadows [out,in] + f32 biases (nn.Linear of Attention :68-92 and Mlp :49-65), f32 LayerNorm parameters */
@@ -271,7 +279,8 @@ typedef struct SaisVitBlockFwd {
     void* xn2;                       /* out: bf16 [M,384] norm2(x_mid) (saved)                                     */
     float* mean2; float* rstd2;      /* out: f32 [M] (saved; NULL in inference)                                    */
     void* h;                         /* out: bf16 [M,1536] GELU(u) (saved; NULL in inference: workspace is used)    */
-    void* gelu_grad;                 /* out: bf16 [M,1536] GELU'(u) (saved; NULL in inference: not evaluated)       */
+    void* gelu_grad;                 /* out: [M,1536] GELU'(u), sais_gelu_grad_bytes() bytes per element: one-byte codes (ABI 12,
+                                        SAIS_EPI_BIAS_GELU_GRADQ_BF16) or bf16 (saved; NULL in inference: not evaluated)       */
     float* x_out;                    /* out: f32 [M,384] (may alias x_mid in inference)                            */
     void* xn_next;                   /* out: bf16 [M,384] next block's norm1(x_out) (with next_norm_g)             */
     float* mean_next; float* rstd_next;   /* out: f32 [M] (optional)                                              */

@@ -115,6 +115,7 @@ EPI_BIAS_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = 0, 1, 2, 3
 EPI_BIAS_GELU_BF16, EPI_DGELU_BF16, EPI_DRELU_BF16, EPI_PATCH_F32 = 4, 5, 6, 7
 EPI_BIAS_RELU_F32, EPI_DRELU_F32 = 8, 9
 EPI_BIAS_GELU_GRAD_BF16, EPI_MUL_BF16, EPI_RAW_SLABS_F32 = 10, 11, 12
+EPI_BIAS_GELU_GRADQ_BF16, EPI_MULQ_BF16 = 13, 14      # GELU' as one-byte codes (ABI 12)
 TG_RAW, TG_BIAS, TG_BIAS_RELU, TG_DRELU = 0, 1, 2, 3
 
 # name -> argtypes; every symbol include/sais_hip.h declares (checked by tests/test_abi.py)
@@ -127,6 +128,7 @@ SIGNATURES = {
     "sais_gemm_ln_fwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
     "sais_gemm_ln_bwd": [ctypes.POINTER(SaisGemmLn), c_void_p],
     "sais_workspace_bytes": [c_int, c_int, c_int],
+    "sais_gelu_grad_bytes": [],
     "sais_vit_block_fwd": [ctypes.POINTER(SaisVitBlockParams), ctypes.POINTER(SaisVitBlockFwd), c_void_p, ctypes.c_size_t,
                            c_void_p],
     "sais_vit_block_bwd": [ctypes.POINTER(SaisVitBlockParams), ctypes.POINTER(SaisVitBlockBwd), c_void_p, ctypes.c_size_t,

@@ -61,6 +61,11 @@ extern "C" size_t sais_workspace_bytes(int op, int frames, int ntok) {
     }
 }
 
+extern "C" int sais_gelu_grad_bytes(void) {
+    static const int v = [] { const char* e = getenv("SAIS_GELU_GRAD_Q8"); return (e && atoi(e) == 0) ? 2 : 1; }();
+    return v;
+}
+
 extern "C" int sais_vit_block_fwd(const SaisVitBlockParams* w, const SaisVitBlockFwd* a, void* workspace, size_t ws_bytes,
                                   void* stream) {
     SAIS_ENTER();
@@ -93,7 +98,9 @@ extern "C" int sais_vit_block_fwd(const SaisVitBlockParams* w, const SaisVitBloc
         TRY(sais_layernorm_fwd(a->x_mid, D, M, D, w->norm2_g, w->norm2_b, 1e-6f, a->xn2, D, nullptr, 0, a->mean2, a->rstd2, stream));
     }
     // MLP branch: fc1 + GELU (+ GELU' for the backward) -> fc2 + residual (+ the next block's norm1)
-    TRY(gemm(a->xn2, D, w->fc1_w, D, M, HID, D, a->gelu_grad ? SAIS_EPI_BIAS_GELU_GRAD_BF16 : SAIS_EPI_BIAS_GELU_BF16, w->fc1_b,
+    const bool gq8 = sais_gelu_grad_bytes() == 1;
+    TRY(gemm(a->xn2, D, w->fc1_w, D, M, HID, D,
+             !a->gelu_grad ? SAIS_EPI_BIAS_GELU_BF16 : gq8 ? SAIS_EPI_BIAS_GELU_GRADQ_BF16 : SAIS_EPI_BIAS_GELU_GRAD_BF16, w->fc1_b,
              h, HID, a->gelu_grad, HID, nullptr, 0, nullptr, stream));
     if (fused && w->next_norm_g) {
         SaisGemmLn g;
@@ -136,7 +143,8 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
     const size_t slab_bytes = block_dw_slab_bytes(M);
     const bool fused = M >= ROW_GEMM_MIN_M;
     // MLP branch: du = (d . W2) * GELU'(u);  d(norm2 out) = du . W1;  norm2's backward adds the residual gradient
-    TRY(gemm(a->dx16_in, D, w->fc2_wt, D, M, HID, D, SAIS_EPI_MUL_BF16, nullptr, du, HID, nullptr, 0, a->gelu_grad, HID, nullptr, stream));
+    TRY(gemm(a->dx16_in, D, w->fc2_wt, D, M, HID, D, sais_gelu_grad_bytes() == 1 ? SAIS_EPI_MULQ_BF16 : SAIS_EPI_MUL_BF16, nullptr, du, HID,
+             nullptr, 0, a->gelu_grad, HID, nullptr, stream));
     if (fused) {
         SaisGemmLn g;
         memset(&g, 0, sizeof(g));

@@ -111,6 +111,16 @@ template <int N> DEVINL void gelu_and_grad_n(float (&y)[N], float (&d)[N]) {
         y[i] = o.x, y[i + 1] = o.y, d[i] = g.x, d[i + 1] = g.y;
     }
 }
+// GELU'(u) in one byte (SAIS_EPI_BIAS_GELU_GRADQ_BF16 / SAIS_EPI_MULQ_BF16): q = clamp(rint(26 + 203 d), 0, 255), d = (q - 26) / 203
+DEVINL unsigned gq8_code(float d) {
+    return (unsigned)__builtin_amdgcn_fmed3f(__builtin_rintf(__builtin_fmaf(d, 203.f, 26.f)), 0.f, 255.f);
+}
+DEVINL unsigned gq8_pack4(float a, float b, float c, float d) {
+    return gq8_code(a) | (gq8_code(b) << 8) | (gq8_code(c) << 16) | (gq8_code(d) << 24);
+}
+DEVINL float gq8_decode(unsigned word, int byte) {
+    return ((float)((word >> (8 * byte)) & 0xffu) - 26.f) * (1.0f / 203.f);
+}
 DEVINL float dgelu_erf(float u) {
     f32x2 g;
     dgelu_erf2(f32x2{u, u}, g);

@@ -30,6 +30,7 @@ constexpr int TILE_BYTES = BM * BK * 2;      // 16 KiB per operand per stage
 struct EpiAux {
     f32x4 r[4][4];        // f32 aux (residual / position rows): 16 columns x 4 sub-tiles
     bf16x8 u[4][2];       // bf16 aux (pre-activation)
+    u32x4 q[4];           // one-byte GELU' codes
 };
 
 template <int EPI>
@@ -58,6 +59,8 @@ DEVINL void epilogue_loads(const NtParams& p, int mbase, int li, int n, float (&
             const bf16* u = (const bf16*)p.aux + (size_t)m * p.ldaux + n;
             a.u[mt][0] = *(const bf16x8*)u;
             a.u[mt][1] = *(const bf16x8*)(u + 8);
+        } else if constexpr (EPI == SAIS_EPI_MULQ_BF16) {
+            a.q[mt] = *(const u32x4*)((const unsigned char*)p.aux + (size_t)m * p.ldaux + n);
         }
     }
 }
@@ -115,9 +118,20 @@ DEVINL void epilogue(const NtParams& p, int m, int n, const float (&v)[16], cons
         gelu_and_grad_n(y, d);
         store_bf16(p.out2, p.ldo2, d);
         store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRADQ_BF16) {
+        float d[16];
+        gelu_and_grad_n(y, d);
+        *(u32x4*)((unsigned char*)p.out2 + (size_t)m * p.ldo2 + n) =
+            u32x4{gq8_pack4(d[0], d[1], d[2], d[3]), gq8_pack4(d[4], d[5], d[6], d[7]), gq8_pack4(d[8], d[9], d[10], d[11]),
+                  gq8_pack4(d[12], d[13], d[14], d[15])};
+        store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) y[i] *= (float)a.u[mt][i >> 3][i & 7];
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_MULQ_BF16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) y[i] *= gq8_decode(a.q[mt][i >> 2], i & 3);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
 #pragma unroll
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_w8p_kernel(NtParams p, int nti
     const int nk = p.K / BK;
     // store instructions one wave issues in a full tile's epilogue
     constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2 : (EPI == SAIS_EPI_PATCH_F32) ? 2
-                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
+                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16 || EPI == SAIS_EPI_BIAS_GELU_GRADQ_BF16) ? 2 : 1;
     const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
 
     // A-operand prefetch into L2 (K = 384, N >= 1024).  The ntn column tiles of a row tile run side by side on one XCD and
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_w8r_kernel(NtParams p, int nti
 #define W8R_WAIT(N, SET) asm volatile("s_waitcnt vmcnt(" #N ") lgkmcnt(0)"                                                 \
                                       : "+v"(wf[SET][0][0]), "+v"(wf[SET][0][1]), "+v"(wf[SET][1][0]), "+v"(wf[SET][1][1]) :: "memory")
     constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2 : (EPI == SAIS_EPI_PATCH_F32) ? 2
-                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
+                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16 || EPI == SAIS_EPI_BIAS_GELU_GRADQ_BF16) ? 2 : 1;
     const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
     auto prologue = [&] {                                             // W(0), A(0), W(1), A(1), A(2), A(3): the order the waits count on
         load_w(0, wf[0]);
@@ -640,7 +654,7 @@ __global__ __launch_bounds__(1024) void gemm_nt_w16_kernel(NtParams p, int ntile
     };
     const int nk = p.K / BK;
     constexpr int SROW = (EPI == SAIS_EPI_BIAS_F32) ? 2 : (EPI == SAIS_EPI_BIAS_RESID_F32) ? 2 : (EPI == SAIS_EPI_PATCH_F32) ? 2
-                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16) ? 2 : 1;
+                       : (EPI == SAIS_EPI_BIAS_GELU_GRAD_BF16 || EPI == SAIS_EPI_BIAS_GELU_GRADQ_BF16) ? 2 : 1;
     const int nstores = 4 * (SROW + ((EPI == SAIS_EPI_BIAS_RESID_F32 || EPI == SAIS_EPI_BIAS_GELU_BF16) && p.out2 ? 1 : 0));
     // virtual workgroup ids: group 0 = blockIdx.x, group 1 = blockIdx.x + gridDim.x (same XCD); both walk with stride 2 G
     const int G2 = 2 * (int)gridDim.x;
@@ -1688,7 +1702,9 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
     SAIS_ENTER();
     if (!g || !g->A || !g->B || !g->out) return SAIS_ERR_ARG;
     if (g->M <= 0 || g->N % BN || g->K % BK || g->lda % 8 || g->ldb % 8 || g->ldo % 8) return SAIS_ERR_ARG;
-    if (g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 && !g->out2) return SAIS_ERR_ARG;
+    if ((g->epilogue == SAIS_EPI_BIAS_GELU_GRAD_BF16 || g->epilogue == SAIS_EPI_BIAS_GELU_GRADQ_BF16) && !g->out2) return SAIS_ERR_ARG;
+    if (g->epilogue == SAIS_EPI_BIAS_GELU_GRADQ_BF16 && (g->ldo2 % 16 || ((uintptr_t)g->out2 & 15))) return SAIS_ERR_ARG;
+    if (g->epilogue == SAIS_EPI_MULQ_BF16 && (!g->aux || g->ldaux % 16 || ((uintptr_t)g->aux & 15))) return SAIS_ERR_ARG;
     if ((g->epilogue == SAIS_EPI_MUL_BF16 || g->epilogue == SAIS_EPI_DGELU_BF16 || g->epilogue == SAIS_EPI_DRELU_BF16 ||
          g->epilogue == SAIS_EPI_BIAS_RESID_F32) && !g->aux)
         return SAIS_ERR_ARG;
@@ -1726,6 +1742,8 @@ extern "C" int sais_gemm_nt(const SaisGemm* g, void* stream) {
         LAUNCH_NT(SAIS_EPI_PATCH_F32)
         LAUNCH_NT(SAIS_EPI_BIAS_GELU_GRAD_BF16)
         LAUNCH_NT(SAIS_EPI_MUL_BF16)
+        LAUNCH_NT(SAIS_EPI_BIAS_GELU_GRADQ_BF16)
+        LAUNCH_NT(SAIS_EPI_MULQ_BF16)
         default: return SAIS_ERR_ARG;
     }
     return sais_check_launch();

@@ -29,6 +29,7 @@ DEVINL int perm_row32(int n) { return (n & ~31) | (((n >> 2) & 3) << 3) | (((n >
 struct EpiAux8 {
     f32x4 r[4][2];        // f32 aux: 8 columns x 4 sub-tiles
     bf16x8 u[4];          // bf16 aux
+    u32x2 q[4];           // one-byte GELU' codes (SAIS_EPI_MULQ_BF16)
 };
 
 template <int EPI>
@@ -53,6 +54,8 @@ DEVINL void epilogue_loads8(const NtParams& p, int mbase, int li, int n, float (
             a.r[mt][1] = *(const f32x4*)(r + 4);
         } else if constexpr (EPI == SAIS_EPI_DGELU_BF16 || EPI == SAIS_EPI_DRELU_BF16 || EPI == SAIS_EPI_MUL_BF16) {
             a.u[mt] = *(const bf16x8*)((const bf16*)p.aux + (size_t)m * p.ldaux + n);
+        } else if constexpr (EPI == SAIS_EPI_MULQ_BF16) {
+            a.q[mt] = *(const u32x2*)((const unsigned char*)p.aux + (size_t)m * p.ldaux + n);
         }
     }
 }
@@ -107,9 +110,19 @@ DEVINL void epilogue8(const NtParams& p, int m, int n, const float (&v)[8], cons
         gelu_and_grad_n(y, d);
         store_bf16(p.out2, p.ldo2, d, 1);
         store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_BIAS_GELU_GRADQ_BF16) {
+        float d[8];
+        gelu_and_grad_n(y, d);
+        *(u32x2*)((unsigned char*)p.out2 + (size_t)m * p.ldo2 + n) =
+            u32x2{gq8_pack4(d[0], d[1], d[2], d[3]), gq8_pack4(d[4], d[5], d[6], d[7])};
+        store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_MUL_BF16) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) y[i] *= (float)a.u[mt][i];
+        store_bf16(p.out, p.ldo, y);
+    } else if constexpr (EPI == SAIS_EPI_MULQ_BF16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] *= gq8_decode(a.q[mt][i >> 2], i & 3);
         store_bf16(p.out, p.ldo, y);
     } else if constexpr (EPI == SAIS_EPI_DGELU_BF16) {
 #pragma unroll

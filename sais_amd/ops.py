@@ -55,7 +55,27 @@ def _timed(tag, flops, nbytes, fn):
 
 
 _NT_NAMES = {12: "raw_slabs_f32", 0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_bf16", 5: "dgelu_bf16", 6: "drelu_bf16",
-             7: "patch_f32", 8: "relu_f32", 9: "drelu_f32", 10: "gelu_grad_bf16", 11: "mul_bf16"}
+             7: "patch_f32", 8: "relu_f32", 9: "drelu_f32", 10: "gelu_grad_bf16", 11: "mul_bf16", 13: "gelu_gradq_bf16",
+             14: "mulq_bf16"}
+
+
+def gelu_grad_q8(M=0):
+    """True: the MLP of a ViT block keeps GELU'(u) for its backward as one-byte codes (EPI_BIAS_GELU_GRADQ_BF16 / EPI_MULQ_BF16,
+    include/sais_hip.h; half the bytes of the tensor) — the library's default (sais_gelu_grad_bytes() == 1; SAIS_GELU_GRAD_Q8=0
+    for bf16).  The one-launch MLP (SAIS_MLP_FUSED=1, an experiment record) has its own bf16 pair."""
+    return L.load().sais_gelu_grad_bytes() == 1 and not mlp_fused_enabled(M)
+
+
+def gelu_grad_buffer(M, n, device):
+    return torch.empty(M, n, dtype=torch.uint8 if gelu_grad_q8(M) else BF16, device=device)
+
+
+def epi_gelu_grad(M=0):
+    return L.EPI_BIAS_GELU_GRADQ_BF16 if gelu_grad_q8(M) else L.EPI_BIAS_GELU_GRAD_BF16
+
+
+def epi_mul(M=0):
+    return L.EPI_MULQ_BF16 if gelu_grad_q8(M) else L.EPI_MUL_BF16
 
 
 def _chk(t, dtype, name):

@@ -333,7 +333,7 @@ class VisionTransformer(nn.Module):
                 if save:
                     xn2 = e16(M, D)
                 mean2, rstd2 = (e32(M), e32(M)) if save else (None, None)
-                u = e16(M, HID) if save else None
+                u = ops.gelu_grad_buffer(M, HID, x.device) if save else None
                 nxt = i + 1 < self.depth
                 blk = dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=[lse0], x_mid=x_mid, mean2=mean2,
                            rstd2=rstd2, xn2=xn2, dgelu=u, h=h) if save else None
@@ -372,7 +372,7 @@ class VisionTransformer(nn.Module):
                             bias=f.w32(p + "attn.proj.bias"), aux=x, rowscale=rs_attn)
                 ops.layernorm_fwd(x_mid, M, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2,
                                   mean=mean2, rstd=rstd2)
-            u = e16(M, HID) if save else None
+            u = ops.gelu_grad_buffer(M, HID, x.device) if save else None
             x_out = e32(M, D) if save else x
             blk = dict(x_in=x, mean1=mean1, rstd1=rstd1, xn1=xn, qkv=qkv, ao=ao, lse=lse, x_mid=x_mid, mean2=mean2,
                        rstd2=rstd2, xn2=xn2, dgelu=u, h=h) if save else None
@@ -389,7 +389,7 @@ class VisionTransformer(nn.Module):
                             beta=f.w32(q + "norm1.bias") if nxt else None, eps=1e-6, mean=mean1 if nxt else None,
                             rstd=rstd1 if nxt else None, rowscale=rs_mlp)
             else:
-                ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
+                ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), ops.epi_gelu_grad(M) if save else L.EPI_BIAS_GELU_BF16, h,
                             bias=f.w32(p + "mlp.fc1.bias"), out2=u)
                 if nxt:
                     ops.gemm_ln_fwd(h, f.w(p + "mlp.fc2.weight"), f.w32(p + "mlp.fc2.bias"), x_mid, x_out, xn,
@@ -451,8 +451,8 @@ class VisionTransformer(nn.Module):
                            out32=x_mid)
         ops.layernorm_fwd(x_mid, Ftot, D, f.w32(p + "norm2.weight"), f.w32(p + "norm2.bias"), 1e-6, y16=xn2, mean=mean2,
                           rstd=rstd2)
-        h, u = e16(Ftot, HID), (e16(Ftot, HID) if save else None)
-        ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), L.EPI_BIAS_GELU_GRAD_BF16 if save else L.EPI_BIAS_GELU_BF16, h,
+        h, u = e16(Ftot, HID), (ops.gelu_grad_buffer(Ftot, HID, x.device) if save else None)
+        ops.gemm_nt(xn2, f.w(p + "mlp.fc1.weight"), ops.epi_gelu_grad(Ftot) if save else L.EPI_BIAS_GELU_BF16, h,
                     bias=f.w32(p + "mlp.fc1.bias"), out2=u)
         ops.gemm_nt_splitk(h, f.w(p + "mlp.fc2.weight"), 12, bias=f.w32(p + "mlp.fc2.bias"), rowscale=rs_mlp, aux=x_mid,
                            out32=x_out)
@@ -486,7 +486,7 @@ class VisionTransformer(nn.Module):
             ops.cast_bf16(dx_c, dxa_c)
         else:
             ops.cast_bf16_rows(dx_c, s["rs_mlp"], dxa_c)
-        ops.gemm_nt(dxa_c, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
+        ops.gemm_nt(dxa_c, f.wt16[p + "mlp.fc2.weight"], ops.epi_mul(Ftot), du, aux=s["dgelu"])
         ops.gemm_nt_splitk(du, f.wt16[p + "mlp.fc1.weight"], 12, out16=dxn)
         ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), Ftot, dy16=dxn, dres=dx_c, dx32=dx_c,
                           dx16=dxb_c, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"), rowscale16=s["rs_attn"])
@@ -586,12 +586,12 @@ class VisionTransformer(nn.Module):
                             s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), dres=dx, dx32=dx, dx16=dxb,
                             dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"), rowscale16=rs_attn)
             elif fused:       # dX of fc1 with norm2's backward (+ residual gradient) in its epilogue
-                ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
+                ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], ops.epi_mul(M), du, aux=s["dgelu"])
                 ops.gemm_ln_bwd(du, f.wt16[p + "mlp.fc1.weight"], s["x_mid"], s["mean2"], s["rstd2"],
                                 f.w32(p + "norm2.weight"), dres=dx, dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"),
                                 dbeta=f.g(p + "norm2.bias"), rowscale16=rs_attn, xn16=s["xn2"], beta=f.w32(p + "norm2.bias"))
             else:
-                ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], L.EPI_MUL_BF16, du, aux=s["dgelu"])
+                ops.gemm_nt(dxa, f.wt16[p + "mlp.fc2.weight"], ops.epi_mul(M), du, aux=s["dgelu"])
                 ops.gemm_nt(du, f.wt16[p + "mlp.fc1.weight"], L.EPI_BIAS_BF16, dxn)
                 ops.layernorm_bwd(s["x_mid"], D, s["mean2"], s["rstd2"], f.w32(p + "norm2.weight"), M, dy16=dxn, dres=dx,
                                   dx32=dx, dx16=dxb, dgamma=f.g(p + "norm2.weight"), dbeta=f.g(p + "norm2.bias"),

@@ -105,8 +105,21 @@ def test_gemm_nt_epilogues(ops, M, N, K):
     assert_close(dg, rf.grad, name="gelu_grad", **tol)
     ops.gemm_nt(a, w, L.EPI_MUL_BF16, out, aux=pre)
     assert_close(out, (ref - bias) * pre.float(), name="mul", **tol)
+    # the shipped pair (ABI 12): GELU' as one-byte codes q = clamp(rint(26 + 203 d), 0, 255), d = (q - 26) / 203
+    dq = torch.empty(M, N, dtype=torch.uint8, device=DEV)
+    ops.gemm_nt(a, w, L.EPI_BIAS_GELU_GRADQ_BF16, out, bias=bias, out2=dq)
+    assert_close(out, F.gelu(ref), name="gelu(+gradq)", **tol)
+    want = (26 + 203 * rf.grad).round().clamp(0, 255)
+    assert float((dq.float() - want).abs().max()) <= 1          # one code off only where 26 + 203 d sits on a rounding boundary
+    assert float((dq.float() != want).float().mean()) <= 2e-3
+    assert float(((dq.float() - 26) / 203 - rf.grad).abs().max()) <= 0.5 / 203 + 1.5e-3      # half a step + the clipped extremes
+    codes = torch.randint(0, 256, (M, N), dtype=torch.uint8, generator=torch.Generator().manual_seed(12)).to(DEV)
+    ops.gemm_nt(a, w, L.EPI_MULQ_BF16, out, aux=codes)
+    assert_close(out, (ref - bias) * ((codes.float() - 26) / 203), name="mulq", **tol)
     with pytest.raises(L.SaisHipError):
         ops.gemm_nt(a, w, L.EPI_BIAS_GELU_GRAD_BF16, out, bias=bias)             # out2 is mandatory
+    with pytest.raises(L.SaisHipError):
+        ops.gemm_nt(a, w, L.EPI_MULQ_BF16, out)                                  # aux is mandatory
     with pytest.raises(L.SaisHipError):
         ops.gemm_nt(a, w, L.EPI_MUL_BF16, out)                                   # aux is mandatory
 
