@@ -23,7 +23,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NT_NAMES = {0: "bias_bf16", 1: "relu_bf16", 2: "f32", 3: "resid_f32", 4: "gelu_bf16", 5: "dgelu_bf16", 6: "drelu_bf16",
-            7: "patch_f32", 8: "relu_f32", 9: "drelu_f32", 10: "gelu_grad_bf16", 11: "mul_bf16", 12: "raw_slabs_f32"}
+            7: "patch_f32", 8: "relu_f32", 9: "drelu_f32", 10: "gelu_grad_bf16", 11: "mul_bf16", 12: "raw_slabs_f32",
+            13: "gelu_gradq_bf16", 14: "mulq_bf16"}
 ROW_NAMES = {0: "gemm_nt<bias_bf16>(row)", 1: "gemm_nt<resid_f32>(row)", 2: "gemm_ln_fwd", 3: "gemm_ln_bwd"}
 
 
