@@ -104,6 +104,14 @@ def test_tail_graph_and_batched_windows_equal_the_small_batch_forms(gpu):
     assert sorted(fit._graphs) == [10, 22, 128] and torch.equal(f9, FeatureExtractor(vit, batch_size=128, use_graph=False,
                                                                                       tail_batch="fit")(frames[:9]))
     assert float((f9 - b[:9]).abs().max()) <= 2e-2 * float(b.abs().max())
+    # at most MAX_GRAPHS captured shapes are kept: the least recently used remainder shape goes, never the main shape
+    small = FeatureExtractor(vit, batch_size=8, use_graph=True, tail_batch="fit", tail_round=1)
+    small.MAX_GRAPHS = 3
+    for n in (8, 1, 2, 1, 3, 4):
+        got = small(frames[:n])
+        assert sorted(small._graphs)[-1] == 8 and len(small._graphs) <= 3
+    assert sorted(small._graphs) == [3, 4, 8]
+    assert torch.equal(got, FeatureExtractor(vit, batch_size=8, use_graph=False, tail_batch="fit", tail_round=1)(frames[:4]))
     reps = synth.reps(seed=3, B=1, T=200)[0, 0].to(DEV)
     flow = synth.reps(seed=4, B=1, T=13)[0, 0].to(DEV)
     big, attn_big, _ = run_windows(m, reps, flow, videoname="v", batch_size=2)                 # 13 windows in one call
