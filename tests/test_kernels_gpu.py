@@ -936,3 +936,15 @@ def test_alternate_dw_forms_pass_the_same_tests(ops, switch, value):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_kernels_gpu.py"), "-q", "-x", "-k", sel],
                        env=dict(os.environ, **{switch: value}), cwd=root, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+def test_bf16_gelu_grad_form_passes_the_model_gradient_tests(ops):
+    """SAIS_GELU_GRAD_Q8=0 (read once per process): GELU' saved as bf16 (epilogues 10 / 11, rounds 3-5) instead of one-byte codes —
+    the ViT gradient tests against the golden vectors in a child process with the switch set, block API and per-launch path."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_model_gpu.py"), "-q", "-x", "-k",
+                        "vit_grads or e2e_train_step or block_level or pruned_last_block"],
+                       env=dict(os.environ, SAIS_GELU_GRAD_Q8="0"), cwd=root, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
