@@ -887,6 +887,12 @@ def main():
         # key of the same kernel in profiles/pmc_traffic.json ("gemm_ln_bwd[N384,K1536]" -> "gemm_ln_bwd[K1536]")
         base = kern.split("[")[0]
         pmc_key = base + "[" + kern.split(",")[-1] if base in ("gemm_ln_fwd", "gemm_ln_bwd") else base
+        if base == "gemm_tn_grouped" and "GEMMs" in kern:
+            # the dW launches of a step share one kernel and differ in size: the counter file keys them by workgroup count.  ViT-S: 24
+            # tiles of 192 x 384 per block (4 GEMMs), 4 for the k / v gradient of the CLS-only block; splits = 256 // tiles
+            n_gemm = int(kern.split("[")[1].split(" ")[0])
+            tiles = (n_gemm // 4) * 24 + (n_gemm % 4) * 4
+            pmc_key = "gemm_tn_grouped[%d wg]" % (tiles * max(1, 256 // tiles))
         pmc_all, pmc_stale = load_pmc("pmc_traffic.json")
         pmc = None if pmc_stale else (pmc_all or {}).get(pmc_key)
         roof = dict(bound="mfma", kernel=kern, achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SAIS_ABI_VERSION 12
+#define SAIS_ABI_VERSION 13
 int sais_abi_version(void);
 /* text of the HIP error behind the calling thread's last SAIS_ERR_LAUNCH (-2) return */
 const char* sais_last_error(void);
@@ -141,7 +141,7 @@ int sais_gemm_tn(const void* P, int ldp, const void* Q, int ldq, int M, int N1, 
                  float* dW, int ldw, float* db, int nsplit, void* stream);
 /* Several weight-gradient GEMMs over the same M rows in ONE launch (all bf16): the four nn.Linear of a ViT
  * block give 108 output tiles, so a few M-splits fill the chip and the atomic traffic shrinks accordingly. */
-#define SAIS_TN_MAX_ITEMS 16
+#define SAIS_TN_MAX_ITEMS 48
 typedef struct SaisTnItem {
     const void* P; int ldp;        /* bf16 [M,N1]  (dY)  */
     const void* Q; int ldq;        /* bf16 [M,N2]  (X)   */
@@ -299,8 +299,21 @@ typedef struct SaisVitBlockBwd {
     void* dx16_out;                  /* out: bf16 [M,384] = bf16(rowscale_prev * dx on return): the next call's dx16_in    */
     const float* rowscale_attn;      /* DropPath scale of THIS block's attention branch, or NULL                           */
     const float* rowscale_prev;      /* DropPath scale of the PREVIOUS block's MLP branch (applied to dx16_out), or NULL   */
+    int defer_dw;                    /* (ABI 13) != 0: the weight / bias gradients of this block are NOT launched by this call;
+                                        sais_vit_blocks_dw launches them for several blocks at once.  Until then the caller keeps
+                                        this struct's tensors, the workspace of this call and dx16_in untouched (dx16_out must
+                                        then be a different buffer than dx16_in)                                             */
 } SaisVitBlockBwd;
 int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBlockBwd* a, void* workspace, size_t ws_bytes, void* stream);
+/* (ABI 13) The weight / bias gradients of `nblocks` blocks whose sais_vit_block_bwd calls ran with defer_dw, as ONE grouped launch of
+ * 4 nblocks GEMMs (dW += P^T Q over the M = frames x ntok rows; LABNOTES R6.8).  One launch per block cuts M into ten splits so
+ * that its 24 tiles fill the chip, and every split writes a partial tile that a second launch sums; two blocks per launch need five
+ * splits, ten blocks none: 187 -> 160 -> 149 us per block at M = 50 432.  w[i], a[i], workspaces[i] = what call i was given
+ * (each workspace >= sais_workspace_bytes(SAIS_OP_VIT_BLOCK_BWD, ...) bytes = ws_bytes). */
+int sais_vit_blocks_dw(const SaisVitBlockParams* const* w, const SaisVitBlockBwd* const* a, void* const* workspaces, size_t ws_bytes,
+                       int nblocks, const SaisTnItem* extra, int nextra, void* stream);
+/* extra / nextra: further GEMMs over the same M rows to ride in the launch (the k / v weight gradient of the CLS-only last block:
+ * 4 more tiles); 4 nblocks + nextra <= SAIS_TN_MAX_ITEMS. */
 
 /* One layer of the temporal encoder per call: the torch-1.8 POST-norm nn.TransformerEncoderLayer(d 384, 4 heads, FF 2048,
  * ReLU, dropout 0.1, LayerNorm eps 1e-5) of prepare_model.py:74-81 as patched by README.md:43-48 (returns the attention map):

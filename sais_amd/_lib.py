@@ -31,7 +31,7 @@ class SaisTGemm(ctypes.Structure):
                 ("site", ctypes.c_uint)]
 
 
-TN_MAX_ITEMS = 16            # SAIS_TN_MAX_ITEMS
+TN_MAX_ITEMS = 48            # SAIS_TN_MAX_ITEMS
 
 
 class SaisTnItem(ctypes.Structure):
@@ -70,7 +70,7 @@ class SaisVitBlockFwd(ctypes.Structure):
 class SaisVitBlockBwd(ctypes.Structure):
     _fields_ = [("frames", c_int), ("ntok", c_int)] + [(n, c_void_p) for n in (
         "x_in", "mean1", "rstd1", "xn1", "qkv", "attn_out", "lse", "x_mid", "mean2", "rstd2", "xn2", "h", "gelu_grad", "dx",
-        "dx16_in", "dx16_out", "rowscale_attn", "rowscale_prev")]
+        "dx16_in", "dx16_out", "rowscale_attn", "rowscale_prev")] + [("defer_dw", c_int)]
 
 
 class SaisTemporalLayerParams(ctypes.Structure):
@@ -133,6 +133,8 @@ SIGNATURES = {
                            c_void_p],
     "sais_vit_block_bwd": [ctypes.POINTER(SaisVitBlockParams), ctypes.POINTER(SaisVitBlockBwd), c_void_p, ctypes.c_size_t,
                            c_void_p],
+    "sais_vit_blocks_dw": [ctypes.POINTER(ctypes.POINTER(SaisVitBlockParams)), ctypes.POINTER(ctypes.POINTER(SaisVitBlockBwd)),
+                           ctypes.POINTER(c_void_p), ctypes.c_size_t, c_int, ctypes.POINTER(SaisTnItem), c_int, c_void_p],
     "sais_temporal_layer_fwd": [ctypes.POINTER(SaisTemporalLayerParams), ctypes.POINTER(SaisTemporalLayerFwd), c_void_p,
                                 ctypes.c_size_t, c_void_p],
     "sais_temporal_layer_bwd": [ctypes.POINTER(SaisTemporalLayerParams), ctypes.POINTER(SaisTemporalLayerBwd), c_void_p,

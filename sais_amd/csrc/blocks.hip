@@ -61,6 +61,37 @@ extern "C" size_t sais_workspace_bytes(int op, int frames, int ntok) {
     }
 }
 
+namespace {
+// scratch of one backward call (sais_workspace_bytes(SAIS_OP_VIT_BLOCK_BWD)): the gradient tensors that live inside the block
+struct BwdScratch { void* du; void* dxb; void* dao; void* dxn; void* dqkv; void* slabs; };
+BwdScratch carve(void* workspace, int M) {
+    char* ws = (char*)workspace;
+    BwdScratch s;
+    s.du = ws;             ws += up((size_t)M * HID * 2);
+    s.dxb = ws;            ws += up((size_t)M * D * 2);
+    s.dao = ws;            ws += up((size_t)M * D * 2);
+    s.dxn = ws;            ws += up((size_t)M * D * 2);
+    s.dqkv = ws;           ws += up((size_t)M * QKV * 2);
+    s.slabs = ws;
+    return s;
+}
+// the four weight / bias gradients of a block as items of the grouped dW launch
+void dw_items(const SaisVitBlockParams* w, const SaisVitBlockBwd* a, const BwdScratch& sc, SaisTnItem* items) {
+    items[0] = SaisTnItem{a->dx16_in, D, a->h, HID, D, HID, w->d_fc2_w, HID, w->d_fc2_b};
+    items[1] = SaisTnItem{sc.du, HID, a->xn2, D, HID, D, w->d_fc1_w, D, w->d_fc1_b};
+    items[2] = SaisTnItem{sc.dxb, D, a->attn_out, D, D, D, w->d_proj_w, D, w->d_proj_b};
+    items[3] = SaisTnItem{sc.dqkv, QKV, a->xn1, D, QKV, D, w->d_qkv_w, D, w->d_qkv_b};
+}
+// M-splits for the kernels that take the number from the caller (the 192 x 384 kernel plans its own)
+int dw_nsplit(int M, int nblocks) {
+    const int tiles = nblocks * ((D / 128) * (HID / 128) * 2 + (D / 128) * (D / 128) + (QKV / 128) * (D / 128));
+    int nsplit = (432 + tiles - 1) / tiles;
+    const int cap = (M + 255) / 256;
+    if (nsplit > cap) nsplit = cap;
+    return nsplit < 1 ? 1 : nsplit;
+}
+}  // namespace
+
 extern "C" int sais_gelu_grad_bytes(void) {
     static const int v = [] { const char* e = getenv("SAIS_GELU_GRAD_Q8"); return (e && atoi(e) == 0) ? 2 : 1; }();
     return v;
@@ -133,14 +164,11 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
     if (!workspace || ws_bytes < sais_workspace_bytes(SAIS_OP_VIT_BLOCK_BWD, a->frames, a->ntok) || ((uintptr_t)workspace & 15))
         return SAIS_ERR_ARG;
     const int M = a->frames * a->ntok;
-    char* ws = (char*)workspace;
-    void* du = ws;             ws += up((size_t)M * HID * 2);
-    void* dxb = ws;            ws += up((size_t)M * D * 2);
-    void* dao = ws;            ws += up((size_t)M * D * 2);
-    void* dxn = ws;            ws += up((size_t)M * D * 2);
-    void* dqkv = ws;           ws += up((size_t)M * QKV * 2);
-    void* slabs = ws;
+    const BwdScratch sc = carve(workspace, M);
+    void* const du = sc.du; void* const dxb = sc.dxb; void* const dao = sc.dao; void* const dxn = sc.dxn; void* const dqkv = sc.dqkv;
+    void* const slabs = sc.slabs;
     const size_t slab_bytes = block_dw_slab_bytes(M);
+    if (a->defer_dw && a->dx16_in == a->dx16_out) return SAIS_ERR_ARG;
     const bool fused = M >= ROW_GEMM_MIN_M;
     // MLP branch: du = (d . W2) * GELU'(u);  d(norm2 out) = du . W1;  norm2's backward adds the residual gradient
     TRY(gemm(a->dx16_in, D, w->fc2_wt, D, M, HID, D, sais_gelu_grad_bytes() == 1 ? SAIS_EPI_MULQ_BF16 : SAIS_EPI_MUL_BF16, nullptr, du, HID,
@@ -163,18 +191,10 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
     TRY(gemm(dxb, D, w->proj_wt, D, M, D, D, SAIS_EPI_BIAS_BF16, nullptr, dao, D, nullptr, 0, nullptr, 0, nullptr, stream));
     TRY(sais_vit_attn_bwd(a->qkv, QKV, dao, D, a->attn_out, D, a->lse, nullptr, a->frames, a->ntok, dqkv, QKV, stream));
     // the four weight / bias gradients of the block in one launch
-    SaisTnItem items[4] = {
-        {a->dx16_in, D, a->h, HID, D, HID, w->d_fc2_w, HID, w->d_fc2_b},
-        {du, HID, a->xn2, D, HID, D, w->d_fc1_w, D, w->d_fc1_b},
-        {dxb, D, a->attn_out, D, D, D, w->d_proj_w, D, w->d_proj_b},
-        {dqkv, QKV, a->xn1, D, QKV, D, w->d_qkv_w, D, w->d_qkv_b}};
-    {
-        const int tiles = (D / 128) * (HID / 128) * 2 + (D / 128) * (D / 128) + (QKV / 128) * (D / 128);
-        int nsplit = (432 + tiles - 1) / tiles;
-        const int cap = (M + 255) / 256;
-        if (nsplit > cap) nsplit = cap;
-        if (nsplit < 1) nsplit = 1;
-        TRY(sais_gemm_tn_grouped_ws(items, 4, M, nsplit, slab_bytes ? slabs : nullptr, slab_bytes, stream));
+    if (!a->defer_dw) {
+        SaisTnItem items[4];
+        dw_items(w, a, sc, items);
+        TRY(sais_gemm_tn_grouped_ws(items, 4, M, dw_nsplit(M, 1), slab_bytes ? slabs : nullptr, slab_bytes, stream));
     }
     // dX of qkv + norm1's backward: the gradient of the block input
     if (fused) {
@@ -192,6 +212,28 @@ extern "C" int sais_vit_block_bwd(const SaisVitBlockParams* w, const SaisVitBloc
                                a->dx16_out, D, w->d_norm1_g, w->d_norm1_b, a->rowscale_prev, nullptr, 0.f, nullptr, 0, stream));
     }
     return SAIS_OK;
+}
+
+extern "C" int sais_vit_blocks_dw(const SaisVitBlockParams* const* w, const SaisVitBlockBwd* const* a, void* const* workspaces,
+                                  size_t ws_bytes, int nblocks, const SaisTnItem* extra, int nextra, void* stream) {
+    SAIS_ENTER();
+    if (!w || !a || !workspaces || nblocks <= 0 || nextra < 0 || (nextra && !extra) || 4 * nblocks + nextra > SAIS_TN_MAX_ITEMS)
+        return SAIS_ERR_ARG;
+    SaisTnItem items[SAIS_TN_MAX_ITEMS];
+    const int M = a[0] ? a[0]->frames * a[0]->ntok : 0;
+    for (int i = 0; i < nblocks; ++i) {
+        if (!w[i] || !a[i] || !workspaces[i] || a[i]->frames * a[i]->ntok != M || M <= 0) return SAIS_ERR_ARG;
+        if (ws_bytes < sais_workspace_bytes(SAIS_OP_VIT_BLOCK_BWD, a[i]->frames, a[i]->ntok)) return SAIS_ERR_ARG;
+        dw_items(w[i], a[i], carve(workspaces[i], M), items + 4 * i);
+    }
+    // partial tiles of the M-splits go to the slab region of the first workspace when it is large enough (it is sized for one block at
+    // ten splits = 240 partial tiles; two blocks at five, five at two are as many); otherwise fp32 atomics
+    for (int i = 0; i < nextra; ++i) items[4 * nblocks + i] = extra[i];
+    const int n = 4 * nblocks + nextra;
+    const size_t need = sais_gemm_tn_grouped_slab_bytes(items, n, M);
+    const size_t have = block_dw_slab_bytes(M);
+    void* slabs = need && need <= have ? carve(workspaces[0], M).slabs : nullptr;
+    return sais_gemm_tn_grouped_ws(items, n, M, dw_nsplit(M, nblocks), slabs, slabs ? have : 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- temporal encoder layer

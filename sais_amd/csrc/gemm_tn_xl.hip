@@ -342,14 +342,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void gemm_tn_xl_kernel(XlGroup gp,
     }
     // D[n1][n2]: register r of tile (i, j) = rows 32 i + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column 32 j + (lane & 31)
     float* const out = p.dW + (size_t)(n1_0 + wr * 96 + 4 * hh) * p.ldw + n2_0 + wc * (32 * BJ) + col;
+    if (gp.nsplit == 1) {                                    // the tile has ONE owner: plain read-add-write, 128-B row segments
 #pragma unroll
-    for (int i = 0; i < AI; ++i)
+        for (int i = 0; i < AI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float* row = out + (size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * p.ldw;
+            for (int r = 0; r < 16; ++r) {
+                float* row = out + (size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * p.ldw;
+                float old[BJ];
 #pragma unroll
-            for (int j = 0; j < BJ; ++j) atomicAdd(row + 32 * j, acc[i * BJ + j][r]);
-        }
+                for (int j = 0; j < BJ; ++j) old[j] = row[32 * j];
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) row[32 * j] = old[j] + acc[i * BJ + j][r];
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < AI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* row = out + (size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * p.ldw;
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) atomicAdd(row + 32 * j, acc[i * BJ + j][r]);
+            }
+    }
     if (do_bias && col < AI) {                               // column i of accb = the sums of fragment i's 32 rows
         float* b = p.db + n1_0 + wr * 96 + 32 * col + 4 * hh;
 #pragma unroll

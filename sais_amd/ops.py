@@ -2,6 +2,7 @@
 memory, the current HIP stream, and dtype checks; every op below is one hand-written gfx950 kernel.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -404,12 +405,39 @@ def vit_block_fwd(P, frames, ntok, xn1, x_in, qkv, attn_out, lse, x_mid, xn2, me
     L.call("sais_vit_block_fwd", ctypes.byref(P), ctypes.byref(a), _p(ws), 0 if ws is None else ws.numel(), _stream())
 
 
-def vit_block_bwd(P, frames, ntok, s, dx, dx16_in, dx16_out, rs_attn, rs_prev, lse, ws):
-    """One ViT Block backward as ONE C call (sais_vit_block_bwd); s = the tensors the forward saved."""
+def vit_block_bwd(P, frames, ntok, s, dx, dx16_in, dx16_out, rs_attn, rs_prev, lse, ws, defer_dw=False):
+    """One ViT Block backward as ONE C call (sais_vit_block_bwd); s = the tensors the forward saved.  defer_dw: the block's weight /
+    bias gradients are left to a later vit_blocks_dw (which takes the returned argument struct); the caller keeps s, ws and dx16_in
+    alive and unmodified until then."""
     a = L.SaisVitBlockBwd(frames, ntok, _p(s["x_in"]), _p(s["mean1"]), _p(s["rstd1"]), _p(s["xn1"]), _p(s["qkv"]), _p(s["ao"]),
                           _p(lse), _p(s["x_mid"]), _p(s["mean2"]), _p(s["rstd2"]), _p(s["xn2"]), _p(s["h"]), _p(s["dgelu"]),
-                          _p(dx), _p(dx16_in), _p(dx16_out), _p(rs_attn), _p(rs_prev))
+                          _p(dx), _p(dx16_in), _p(dx16_out), _p(rs_attn), _p(rs_prev), 1 if defer_dw else 0)
     L.call("sais_vit_block_bwd", ctypes.byref(P), ctypes.byref(a), _p(ws), ws.numel(), _stream())
+    return a
+
+
+def dw_group(dp_hooks=False):
+    """ViT blocks per weight-gradient launch at training size (LABNOTES R6.8).  A launch per block cuts M into ten splits to fill
+    the chip with its 24 tiles; 24 G tiles need 10 / G, and ten blocks none: 187 -> 160 -> 149 us per block.  Default 10 (one launch
+    for blocks 10..1 + the CLS-only block's k / v gradient, one for block 0); 2 when a data-parallel gradient hook waits for the
+    blocks' gradients (they become final G blocks at a time: the all-reduce of a bucket overlaps the backward of the next blocks
+    only if G is small).  SAIS_DW_GROUP overrides (1 = one launch per block, rounds 1-6); read per call: tests switch it."""
+    e = os.environ.get("SAIS_DW_GROUP")
+    g = int(e) if e else (2 if dp_hooks else 10)
+    return max(1, min(g, (L.TN_MAX_ITEMS - 1) // 4))
+
+
+def vit_blocks_dw(pending, extra=()):
+    """The deferred weight / bias gradients of several blocks as ONE grouped launch (sais_vit_blocks_dw); pending = [(P, a, ws)]
+    of vit_block_bwd(..., defer_dw=True) calls; extra = further (p, q, dW, db) items over the same rows."""
+    n = len(pending)
+    Ps = (ctypes.POINTER(L.SaisVitBlockParams) * n)(*[ctypes.pointer(P) for P, _, _ in pending])
+    As = (ctypes.POINTER(L.SaisVitBlockBwd) * n)(*[ctypes.pointer(a) for _, a, _ in pending])
+    Ws = (ctypes.c_void_p * n)(*[_p(ws) for _, _, ws in pending])
+    ex = (L.SaisTnItem * max(1, len(extra)))()
+    for i, (p, q, dW, db) in enumerate(extra):
+        ex[i] = L.SaisTnItem(_p(p), p.stride(0), _p(q), q.stride(0), p.shape[1], q.shape[1], _p(dW), dW.stride(0), _p(db))
+    L.call("sais_vit_blocks_dw", Ps, As, Ws, min(ws.numel() for _, _, ws in pending), n, ex, len(extra), _stream())
 
 
 def temporal_layer_params(f, prefix):

@@ -97,6 +97,7 @@ class GradSync:
         def fn(lo, hi):
             self.flush_temporal()           # the temporal backward is complete once the ViT backward starts
             self._reduce(vit.flat.grad[lo:hi])
+        fn.active = self.active             # an idle hook (world of one) does not ask for early gradients: vit.py, R6.8
         return fn
 
     @staticmethod

@@ -420,11 +420,12 @@ class VisionTransformer(nn.Module):
             self._bp = (key, [ops.vit_block_params(f, j, self.depth) for j in range(self.depth)])
         return self._bp[1][i]
 
-    def _ws(self, op, grp, dev):
-        """Scratch for a block-level call (sais_workspace_bytes), kept per (op, shape) outside hipGraph pools."""
+    def _ws(self, op, grp, dev, slot=0):
+        """Scratch for a block-level call (sais_workspace_bytes), kept per (op, shape, slot) outside hipGraph pools.  slot: the
+        position of a backward call among those whose weight gradients are still to be launched (their scratch must survive)."""
         if torch.cuda.is_current_stream_capturing():
             return ops.block_workspace(op, grp["Fr"], grp["ntok"], dev)
-        key = (op, grp["Fr"], grp["ntok"], str(dev))
+        key = (op, grp["Fr"], grp["ntok"], str(dev), slot)
         if key not in self._wsbuf:
             self._wsbuf[key] = ops.block_workspace(op, grp["Fr"], grp["ntok"], dev)
         return self._wsbuf[key]
@@ -463,7 +464,7 @@ class VisionTransformer(nn.Module):
                     xn2=xn2, dgelu=u, h=h, rs_attn=rs_attn, rs_mlp=rs_mlp, x_out=x_out, meanN=meanN, rstdN=rstdN) if save else None
         return reps, tail
 
-    def _cls_tail_bwd(self, f, saved, dreps, dx, dxa, dqkv, fused):
+    def _cls_tail_bwd(self, f, saved, dreps, dx, dxa, dqkv, fused, defer=None):
         """Backward of _cls_tail_fwd: the gradient enters on the CLS rows only.  Everything row-local stays on [frames, 384]
         tensors; the attention backward (sais_vit_attn_cls_bwd) writes the whole dqkv (dk, dv of every token, dq of the CLS
         rows, zeros elsewhere); the dX of qkv + norm1's backward then writes EVERY row of dx / dxa, taking the residual-stream
@@ -503,7 +504,11 @@ class VisionTransformer(nn.Module):
             Fr, ntok = groups[0]["Fr"], groups[0]["ntok"]
             compact.append((dqkv.view(Fr, ntok, 3 * D)[:, 0, :D], s["xn1"].view(Fr, ntok, D)[:, 0], gW[:D], gb[:D]))
             ops.gemm_tn_grouped(compact, Ftot)
-            ops.gemm_tn_grouped([(dqkv[:, D:], s["xn1"], gW[D:], gb[D:])], M)
+            kv = (dqkv[:, D:], s["xn1"], gW[D:], gb[D:])
+            if defer is not None:                     # rides in the first grouped launch of the blocks below (4 more tiles)
+                defer.append(kv)
+            else:
+                ops.gemm_tn_grouped([kv], M)
         else:
             ops.gemm_tn_grouped(compact, Ftot)
             ops.gemm_tn_grouped([(dqkv, s["xn1"], gW, gb)], M)
@@ -529,7 +534,7 @@ class VisionTransformer(nn.Module):
                               dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"),
                               rowscale16=rs_prev)
         saved["blocks"][i] = None
-        if self.grad_ready_hook:
+        if self.grad_ready_hook:                      # (with a hook nothing of this block is deferred: _backward_kernels)
             self.grad_ready_hook(*self.block_grad_range(i))
 
     # ------------------------------------------------------------------ backward kernels
@@ -542,10 +547,21 @@ class VisionTransformer(nn.Module):
         pruned = bool(saved.get("pruned"))
         fused = M >= ops.ROW_GEMM_MIN_M
         dxa, dxb = e16(M, D), e16(M, D)            # bf16 copies of the residual-stream gradient (block input / mid)
+        # Weight gradients of G blocks in ONE grouped launch (LABNOTES R6.8): a block's dW needs ten M-splits to fill the chip with
+        # its 24 tiles, each split writing a partial tile that a second launch sums; 24 G tiles need 10 / G.  The operands of a
+        # deferred block (its du / d(mid) / dqkv, the bf16 gradient that entered it, the saved activations) stay alive until then.
+        G = 1
+        # a data-parallel hook that all-reduces the blocks' gradients while the backward goes on (an idle one — GradSync in a world
+        # of one — carries active = False)
+        hooked = self.grad_ready_hook is not None and getattr(self.grad_ready_hook, "active", True)
+        if fused and len(groups) == 1 and not ops.mlp_fused_enabled(M):
+            G = ops.dw_group(dp_hooks=hooked)
+        pend_extra = []
         if pruned:                                  # every row of dx is WRITTEN by the last block's dX qkv + norm1' kernel
             dx = torch.empty(M, D, dtype=torch.float32, device=dev)
             dqkv0 = e16(M, 3 * D)
-            self._cls_tail_bwd(f, saved, dreps, dx, dxa, dqkv0, fused)
+            self._cls_tail_bwd(f, saved, dreps, dx, dxa, dqkv0, fused,
+                               defer=pend_extra if G > 1 and not hooked else None)
         else:
             dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         for g in ([] if pruned else groups):
@@ -567,6 +583,21 @@ class VisionTransformer(nn.Module):
         dqkv = dqkv0 if pruned else e16(M, 3 * D)
         if self.grad_ready_hook and not pruned:
             self.grad_ready_hook(f.offsets["norm.weight"], f.numel)
+        pend_calls, pend_items, pend_blocks = [], [], []
+
+        def flush_dw():
+            if pend_calls:
+                ops.vit_blocks_dw([c[:3] for c in pend_calls], extra=pend_extra)
+                pend_extra.clear()
+            if pend_items:
+                ops.gemm_tn_grouped(pend_items + pend_extra, M)
+                pend_extra.clear()
+            for j in pend_blocks:
+                saved["blocks"][j] = None
+                if self.grad_ready_hook:              # the block's gradient slice is final: DP all-reduce may start
+                    self.grad_ready_hook(*self.block_grad_range(j))
+            pend_calls.clear(); pend_items.clear(); pend_blocks.clear()
+
         for i in reversed(range(self.depth - 1 if pruned else self.depth)):
             p = f"blocks.{i}."
             s = saved["blocks"][i]
@@ -574,12 +605,25 @@ class VisionTransformer(nn.Module):
             rs_prev = None if dp is None or i == 0 else dp[2 * (i - 1) + 1]     # the MLP branch of block i - 1
             if self.block_calls and ops.TIMER is None and len(groups) == 1 and fused and not ops.mlp_fused_enabled(M):
                 g0 = groups[0]
+                if G > 1:
+                    dxa_out = e16(M, D)
+                    ws = self._ws(L.OP_VIT_BLOCK_BWD, g0, dev, slot=len(pend_calls))
+                    a = ops.vit_block_bwd(self._block_params(i), g0["Fr"], g0["ntok"], s, dx, dxa, dxa_out, rs_attn, rs_prev,
+                                          s["lse"][0], ws, defer_dw=True)
+                    pend_calls.append((self._block_params(i), a, ws, dxa, s))          # dxa, s: kept alive for the launch
+                    pend_blocks.append(i)
+                    dxa = dxa_out
+                    if len(pend_blocks) == G or i == 0:
+                        flush_dw()
+                    continue
                 ops.vit_block_bwd(self._block_params(i), g0["Fr"], g0["ntok"], s, dx, dxa, dxa, rs_attn, rs_prev, s["lse"][0],
                                   self._ws(L.OP_VIT_BLOCK_BWD, g0, dev))
                 saved["blocks"][i] = None
                 if self.grad_ready_hook:
                     self.grad_ready_hook(*self.block_grad_range(i))
                 continue
+            if G > 1:                                 # per-launch path with deferred dW: this block's gradient tensors are its own
+                du, dqkv, dxb = e16(M, HID), e16(M, 3 * D), e16(M, D)
             # MLP branch
             if fused and ops.mlp_fused_enabled(M):    # dX of fc2 x GELU' -> dX of fc1 -> norm2's backward: ONE launch
                 ops.mlp_bwd(dxa, f.wt16[p + "mlp.fc2.weight"], s["dgelu"], f.wt16[p + "mlp.fc1.weight"], du, s["x_mid"],
@@ -604,11 +648,16 @@ class VisionTransformer(nn.Module):
                 ops.vit_attn_bwd(s["qkv"][lo:hi], dao[lo:hi], s["ao"][lo:hi], lg, None, Fr, dqkv[lo:hi], ntok=ntok)
             # all four weight / bias gradients of the block in one launch.  (A side stream for this launch was measured
             # in round 1: 20.4 vs 19.6 ms/step — both kernels fill the chip — and removed.)
-            ops.gemm_tn_grouped([
-                (dxa, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
-                (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
-                (dxb, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias")),
-                (dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))], M)
+            dw = [(dxa, s["h"], f.g(p + "mlp.fc2.weight"), f.g(p + "mlp.fc2.bias")),
+                  (du, s["xn2"], f.g(p + "mlp.fc1.weight"), f.g(p + "mlp.fc1.bias")),
+                  (dxb, s["ao"], f.g(p + "attn.proj.weight"), f.g(p + "attn.proj.bias")),
+                  (dqkv, s["xn1"], f.g(p + "attn.qkv.weight"), f.g(p + "attn.qkv.bias"))]
+            if G > 1:
+                pend_items += dw
+                pend_blocks.append(i)
+                dxa = e16(M, D)                       # norm1's backward writes the NEXT block's bf16 gradient beside this one's
+            else:
+                ops.gemm_tn_grouped(dw, M)
             if fused:         # dX of qkv with norm1's backward in its epilogue
                 ops.gemm_ln_bwd(dqkv, f.wt16[p + "attn.qkv.weight"], s["x_in"], s["mean1"], s["rstd1"],
                                 f.w32(p + "norm1.weight"), dres=dx, dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"),
@@ -618,9 +667,16 @@ class VisionTransformer(nn.Module):
                 ops.layernorm_bwd(s["x_in"], D, s["mean1"], s["rstd1"], f.w32(p + "norm1.weight"), M, dy16=dxn, dres=dx,
                                   dx32=dx, dx16=dxa, dgamma=f.g(p + "norm1.weight"), dbeta=f.g(p + "norm1.bias"),
                                   rowscale16=rs_prev)
+            if G > 1:
+                if len(pend_blocks) == G or i == 0:
+                    flush_dw()
+                continue
             saved["blocks"][i] = None
             if self.grad_ready_hook:                  # the block's gradient slice is final: DP all-reduce may start
                 self.grad_ready_hook(*self.block_grad_range(i))
+        flush_dw()
+        if pend_extra:                                # (no block below the CLS-only one: depth 1)
+            ops.gemm_tn_grouped(pend_extra, M)
         dpatch = e16(saved["patches"].shape[0], D)
         for g in groups:
             Fr, ntok, lo, po = g["Fr"], g["ntok"], g["off"], g["poff"]

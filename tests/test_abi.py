@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib.sais_abi_version.restype = ctypes.c_int
-    assert lib.sais_abi_version() == 12
+    assert lib.sais_abi_version() == 13
     assert lib.sais_gelu_grad_bytes() == 1                       # GELU' of the block API as one-byte codes by default
 
 

@@ -459,6 +459,37 @@ def test_block_level_c_calls_equal_the_per_launch_sequence(gpu, rate, train):
         assert float((g1 - g0).norm() / g0.norm()) <= 1e-5
 
 
+@pytest.mark.parametrize("frames,prune", [(128, True), (64, False)])
+def test_grouped_weight_gradient_launches_equal_one_per_block(gpu, monkeypatch, frames, prune):
+    """SAIS_DW_GROUP = G (LABNOTES R6.8): the weight / bias gradients of G blocks in ONE grouped launch (sais_vit_blocks_dw; the
+    operands of a deferred block — its own du / d(mid) / dqkv, the bf16 gradient that entered it — stay alive until then) must equal
+    one launch per block up to fp32 summation order (the number of M-splits changes with G), on both backward paths: the block-level
+    C calls and the per-launch Python sequence.  depth 5, DropPath on: groups of 2 + 2 + 1 (or 2 + 2 with the pruned last block),
+    of 4 + 1, of 5.  128 frames = 788 steps of 32 rows (the 192 x 384 kernel at every G), 64 frames = 394 (G = 1 falls back)."""
+    from sais_amd.vit import vit_small
+
+    def run(G, block_calls):
+        monkeypatch.setenv("SAIS_DW_GROUP", str(G))
+        v = vit_small(patch_size=16, drop_path_rate=0.2, depth=5)
+        v.load_state_dict(synth.vit_state_dict(seed=0, depth=5), strict=True)
+        v = v.to(DEV).train()
+        v.block_calls = block_calls
+        v.prune_last_block = prune
+        v.drop_path_seed = 9
+        x = synth.clips(seed=961, B=1, T=frames)[0].to(DEV)
+        w = synth.reps(seed=962, B=1, T=frames)[0, 0].to(DEV)
+        feat = v(x)
+        (feat * w).sum().backward()
+        return feat.detach(), v.flat.grad.clone()
+
+    f_ref, g_ref = run(1, True)
+    assert float(g_ref.abs().max()) > 0
+    for G, bc in ((2, True), (4, True), (10, True), (2, False), (5, False)):
+        f, g = run(G, bc)
+        assert torch.equal(f, f_ref)
+        assert float((g - g_ref).norm() / g_ref.norm()) <= 1e-5, (G, bc)
+
+
 @pytest.mark.parametrize("frames,rate", [(6, 0.0), (48, 0.2)])
 def test_pruned_last_block_equals_full_compute(gpu, frames, rate):
     """forward() returns norm(x)[:, 0]: the last block runs on the CLS rows / the CLS query only (sais_amd.vit,

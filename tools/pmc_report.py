@@ -75,7 +75,12 @@ def collect(folder):
                 agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 continue
             if n == "gemm_tn_grouped[xl]":
-                n = "gemm_tn_grouped"
+                # launches of different sizes share the kernel (R6.8: blocks 10..1 + the k / v gradient in one launch of 244
+                # workgroups, block 0 in one of 24 tiles x 10 splits): families by workgroup count, as bench.py keys them
+                try:
+                    n = "gemm_tn_grouped[%d wg]" % (int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
+                except (KeyError, ValueError, ZeroDivisionError):
+                    n = "gemm_tn_grouped"
                 agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 continue
             if n in ROW_K_PATTERN:
@@ -146,14 +151,16 @@ def main():
         tr[n] = {"hbm_bytes_per_launch": int((2 * f + w) * 1024), "fetch_kb_raw": int(f), "write_kb": int(w),
                  "launches_sampled": len(fetch[n].get("FETCH_SIZE", [])),
                  "note": "separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled (gfx950 correction)"}
-    if "gemm_tn_grouped[finish]" in tr and "gemm_tn_grouped" in tr:
-        # bench.py times the dW launch PAIR (partial tiles + finish) under one tag: report the pair's bytes there too
-        tr["gemm_tn_grouped"]["hbm_bytes_per_launch_kernel_only"] = tr["gemm_tn_grouped"]["hbm_bytes_per_launch"]
-        tr["gemm_tn_grouped"]["hbm_bytes_per_launch"] += tr["gemm_tn_grouped[finish]"]["hbm_bytes_per_launch"]
-        tr["gemm_tn_grouped"]["note"] += "; = 192 x 384 kernel + its finish launch (the pair bench.py times under this tag)"
-    # whole-step HBM bytes by counters: launches per step x bytes per launch over every family that was matched (steps in
-    # the profiled run = dW launches / 12 blocks)
-    nsteps = max(1, len(fetch.get("gemm_tn_grouped", {}).get("FETCH_SIZE", [])) // 11)
+    # the launches that cut M into splits (240 workgroups = 24 tiles x 10, 48 x 5, ...) are followed by a finish launch, and bench.py
+    # times the PAIR under one tag: report the pair's bytes there too
+    pair = next((k for k in ("gemm_tn_grouped[240 wg]", "gemm_tn_grouped") if k in tr), None)
+    if "gemm_tn_grouped[finish]" in tr and pair:
+        tr[pair]["hbm_bytes_per_launch_kernel_only"] = tr[pair]["hbm_bytes_per_launch"]
+        tr[pair]["hbm_bytes_per_launch"] += tr["gemm_tn_grouped[finish]"]["hbm_bytes_per_launch"]
+        tr[pair]["note"] += "; = 192 x 384 kernel + its finish launch (the pair bench.py times under this tag)"
+    # whole-step HBM bytes by counters: launches per step x bytes per launch over every family that was matched (steps in the
+    # profiled run = launches of the CLS-only block's compact dW, one per step)
+    nsteps = max(1, len(fetch.get("gemm_tn_grouped[compact]", {}).get("FETCH_SIZE", [])))
     per_step = {n: round(v["launches_sampled"] / nsteps, 2) for n, v in tr.items()}
     step_bytes = sum(tr[n].get("hbm_bytes_per_launch_kernel_only", tr[n]["hbm_bytes_per_launch"]) * per_step[n] for n in tr)
     tr["_step"] = {"step_hbm_bytes": int(step_bytes), "steps_profiled": nsteps, "launches_per_step": per_step,
