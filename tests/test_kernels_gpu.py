@@ -587,7 +587,8 @@ def test_gemm_tn_grouped_large_tile_exact_integers_and_bitwise_repeatable(ops):
     (197 * 512, [(384, 1536), (1536, 384)]),                                # config 4's M = 100 864: 16 tiles x 16 splits of 197
     (197 * 256, [(768, 384)]),                                              # the pruned block's k/v-only launch: 4 tiles, 64 splits < 48 steps: falls back
     (197 * 256, [(384, 384), (384, 768), (768, 1152)]),                     # uneven tile counts per item: 2 + 4 + 12 = 18 tiles x 14 splits
-])
+    (197 * 64, [(384, 1536), (1536, 384), (384, 384), (1152, 384)] * 6 + [(768, 384)]),   # R6.8: six blocks + the k / v item = 148 tiles, ONE
+])                                                                          # split: every tile has one owner (plain read-add-write)
 def test_gemm_tn_grouped_large_tile_strided_views_and_accumulation(ops, M, shapes):
     """The large-tile dW kernel over what its callers hand it: P / Q as column slices of wider buffers (leading dimension > N, base
     pointer 16-B but not 128-B aligned), dW as a slice of a wider gradient buffer, a SECOND call that must add to the first (+=), db
