@@ -16,6 +16,11 @@ for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             n = timer_name(r["Kernel_Name"])
+            if n == "gemm_tn_grouped[xl]":       # launches of different sizes share the kernel: families by workgroup count (pmc_report.py)
+                try:
+                    n = "gemm_tn_grouped[%d wg]" % (int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
+                except (KeyError, ValueError, ZeroDivisionError):
+                    pass
             if n:
                 agg[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
