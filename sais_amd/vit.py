@@ -554,7 +554,7 @@ class VisionTransformer(nn.Module):
         # a data-parallel hook that all-reduces the blocks' gradients while the backward goes on (an idle one — GradSync in a world
         # of one — carries active = False)
         hooked = self.grad_ready_hook is not None and getattr(self.grad_ready_hook, "active", True)
-        if fused and len(groups) == 1 and not ops.mlp_fused_enabled(M):
+        if fused and M % 32 == 0 and not ops.mlp_fused_enabled(M):      # (several resolution groups: the per-launch path below)
             G = ops.dw_group(dp_hooks=hooked)
         pend_extra = []
         if pruned:                                  # every row of dx is WRITTEN by the last block's dX qkv + norm1' kernel

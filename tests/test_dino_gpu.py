@@ -360,7 +360,9 @@ def test_graphed_train_step_equals_eager():
     assert sg == se == [5, 2]
     for it, ((lg, ng, cg), (le, ne, ce)) in enumerate(zip(rg, re_)):
         assert abs(lg - le) <= 2e-5 * abs(le), (it, lg, le)
-        assert rel(ng, ne) < 1e-3, (it, rel(ng, ne))
+        # the two runs' weights part by up to 2 lr per element and step (below), so their gradients part a little more with every
+        # step: 1.06e-3 at iteration 4 in one run of six on one box (fp32 atomics order), 3-7e-4 otherwise
+        assert rel(ng, ne) < 1e-3 * (1 + it), (it, rel(ng, ne))
         assert float((cg - ce).abs().max()) <= 1e-6 + 1e-3 * float(ce.abs().max()), it      # the weights drift apart by ~lr (below)
     for n in pe:
         # AdamW moves an element by ~lr whatever the gradient's size: where the sign of a rounding-noise gradient differs between
